@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- MAP gradient iterations/s of the MI355X-native path.
+
+One "step" = one MAP gradient iteration = one ObjectiveFunction::ComputeAllTerms
+(data term over all K frames + IRLS-weighted regulariser, cost and gradient,
+reference src/optimization/objective_function.cpp:5-20) on device-resident
+synthetic inputs.
+
+N = 1 workload: BASELINE.json configs[1] -- 16-frame grayscale, 4x upscale to
+2048x2048 HR, Gaussian blur (3, sigma 1) + BTV (range 3, decay 0.5, lambda 0.01).
+N > 1 (one process per GPU, torch.distributed over RCCL): the path shards by
+channel (the reference's split_channels semantics, irls_map_solver.cpp:200-262):
+rank r owns channel r of an N-channel problem of the same per-channel geometry,
+so per-GPU work is fixed ("weak" scaling); the only exchange of a joint solve
+is the all-reduce of the scalar cost, which is issued every step over RCCL.
+`value` counts channel-iterations per second summed over ranks (at N = 1 this is
+plain iterations per second).  `--shard frames` runs the north-star's
+frame-sharded variant instead (each rank K/N frames of the SAME image + RCCL
+all-reduce of the HR gradient), reported as strong scaling.
+
+Prints ONE JSON line on rank 0 (see the task contract), including
+  "roofline":     algorithmic bytes of one step / mean step time vs 8 TB/s HBM
+  "cpu_baseline": the CPU oracle (a port of the reference, oracle/) timed on
+                  this host on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_ground_truth(W, H, C):
+    """smooth + edges, channel scaled."""
+    u, v = np.meshgrid((np.arange(W) + 0.5) / W, (np.arange(H) + 0.5) / H)
+    base = 0.5 + 0.25 * np.sin(2 * np.pi * 3 * u) * np.cos(2 * np.pi * 5 * v) \
+        + 0.25 * (((u - .5) ** 2 + (v - .5) ** 2) < .09)
+    base = np.clip(base, 0, 1)
+    scale = [(0.6 + 0.4 * c / (C - 1)) if C > 1 else 1.0 for c in range(C)]
+    return np.stack([base * s for s in scale])
+
+
+def bilinear_upsample(img, s):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(img))[None]
+    return torch.nn.functional.interpolate(t, scale_factor=s, mode="bilinear", align_corners=False)[0].numpy()
+
+
+def cpu_baseline(cfg, lr, x0, wts, budget_s=20.0):
+    """Oracle (CPU restatement of the reference, 1 thread like the reference) on
+    a bounded crop of the same workload, scaled by pixel count."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    s, K = cfg["scale"], cfg["frames"]
+    crop_lr = 128  # LR crop 128x128 -> HR 512x512: 1/16 of the cfg2 pixels
+    crop_lr = min(crop_lr, lr.shape[-1])
+    ch = crop_lr * s
+    model = orc.ImageModel(scale=s, shifts=cfg["shifts"], blur_ksize=cfg["blur"][0], blur_sigma=cfg["blur"][1])
+    prob = orc.Problem(model, lr[:, :1, :crop_lr, :crop_lr])
+    prob.add_regularizer(orc.REG_BTV, cfg["lambda"], cfg["btv"][0], cfg["btv"][1])
+    prob.set_irls_weights(0, wts[:1, :ch, :ch])
+    x = np.ascontiguousarray(x0[:1, :ch, :ch])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        prob.objective(x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 5:
+            break
+    per_eval_crop = el / n
+    frac = (ch * ch) / float(cfg["W"] * cfg["H"])
+    per_eval_full = per_eval_crop / frac
+    return {"value": 1.0 / per_eval_full, "unit": "MAP gradient iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d evaluations of a %dx%d HR crop (%d frames, same blur/BTV), %.2f s each, scaled by "
+                      "pixel count x%.0f to the full %dx%d" % (n, ch, ch, K, per_eval_crop, 1 / frac, cfg["W"], cfg["H"]),
+            "ms_per_step": per_eval_full * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="arithmetic/storage type on device (the reference is f64)")
+    ap.add_argument("--shard", choices=["channels", "frames"], default="channels")
+    ap.add_argument("--impl", choices=["auto", "direct", "tiled"], default="auto")
+    ap.add_argument("--hr", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import srmap
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    s, K = 4, 16
+    W = H = args.hr
+    w, h = W // s, H // s
+    shifts_all = [[k % s, (k // s) % s] for k in range(K)]
+    cfg = {"W": W, "H": H, "scale": s, "frames": K, "shifts": shifts_all, "blur": (3, 1.0),
+           "btv": (3, 0.5), "lambda": 0.01}
+    dtype = srmap.F64 if args.dtype == "f64" else srmap.F32
+    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
+    E = 8 if args.dtype == "f64" else 4
+
+    frame_ids = list(range(K))
+    units_per_step = 1.0
+    if world > 1 and args.shard == "frames":
+        frame_ids = [k for k in range(K) if k % world == rank]
+    shifts = [shifts_all[k] for k in frame_ids]
+    Kloc = len(frame_ids)
+
+    ctx = srmap.Context(local_rank)
+    prob = srmap.Problem(ctx, W, H, 1, Kloc, s, shifts, 3, 1.0, dtype)
+    prob.set_impl({"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED}[args.impl])
+
+    # ---- synthetic data, seeded; channel = rank under channel sharding
+    rng = np.random.default_rng(20240607 + (rank if args.shard == "channels" else 0))
+    gt = synth_ground_truth(W, H, max(world, 1) if args.shard == "channels" else 1)
+    gt = gt[rank:rank + 1] if args.shard == "channels" and world > 1 else gt[:1]
+    lr = np.stack([prob.apply(gt, i) for i in range(Kloc)])
+    noise_rng = np.random.default_rng(777 + rank)
+    lr = lr + (5.0 / 255.0) * noise_rng.standard_normal(lr.shape)
+    prob.set_observations(lr)
+    reg = prob.add_regularizer(srmap.REG_BTV, cfg["lambda"], 3, 0.5)
+    x0 = bilinear_upsample(lr[0], s)
+    r0 = prob.reg_values(reg, x0)
+    wts = 1.0 / np.maximum(1e-5, r0)
+    prob.set_irls_weights(reg, wts)
+
+    x_dev = torch.from_numpy(x0).to(dev, tdtype).contiguous()
+    g_dev = torch.empty_like(x_dev)
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+    cost_buf = torch.zeros(1, dtype=torch.float64, device=dev)
+    terms = srmap.TERM_ALL
+    if world > 1 and args.shard == "frames" and rank != 0:
+        terms = srmap.TERM_DATA  # the regulariser term is evaluated once (rank 0)
+
+    def step():
+        prob.eval_device(x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
+        if dist is not None:
+            with torch.cuda.stream(stream):
+                if args.shard == "frames":
+                    dist.all_reduce(g_dev)          # HR gradient all-reduce over RCCL/xGMI
+                dist.all_reduce(cost_buf)           # scalar cost of the joint objective
+
+    def barrier():
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    with torch.cuda.stream(stream):
+        ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
+
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+    ms_per_step = wall / args.steps * 1e3
+    if world > 1 and args.shard == "channels":
+        units_per_step = float(world)
+    value = units_per_step * args.steps / wall
+
+    if rank == 0:
+        C_total = world if (world > 1 and args.shard == "channels") else 1
+        N, n = W * H, w * h
+        rho = 1
+        b_alg = E * C_total * ((2 + rho) * N + K * n)  # x, y, w read once, g written once
+        step_dev_s = dev_ms / args.steps * 1e-3
+        achieved = (b_alg / max(C_total, 1)) / step_dev_s / 1e9  # per GPU
+        out = {
+            "metric": "MAP gradient iterations/sec at fixed HR size",
+            "value": value,
+            "unit": "MAP gradient iterations/s" if C_total == 1 else "channel-iterations/s (one 16-frame 2048^2 channel per GPU)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if (world > 1 and args.shard == "frames") else "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: 16-frame grayscale, 4x upscale to %dx%d, Gaussian blur 3/1.0 + BTV(3,0.5) "
+                                   "lambda 0.01, IRLS weights from x0" % (W, H),
+                       "frames": K, "scale": s, "channels": C_total, "shard": args.shard if world > 1 else "none",
+                       "impl": args.impl, "device_ms_per_step": dev_ms / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_step": b_alg / max(C_total, 1),
+                         "kernel": "whole evaluation (all kernels of one step), HIP events on the launch stream"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, lr, x0, wts)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+/*
+ * srmap.h -- C ABI of libsrmap.so: the MI355X-native (HIP, gfx950) MAP
+ * super-resolution gradient path.
+ *
+ * This is the drop-in boundary for ONE path of rteammco/super-resolution: the
+ * per-iteration MAP cost + gradient (ObjectiveFunction::ComputeAllTerms) and
+ * the operators and solver loop around it.  The reference has no FFI of its
+ * own -- the path sits behind plain C++ virtual interfaces -- so every entry
+ * point below names the reference interface it replaces (file:line relative to
+ * the reference repository), and super-resolution_amd/host/ holds C++ classes
+ * with the reference's names that forward here.
+ *
+ * Conventions
+ *   - every function returns an srmap_status (0 = ok); nothing aborts or throws
+ *     across the ABI; srmap_last_error() gives the message.  The reference's
+ *     CHECK-class violations (glog abort) map to SRMAP_EINVAL.
+ *   - images are planar [C][H][W], index c*W*H + row*W + col (util.cpp:81-89);
+ *     LR stacks are [K][C][h][w].  Host buffers are IEEE double, owned by the
+ *     caller.  Device buffers passed to *_device entry points hold the
+ *     problem's dtype (double or float) and are owned by the caller.
+ *   - one context = one GPU (one process per GPU); a problem is used from one
+ *     host thread at a time.
+ *   - there is no CPU fallback: without a usable HIP device every entry point
+ *     that computes fails with SRMAP_EHIP.
+ */
+#ifndef SRMAP_H_
+#define SRMAP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srmap_ctx srmap_ctx;
+typedef struct srmap_problem srmap_problem;
+
+typedef enum {
+  SRMAP_OK = 0,
+  SRMAP_EINVAL = 1,       /* a reference CHECK would have fired */
+  SRMAP_ENOMEM = 2,
+  SRMAP_EHIP = 3,         /* HIP runtime / device error */
+  SRMAP_EUNSUPPORTED = 4  /* valid for the reference, not representable here */
+} srmap_status;
+
+typedef enum { SRMAP_F64 = 0, SRMAP_F32 = 1 } srmap_dtype;
+
+/* Regularizer kinds: TotalVariationRegularizer (tv_regularizer.h),
+ * the same with SetUse3dTotalVariation(true), and
+ * BilateralTotalVariationRegularizer (btv_regularizer.h). */
+typedef enum { SRMAP_REG_TV = 0, SRMAP_REG_TV3D = 1, SRMAP_REG_BTV = 2 } srmap_reg_kind;
+
+/* Which ObjectiveTerms an evaluation includes (objective_function.h:18-26). */
+enum {
+  SRMAP_TERM_DATA = 1u,  /* ObjectiveDataTerm */
+  SRMAP_TERM_REG = 2u,   /* every ObjectiveIRLSRegularizationTerm */
+  SRMAP_TERM_ALL = 3u
+};
+
+/* Kernel family selection (for tests and A/B measurements; AUTO picks the
+ * LDS-tiled kernels whenever the problem geometry admits them). */
+typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2 } srmap_impl;
+
+/* ---------------------------------------------------------------- context */
+/* Binds HIP device `device_id`.  Replaces nothing in the reference (it has no
+ * device notion); it is what a maintainer creates once per process. */
+int srmap_ctx_create(int device_id, srmap_ctx** out);
+void srmap_ctx_destroy(srmap_ctx* ctx);
+const char* srmap_last_error(const srmap_ctx* ctx);
+/* Library/version string, e.g. "srmap 0.1 (gfx950)". */
+const char* srmap_version(void);
+
+/* ---------------------------------------------------------------- problem */
+/* ImageModelParameters + MapSolver geometry: image_model.h:26-44,
+ * ImageModel::CreateImageModel image_model.cpp:17-61, MapSolver::MapSolver
+ * map_solver.cpp:52-86. */
+typedef struct {
+  int hr_width, hr_height;  /* HR image size (= LR size * scale when solving) */
+  int channels;             /* C */
+  int frames;               /* K observations / motion shifts */
+  int scale;                /* DownsamplingModule scale >= 1 */
+  const double* shifts_xy;  /* K x (dx, dy) MotionShift; NULL = no MotionModule */
+  int blur_ksize;           /* BlurModule "blur_radius" = kernel size (odd);
+                               0 (or sigma <= 0) = no BlurModule */
+  double blur_sigma;
+  int dtype;                /* srmap_dtype: arithmetic/storage type on device */
+} srmap_problem_desc;
+
+int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* desc,
+                         srmap_problem** out);
+void srmap_problem_destroy(srmap_problem* p);
+int srmap_problem_set_impl(srmap_problem* p, int impl /* srmap_impl */);
+
+/* LR size the model produces: (int)(len * (1.0/scale)),
+ * DownsamplingModule::ApplyToImage downsampling_module.cpp:19-27. */
+int srmap_problem_lr_size(const srmap_problem* p, int* lr_width, int* lr_height);
+
+/* MapSolver's low_res_images (map_solver.cpp:52-86): [K][C][h][w] doubles at LR
+ * resolution.  (The reference stores them NN-upsampled to HR; this library
+ * keeps LR and accounts for the s*s replication arithmetically.)  Requires
+ * hr size == lr size * scale. */
+int srmap_set_observations(srmap_problem* p, const double* lr_host);
+/* Same from a device buffer holding the problem dtype. */
+int srmap_set_observations_device(srmap_problem* p, const void* lr_dev);
+
+/* MapSolver::AddRegularizer(regularizer, regularization_parameter)
+ * map_solver.cpp:88-94; constructors tv_regularizer.h / btv_regularizer.cpp
+ * :50-65 (range >= 1, 0 < decay <= 1).  Gradients are bug-compatible with the
+ * reference.  *reg_index receives the handle. */
+int srmap_add_regularizer(srmap_problem* p, int kind, double lambda,
+                          int btv_range, double btv_decay, int* reg_index);
+int srmap_clear_regularizers(srmap_problem* p);
+/* The irls_weights_ vector an ObjectiveIRLSRegularizationTerm holds
+ * (objective_irls_regularization_term.h:40); NULL = all ones. */
+int srmap_set_irls_weights(srmap_problem* p, int reg, const double* w_host);
+/* w = 1 / max(1e-5, regularizer(x)) on device, irls_map_solver.cpp:128-143. */
+int srmap_update_irls_weights_device(srmap_problem* p, int reg, const void* x_dev);
+
+/* ------------------------------------------------------- operators (host) */
+/* ImageModel::ApplyToImage(ImageData*, index) image_model.cpp:86-91:
+ * hr [C][H][W] -> lr [C][h][w]. */
+int srmap_apply(srmap_problem* p, int frame, const double* hr, double* lr);
+/* ImageModel::ApplyTransposeToImage image_model.cpp:93-101:
+ * lr [C][h][w] -> hr [C][h*s][w*s]. */
+int srmap_apply_transpose(srmap_problem* p, int frame, const double* lr, double* hr);
+/* Regularizer::ApplyToImage regularizer.h:13-30 (values only). */
+int srmap_reg_values(srmap_problem* p, int reg, const double* x, double* values);
+/* Regularizer::ApplyToImageWithDifferentiation regularizer.h:32-45: values and
+ * the gradient for the given per-pixel gradient_constants. */
+int srmap_reg_values_and_gradient(srmap_problem* p, int reg, const double* x,
+                                  const double* gradient_constants,
+                                  double* values, double* gradient);
+
+/* ---------------------------------------------------------- objective */
+/* ObjectiveFunction::ComputeAllTerms(x, gradient) objective_function.cpp:5-20
+ * restricted to `terms`: zeroes the gradient, then adds the selected terms.
+ * grad may be NULL (cost only, objective_function.h:23). */
+int srmap_eval(srmap_problem* p, unsigned terms, const double* x, double* cost,
+               double* grad);
+/* Device-resident form: x_dev / g_dev hold the problem dtype ([C][H][W]).
+ * Work is enqueued on `hip_stream` (NULL = the context's stream).  When
+ * cost != NULL the call synchronises the stream and returns the cost; when
+ * cost == NULL it returns right after enqueueing (the cost stays on device
+ * until srmap_last_cost()). */
+int srmap_eval_device(srmap_problem* p, unsigned terms, const void* x_dev,
+                      void* g_dev, double* cost, void* hip_stream);
+int srmap_last_cost(srmap_problem* p, double* cost);
+
+/* Device memory helpers for C/C++ hosts that do not bring their own allocator
+ * (element = the problem dtype). */
+int srmap_device_alloc(srmap_ctx* ctx, size_t bytes, void** dev);
+int srmap_device_free(srmap_ctx* ctx, void* dev);
+int srmap_upload(srmap_problem* p, const double* host, void* dev, size_t count);
+int srmap_download(srmap_problem* p, const void* dev, double* host, size_t count);
+int srmap_synchronize(srmap_ctx* ctx);
+
+/* ------------------------------------------------------------- solver */
+/* IRLSMapSolverOptions (irls_map_solver.h:14-36) + MapSolverOptions
+ * (map_solver.h:28-79); srmap_irls_options_default() fills the reference
+ * defaults.  Only CG with analytic differentiation is provided
+ * (alglib_objective.cpp:47-75); L-BFGS / numeric differentiation are test-only
+ * alternatives in the reference and are out of scope. */
+typedef struct {
+  int max_num_solver_iterations;         /* 50 */
+  double gradient_norm_threshold;        /* 1e-6 */
+  double cost_decrease_threshold;        /* 1e-6 */
+  double parameter_variation_threshold;  /* 1e-6 */
+  int split_channels;                    /* 0 */
+  int max_num_irls_iterations;           /* 20 */
+  double irls_cost_difference_threshold; /* 1e-5 */
+} srmap_irls_options;
+void srmap_irls_options_default(srmap_irls_options* o);
+
+typedef struct {
+  int irls_rounds;
+  int cg_iterations;
+  int evaluations;       /* cost+gradient evaluations ("MAP gradient iterations") */
+  int last_termination;  /* ALGLIB-style code of the last CG run */
+  double final_cost;
+} srmap_solve_report;
+
+/* Hook for multi-GPU solves where each rank holds a shard of the unknowns
+ * (channel or row sharding): sums `n` doubles in place across ranks.  NULL for
+ * single-GPU solves. */
+typedef void (*srmap_allreduce_fn)(double* values, int n, void* user);
+
+/* IRLSMapSolver::Solve(initial_estimate) irls_map_solver.cpp:192-265:
+ * x0 / x_out are [C][H][W] host doubles.  The iterate, gradient and CG vectors
+ * stay on the GPU; only scalars cross PCIe per evaluation. */
+int srmap_solve(srmap_problem* p, const srmap_irls_options* options,
+                const double* x0, double* x_out, srmap_solve_report* report);
+int srmap_solve_ex(srmap_problem* p, const srmap_irls_options* options,
+                   const double* x0, double* x_out, srmap_solve_report* report,
+                   srmap_allreduce_fn allreduce, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* SRMAP_H_ */

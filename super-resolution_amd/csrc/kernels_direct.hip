@@ -1,0 +1,396 @@
+// kernels_direct.hip -- straightforward gfx950 kernels for every operator of
+// the MAP gradient path: one thread per output element, inputs read through
+// L1/L2.  They accept every geometry the reference accepts (arbitrary shifts,
+// blur sizes, non-divisible HR sizes for ImageModel::ApplyToImage) and serve
+//   (a) the operator entry points (srmap_apply, srmap_apply_transpose,
+//       srmap_reg_values, srmap_reg_values_and_gradient), and
+//   (b) the fallback of srmap_eval when the LDS-tiled kernels
+//       (kernels_tiled.hip) do not cover the geometry, and their cross-check.
+//
+// Math: SURVEY.md section 8(a'); reference lines are cited per kernel.
+#include "srmap_internal.hpp"
+
+namespace srmap {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in thread 0.
+__device__ __forceinline__ double block_sum_256(double v, double* smem4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) smem4[wid] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) r = (smem4[0] + smem4[1]) + (smem4[2] + smem4[3]);
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ WarpTaps<T> identity_warp() {
+  WarpTaps<T> w;
+  w.ox = 0; w.oy = 0; w.ntaps = 1; w.pad = 0;
+  w.w[0] = T(1); w.w[1] = T(0); w.w[2] = T(0); w.w[3] = T(0);
+  return w;
+}
+
+// warped_k(rr, cc) for (rr, cc) already known to be inside the image:
+// cv::warpAffine bilinear gather with zero border (motion_module.cpp:18-38).
+template <typename T>
+__device__ __forceinline__ T warp_sample(const T* __restrict__ plane, int W, int H,
+                                         const WarpTaps<T>& wt, int rr, int cc) {
+  const int sr = rr + wt.oy, sc = cc + wt.ox;
+  if (wt.ntaps == 1) {
+    return (sr >= 0 && sr < H && sc >= 0 && sc < W) ? plane[(size_t)sr * W + sc] : T(0);
+  }
+  const bool r0 = sr >= 0 && sr < H, r1 = sr + 1 >= 0 && sr + 1 < H;
+  const bool c0 = sc >= 0 && sc < W, c1 = sc + 1 >= 0 && sc + 1 < W;
+  const T v0 = (r0 && c0) ? plane[(size_t)sr * W + sc] : T(0);
+  const T v1 = (r0 && c1) ? plane[(size_t)sr * W + sc + 1] : T(0);
+  const T v2 = (r1 && c0) ? plane[(size_t)(sr + 1) * W + sc] : T(0);
+  const T v3 = (r1 && c1) ? plane[(size_t)(sr + 1) * W + sc + 1] : T(0);
+  return ((v0 * wt.w[0] + v1 * wt.w[1]) + v2 * wt.w[2]) + v3 * wt.w[3];
+}
+
+// ---------------------------------------------------------------------------
+// Forward model A_k = D B M_k (image_model.cpp:86-91) at every LR pixel of
+// frames [k0, k0+gridDim.z), optionally minus the observation, optionally with
+// the data-term cost partial s^2 * sum(res^2) (objective_data_term.cpp:29-50).
+template <typename T>
+__global__ __launch_bounds__(256) void k_forward_direct(
+    const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out,
+    double* __restrict__ partials, Geometry g,
+    const WarpTaps<T>* __restrict__ warps, const T* __restrict__ blur,
+    const int* __restrict__ col_map, const int* __restrict__ row_map, int k0,
+    double cost_scale, int obs_C, int obs_c0) {
+  __shared__ double red[4];
+  const int lp = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y, kk = blockIdx.z, k = k0 + kk;
+  const int n = g.w * g.h;
+  double sq = 0.0;
+  if (lp < n) {
+    const int i = lp / g.w, j = lp - i * g.w;
+    const int R0 = row_map[i], C0 = col_map[j];
+    const T* plane = x + (size_t)c * g.W * g.H;
+    const WarpTaps<T> wt = warps ? warps[k] : identity_warp<T>();
+    T acc = T(0);
+    for (int a = 0; a < g.b; ++a) {
+      const int rr = R0 + a - g.hb;
+      if (rr < 0 || rr >= g.H) continue;  // filter2D BORDER_CONSTANT on the warped image
+      for (int e = 0; e < g.b; ++e) {
+        const int cc = C0 + e - g.hb;
+        if (cc < 0 || cc >= g.W) continue;
+        acc += blur[a * g.b + e] * warp_sample(plane, g.W, g.H, wt, rr, cc);
+      }
+    }
+    T res = acc;
+    if (y) res -= y[((size_t)k * obs_C + c + obs_c0) * n + lp];
+    out[((size_t)kk * g.C + c) * n + lp] = res;
+    sq = (double)res * (double)res;
+  }
+  if (partials) {
+    const double s = block_sum_256(sq, red);
+    if (threadIdx.x == 0)
+      partials[(size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
+          cost_scale * s;
+  }
+}
+
+template <typename T>
+int launch_forward_direct(srmap_problem* p, const Geometry& g, const T* x, const T* y,
+                          int obs_C, int obs_c0, T* out, int k0, int nk,
+                          double* partials, int* nblocks, hipStream_t st) {
+  dim3 grid((g.w * g.h + 255) / 256, g.C, nk);
+  const double cost_scale = (double)g.s * (double)g.s;
+  hipLaunchKernelGGL(k_forward_direct<T>, grid, dim3(256), 0, st, x, y, out, partials, g,
+                     p->has_motion ? (const WarpTaps<T>*)p->d_fwd_warps : nullptr,
+                     (const T*)p->d_blur, p->d_col_map, p->d_row_map, k0, cost_scale, obs_C,
+                     obs_c0);
+  if (nblocks) *nblocks = (int)(grid.x * grid.y * grid.z);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Transpose model sum_k M_k^T B^T D^T r_k (image_model.cpp:93-101) in gather
+// form at every HR pixel: zero-insertion upsample (image_data.cpp:99-115),
+// correlation with kernel.t() (blur_module.cpp:30-36), warpAffine(-dx,-dy)
+// (motion_module.cpp:40-51); each stage clipped to the H x W domain.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_direct(
+    const T* __restrict__ resid, T* __restrict__ gout, Geometry g,
+    const WarpTaps<T>* __restrict__ warps, const T* __restrict__ blur_t, int k0,
+    int nk, T out_scale, int accumulate) {
+  const int hp = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int N = g.W * g.H, n = g.w * g.h;
+  if (hp >= N) return;
+  const int r = hp / g.W, col = hp - r * g.W;
+  T acc = T(0);
+  for (int kk = 0; kk < nk; ++kk) {
+    const WarpTaps<T> wt = warps ? warps[k0 + kk] : identity_warp<T>();
+    const T* rk = resid + ((size_t)kk * g.C + c) * n;
+    T tk = T(0);
+    for (int t = 0; t < wt.ntaps; ++t) {
+      const int pr = r + wt.oy + (t >> 1), pc = col + wt.ox + (t & 1);
+      if (pr < 0 || pr >= g.H || pc < 0 || pc >= g.W) continue;
+      T v = T(0);
+      for (int a = 0; a < g.b; ++a) {
+        const int R = pr + a - g.hb;
+        if (R < 0 || R >= g.H || (R % g.s) != 0) continue;
+        const int li = R / g.s;
+        if (li >= g.h) continue;
+        for (int e = 0; e < g.b; ++e) {
+          const int Cc = pc + e - g.hb;
+          if (Cc < 0 || Cc >= g.W || (Cc % g.s) != 0) continue;
+          const int lj = Cc / g.s;
+          if (lj >= g.w) continue;
+          v += blur_t[a * g.b + e] * rk[(size_t)li * g.w + lj];
+        }
+      }
+      tk += wt.w[t] * v;
+    }
+    acc += tk;
+  }
+  const size_t o = (size_t)c * N + hp;
+  const T base = accumulate ? gout[o] : T(0);
+  gout[o] = base + out_scale * acc;
+}
+
+template <typename T>
+int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, T* g,
+                         int k0, int nk, double out_scale, bool accumulate,
+                         hipStream_t st) {
+  dim3 grid((geo.W * geo.H + 255) / 256, geo.C);
+  hipLaunchKernelGGL(k_gather_direct<T>, grid, dim3(256), 0, st, resid, g, geo,
+                     p->has_motion ? (const WarpTaps<T>*)p->d_bwd_warps : nullptr,
+                     (const T*)p->d_blur_t, k0, nk, (T)out_scale, accumulate ? 1 : 0);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Regularizer values: TotalVariationRegularizer::ApplyToImage
+// (tv_regularizer.cpp:110-132, helpers :21-106) and
+// BilateralTotalVariationRegularizer::ApplyToImage (btv_regularizer.cpp:19-46,
+// :67-90).
+struct PowTable {
+  double v[2 * kMaxBtvRange + 1];
+};
+
+template <typename T>
+__device__ __forceinline__ T absval(T v) { return v < T(0) ? -v : v; }
+
+template <typename T>
+__device__ __forceinline__ T reg_value_at(const T* __restrict__ x, int W, int H, int C,
+                                          int c, int r, int col, int kind, int range,
+                                          const PowTable& pw) {
+  const size_t N = (size_t)W * H;
+  const T* plane = x + (size_t)c * N;
+  const T x0 = plane[(size_t)r * W + col];
+  if (kind == SRMAP_REG_BTV) {
+    T tv = T(0);
+    for (int i = 0; i <= range; ++i) {
+      const int rr = r + i;
+      if (rr >= H) continue;
+      for (int j = 0; j <= range; ++j) {
+        const int cc = col + j;
+        if (cc >= W) continue;
+        tv += (T)pw.v[i + j] * absval(x0 - plane[(size_t)rr * W + cc]);
+      }
+    }
+    return tv;
+  }
+  const T yv = (r + 1 < H) ? absval(plane[(size_t)(r + 1) * W + col] - x0) : T(0);
+  const T xv = (col + 1 < W) ? absval(plane[(size_t)r * W + col + 1] - x0) : T(0);
+  T tv = yv + xv;
+  if (kind == SRMAP_REG_TV3D && c + 1 < C) tv += absval(plane[N + (size_t)r * W + col] - x0);
+  return tv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_reg_values(const T* __restrict__ x,
+                                                   T* __restrict__ values, int W, int H,
+                                                   int C, int kind, int range,
+                                                   PowTable pw) {
+  const int hp = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (hp >= W * H) return;
+  const int r = hp / W, col = hp - r * W;
+  values[(size_t)c * W * H + hp] = reg_value_at(x, W, H, C, c, r, col, kind, range, pw);
+}
+
+static PowTable make_pow(const RegSpec& rs) {
+  PowTable t;
+  for (int i = 0; i < 2 * kMaxBtvRange + 1; ++i) t.v[i] = rs.pow_table[i];
+  return t;
+}
+
+template <typename T>
+int launch_reg_values(srmap_problem* p, const Geometry& g, const RegSpec& rs,
+                      const T* x, T* values, hipStream_t st) {
+  dim3 grid((g.W * g.H + 255) / 256, g.C);
+  hipLaunchKernelGGL(k_reg_values<T>, grid, dim3(256), 0, st, x, values, g.W, g.H, g.C,
+                     rs.kind, rs.range, make_pow(rs));
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Regularizer gradient given the values (tv_regularizer.cpp:143-224,
+// btv_regularizer.cpp:105-166), bug-compatible: 3-D TV has no z self term; BTV
+// uses the exclusive window and skips the absolute pixel (0,0) as a source.
+// Constants c[q] = gc_scale * gc[q] (gc == nullptr means 1).
+template <typename T>
+__device__ __forceinline__ T sgn(T d) { return d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_reg_gradient_direct(
+    const T* __restrict__ x, const T* __restrict__ gc, T gc_scale,
+    const T* __restrict__ values, T* __restrict__ gout, int accumulate,
+    double* __restrict__ partials, int W, int H, int C, int kind, int range,
+    PowTable pw) {
+  __shared__ double red[4];
+  const int hp = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  const size_t N = (size_t)W * H;
+  double cost = 0.0;
+  if (hp < W * H) {
+    const int r = hp / W, col = hp - r * W;
+    const T* plane = x + (size_t)c * N;
+    const T* vals = values + (size_t)c * N;
+    const T* gcp = gc ? gc + (size_t)c * N : nullptr;
+    const size_t idx = (size_t)r * W + col;
+    const T x0 = plane[idx];
+    const T wt0 = gcp ? gcp[idx] : T(1);
+    const T c0 = gc_scale * wt0;
+    const T r0 = vals[idx];
+    T grad = T(0);
+    if (kind == SRMAP_REG_BTV) {
+      T didi = T(0);
+      for (int i = 0; i < range; ++i) {
+        const int rr = r + i;
+        if (rr >= H) continue;
+        for (int j = 0; j < range; ++j) {
+          const int cc = col + j;
+          if (cc >= W) continue;
+          didi += (T)pw.v[i + j] * sgn(x0 - plane[(size_t)rr * W + cc]);
+        }
+      }
+      grad += T(2) * c0 * r0 * didi;
+      for (int i = 0; i < range; ++i) {
+        const int rr = r - i;
+        if (rr < 0) continue;
+        for (int j = 0; j < range; ++j) {
+          const int cc = col - j;
+          if (cc < 0 || (rr == 0 && cc == 0)) continue;
+          const size_t q = (size_t)rr * W + cc;
+          const T cq = gc_scale * (gcp ? gcp[q] : T(1));
+          const T didj = -sgn(plane[q] - x0) * (T)pw.v[i + j];
+          grad += T(2) * cq * vals[q] * didj;
+        }
+      }
+    } else {
+      T didi = T(0);
+      if (col + 1 < W) didi -= sgn(plane[idx + 1] - x0);
+      if (r + 1 < H) didi -= sgn(plane[idx + W] - x0);
+      grad += T(2) * c0 * r0 * didi;
+      if (col - 1 >= 0) {
+        const size_t q = idx - 1;
+        const T cq = gc_scale * (gcp ? gcp[q] : T(1));
+        grad += T(2) * cq * vals[q] * sgn(x0 - plane[q]);
+      }
+      if (r - 1 >= 0) {
+        const size_t q = idx - W;
+        const T cq = gc_scale * (gcp ? gcp[q] : T(1));
+        grad += T(2) * cq * vals[q] * sgn(x0 - plane[q]);
+      }
+      if (kind == SRMAP_REG_TV3D && c > 0) {
+        const T xb = plane[idx - N];
+        const T cq = gc_scale * (gcp ? gcp[idx - N] : T(1));
+        grad += T(2) * cq * vals[idx - N] * sgn(x0 - xb);
+      }
+    }
+    const size_t o = (size_t)c * N + idx;
+    if (gout) gout[o] = (accumulate ? gout[o] : T(0)) + grad;
+    // lambda * w * r^2  (objective_irls_regularization_term.cpp:45-50)
+    cost = (double)c0 * (double)r0 * (double)r0;
+  }
+  if (partials) {
+    const double s = block_sum_256(cost, red);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+template <typename T>
+int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegSpec& rs,
+                               const T* x, const T* gc, double gc_scale, const T* values,
+                               T* g, bool accumulate, double* partials, int* nblocks,
+                               hipStream_t st) {
+  dim3 grid((geo.W * geo.H + 255) / 256, geo.C);
+  hipLaunchKernelGGL(k_reg_gradient_direct<T>, grid, dim3(256), 0, st, x, gc, (T)gc_scale,
+                     values, g, accumulate ? 1 : 0, partials, geo.W, geo.H, geo.C, rs.kind,
+                     rs.range, make_pow(rs));
+  if (nblocks) *nblocks = (int)(grid.x * grid.y);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+// w = 1 / max(1e-5, r)  (irls_map_solver.cpp:128-143, kMinResidualValue :35)
+template <typename T>
+__global__ __launch_bounds__(256) void k_irls_weights(const T* __restrict__ values,
+                                                     T* __restrict__ weights, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const T r = values[i];
+  const T m = r > (T)0.00001 ? r : (T)0.00001;
+  weights[i] = T(1) / m;
+}
+
+template <typename T>
+int launch_irls_weights(srmap_problem* p, const T* values, T* weights, size_t n,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_irls_weights<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     values, weights, n);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+// Deterministic final reduction of per-block partials: one 256-thread block,
+// fixed order.  out[0] = sum.
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partials,
+                                                        int n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+  const double s = block_sum_256(v, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+int launch_reduce_partials(srmap_problem* p, const double* partials, int n, double* out,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partials, n, out);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+#define INSTANTIATE(T)                                                                      \
+  template int launch_forward_direct<T>(srmap_problem*, const Geometry&, const T*,         \
+                                        const T*, int, int, T*, int, int, double*, int*,   \
+                                        hipStream_t);                                       \
+  template int launch_gather_direct<T>(srmap_problem*, const Geometry&, const T*, T*, int, \
+                                       int, double, bool, hipStream_t);                     \
+  template int launch_reg_values<T>(srmap_problem*, const Geometry&, const RegSpec&,       \
+                                    const T*, T*, hipStream_t);                             \
+  template int launch_reg_gradient_direct<T>(srmap_problem*, const Geometry&,              \
+                                             const RegSpec&, const T*, const T*, double,   \
+                                             const T*, T*, bool, double*, int*,            \
+                                             hipStream_t);                                  \
+  template int launch_irls_weights<T>(srmap_problem*, const T*, T*, size_t, hipStream_t);
+INSTANTIATE(float)
+INSTANTIATE(double)
+
+}  // namespace srmap

@@ -1,0 +1,161 @@
+// srmap_internal.hpp -- shared declarations of libsrmap.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "srmap.h"
+
+namespace srmap {
+
+constexpr int kMaxRegularizers = 4;
+constexpr int kMaxBtvRange = 8;        // alpha^(i+j) table holds 2*range+1 entries
+constexpr int kMaxBlurTaps = 15 * 15;  // b*b taps kept in kernel-argument space
+
+// One MotionModule warp (forward or transpose) of one frame, as cv::warpAffine
+// evaluates it (motion_module.cpp:18-51): source pixel = destination + (ox, oy)
+// plus up to four bilinear taps with 1/32-pixel quantised weights.
+template <typename T>
+struct WarpTaps {
+  int ox, oy;
+  int ntaps;  // 1 = integer shift (weights 1,0,0,0), 4 = bilinear
+  int pad;
+  T w[4];     // (0,0) (1,0) (0,1) (1,1) as (dx,dy) tap offsets
+};
+
+struct Geometry {
+  int W, H, C, K;  // HR size, channels, frames
+  int w, h;        // LR size
+  int s;           // scale
+  int b, hb;       // blur kernel size (1 = none) and (b-1)/2
+};
+
+struct RegSpec {
+  int kind;
+  int range;
+  double decay;
+  double lambda;
+  void* weights;  // device [C][H][W] dtype; nullptr = all ones
+  double pow_table[2 * kMaxBtvRange + 1];  // std::pow(decay, k), host libm
+};
+
+// Tile geometry of the LDS-tiled kernels for one problem.
+struct TilePlan {
+  bool usable = false;
+  int halo_l = 0, halo_r = 0, halo_u = 0, halo_d = 0;  // x halo of the fused tile
+};
+
+}  // namespace srmap
+
+struct srmap_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  int num_cus = 0;
+};
+
+struct srmap_problem {
+  srmap_ctx* ctx = nullptr;
+  srmap::Geometry geo{};
+  int dtype = SRMAP_F64;
+  int impl = SRMAP_IMPL_AUTO;
+  bool has_motion = false;
+  bool maps_regular = true;       // decimation map == s*j on both axes
+  std::vector<double> shifts;     // K x 2
+  std::vector<double> blur2d;     // b*b (double); transposed copy in blur2d_t
+  std::vector<double> blur2d_t;
+  // device constants
+  void* d_fwd_warps = nullptr;    // WarpTaps<T>[K]
+  void* d_bwd_warps = nullptr;    // WarpTaps<T>[K]
+  void* d_blur = nullptr;         // T[b*b]
+  void* d_blur_t = nullptr;       // T[b*b]
+  int* d_col_map = nullptr;       // int[w]  decimation source column
+  int* d_row_map = nullptr;       // int[h]
+  // host mirrors of the warp taps (double) for tile planning
+  std::vector<srmap::WarpTaps<double>> fwd_warps, bwd_warps;
+  // state
+  void* d_obs = nullptr;          // [K][C][h][w] dtype
+  bool have_obs = false;
+  void* d_resid = nullptr;        // [K][C][h][w] dtype scratch
+  void* d_regvals = nullptr;      // [C][H][W] dtype scratch
+  void* d_x = nullptr;            // [C][H][W] staging for host-buffer entry points
+  void* d_g = nullptr;
+  void* d_tmp = nullptr;          // [C][H][W] staging (gradient constants, values)
+  double* d_partials = nullptr;   // per-block cost partials
+  size_t partials_cap = 0;
+  double* d_cost = nullptr;       // [4] reduced scalars
+  int nreg = 0;
+  srmap::RegSpec reg[srmap::kMaxRegularizers];
+  srmap::TilePlan plan;
+  // channel view of the current evaluation (split_channels solves one channel
+  // at a time, irls_map_solver.cpp:200-262); default = all channels
+  int view_c0 = 0, view_C = 0;
+  size_t elem() const { return dtype == SRMAP_F32 ? 4 : 8; }
+  size_t hr_count() const { return (size_t)geo.C * geo.H * geo.W; }
+  size_t lr_count() const { return (size_t)geo.K * geo.C * geo.h * geo.w; }
+};
+
+namespace srmap {
+
+int set_error(srmap_ctx* ctx, int status, const char* fmt, ...);
+
+#define SRMAP_HIP(ctx, call)                                                     \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess)                                                        \
+      return ::srmap::set_error((ctx), SRMAP_EHIP, "%s failed: %s (%s:%d)", #call, \
+                                hipGetErrorString(e_), __FILE__, __LINE__);      \
+  } while (0)
+
+// ---- kernel launchers (kernels_direct.hip) ----
+// out = A_k x (y == nullptr) or A_k x - y_k for frames [k0, k0+nk); optional
+// cost partials (s^2 * sum of squares, double) appended at partials[0..nblocks).
+// `g` is the geometry of this evaluation (g.C may be a channel sub-range of the
+// problem: y is indexed with the problem's channel count obs_C and offset obs_c0).
+template <typename T>
+int launch_forward_direct(srmap_problem* p, const Geometry& g, const T* x, const T* y,
+                          int obs_C, int obs_c0, T* out, int k0, int nk,
+                          double* partials, int* nblocks, hipStream_t st);
+// g = (accumulate ? g : 0) + 2 s^2 sum_k A_k^T r_k   (r: [K][C][h][w])
+template <typename T>
+int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, T* g,
+                         int k0, int nk, double out_scale, bool accumulate,
+                         hipStream_t st);
+template <typename T>
+int launch_reg_values(srmap_problem* p, const Geometry& geo, const RegSpec& rs,
+                      const T* x, T* values, hipStream_t st);
+// g += d(reg)/dx with constants c = lambda_or_1 * gc[p]; optional cost partials
+// lambda * w * r^2 (only meaningful when gc are the IRLS weights).
+template <typename T>
+int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegSpec& rs,
+                               const T* x, const T* gc, double gc_scale, const T* values,
+                               T* g, bool accumulate, double* partials, int* nblocks,
+                               hipStream_t st);
+template <typename T>
+int launch_irls_weights(srmap_problem* p, const T* values, T* weights, size_t n,
+                        hipStream_t st);
+int launch_reduce_partials(srmap_problem* p, const double* partials, int n,
+                           double* out, hipStream_t st);
+
+// ---- LDS-tiled kernels (kernels_tiled.hip) ----
+bool tiled_plan(srmap_problem* p);
+template <typename T>
+int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,
+                      const T* x, T* g, double* partials, int* nblocks, hipStream_t st);
+
+// ---- vector kernels for the solver (solver.hip) ----
+int solve_impl(srmap_problem* p, const srmap_irls_options* o, const double* x0,
+               double* x_out, srmap_solve_report* rep, srmap_allreduce_fn ar,
+               void* user);
+
+// conversions
+int convert_upload(srmap_problem* p, const double* host, void* dev, size_t n,
+                   hipStream_t st);
+int convert_download(srmap_problem* p, const void* dev, double* host, size_t n,
+                     hipStream_t st);
+
+}  // namespace srmap

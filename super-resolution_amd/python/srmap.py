@@ -1,0 +1,267 @@
+"""ctypes binding of libsrmap.so (include/srmap.h) for the test-suite and
+bench.py.  This is harness plumbing: the product is the C-ABI library and the
+C++ facade in super-resolution_amd/host.  There is no CPU fallback -- importing
+works anywhere (so that symbol checks can run without a GPU), but creating a
+context without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsrmap.so")
+
+OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
+F64, F32 = 0, 1
+REG_TV, REG_TV3D, REG_BTV = 0, 1, 2
+TERM_DATA, TERM_REG, TERM_ALL = 1, 2, 3
+IMPL_AUTO, IMPL_DIRECT, IMPL_TILED = 0, 1, 2
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class SrmapError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("srmap status %d: %s" % (status, message))
+        self.status = status
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [("hr_width", C.c_int), ("hr_height", C.c_int), ("channels", C.c_int),
+                ("frames", C.c_int), ("scale", C.c_int), ("shifts_xy", c_double_p),
+                ("blur_ksize", C.c_int), ("blur_sigma", C.c_double), ("dtype", C.c_int)]
+
+
+class IrlsOptions(C.Structure):
+    _fields_ = [("max_num_solver_iterations", C.c_int),
+                ("gradient_norm_threshold", C.c_double),
+                ("cost_decrease_threshold", C.c_double),
+                ("parameter_variation_threshold", C.c_double),
+                ("split_channels", C.c_int),
+                ("max_num_irls_iterations", C.c_int),
+                ("irls_cost_difference_threshold", C.c_double)]
+
+
+class SolveReport(C.Structure):
+    _fields_ = [("irls_rounds", C.c_int), ("cg_iterations", C.c_int), ("evaluations", C.c_int),
+                ("last_termination", C.c_int), ("final_cost", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, c_double_p, C.c_int, C.c_void_p)
+
+# every symbol include/srmap.h declares: (name, restype, argtypes)
+_SIGNATURES = [
+    ("srmap_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("srmap_ctx_destroy", None, [C.c_void_p]),
+    ("srmap_last_error", C.c_char_p, [C.c_void_p]),
+    ("srmap_version", C.c_char_p, []),
+    ("srmap_problem_create", C.c_int, [C.c_void_p, C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),
+    ("srmap_problem_destroy", None, [C.c_void_p]),
+    ("srmap_problem_set_impl", C.c_int, [C.c_void_p, C.c_int]),
+    ("srmap_problem_lr_size", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("srmap_set_observations", C.c_int, [C.c_void_p, c_double_p]),
+    ("srmap_set_observations_device", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("srmap_add_regularizer", C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int)]),
+    ("srmap_clear_regularizers", C.c_int, [C.c_void_p]),
+    ("srmap_set_irls_weights", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    ("srmap_update_irls_weights_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    ("srmap_apply", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
+    ("srmap_apply_transpose", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
+    ("srmap_reg_values", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
+    ("srmap_reg_values_and_gradient", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
+    ("srmap_eval", C.c_int, [C.c_void_p, C.c_uint, c_double_p, c_double_p, c_double_p]),
+    ("srmap_eval_device", C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, c_double_p, C.c_void_p]),
+    ("srmap_last_cost", C.c_int, [C.c_void_p, c_double_p]),
+    ("srmap_device_alloc", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("srmap_device_free", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("srmap_upload", C.c_int, [C.c_void_p, c_double_p, C.c_void_p, C.c_size_t]),
+    ("srmap_download", C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_size_t]),
+    ("srmap_synchronize", C.c_int, [C.c_void_p]),
+    ("srmap_irls_options_default", None, [C.POINTER(IrlsOptions)]),
+    ("srmap_solve", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
+    ("srmap_solve_ex", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport), ALLREDUCE_FN, C.c_void_p]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def load():
+    """dlopen libsrmap.so; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libsrmap.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                               "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in _SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_double_p)
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        st = load().srmap_ctx_create(device, C.byref(self._h))
+        if st != OK:
+            raise SrmapError(st, "srmap_ctx_create failed (no usable HIP device %d; no CPU path exists)" % device)
+
+    def check(self, st):
+        if st != OK:
+            raise SrmapError(st, load().srmap_last_error(self._h).decode())
+
+    def synchronize(self):
+        self.check(load().srmap_synchronize(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().srmap_ctx_destroy(self._h)
+            self._h = None
+
+
+def default_irls_options():
+    o = IrlsOptions()
+    load().srmap_irls_options_default(C.byref(o))
+    return o
+
+
+class Problem:
+    def __init__(self, ctx, hr_width, hr_height, channels, frames, scale, shifts=None,
+                 blur_ksize=0, blur_sigma=0.0, dtype=F64):
+        self.ctx = ctx
+        self.W, self.H, self.C, self.K, self.s = hr_width, hr_height, channels, frames, scale
+        self.dtype = dtype
+        d = ProblemDesc()
+        d.hr_width, d.hr_height, d.channels, d.frames, d.scale = hr_width, hr_height, channels, frames, scale
+        self._shifts = None
+        if shifts is not None:
+            self._shifts = np.ascontiguousarray(shifts, dtype=np.float64).reshape(-1, 2)
+            assert len(self._shifts) == frames
+            d.shifts_xy = self._shifts.ctypes.data_as(c_double_p)
+        d.blur_ksize, d.blur_sigma, d.dtype = blur_ksize, blur_sigma, dtype
+        self._h = C.c_void_p()
+        ctx.check(load().srmap_problem_create(ctx._h, C.byref(d), C.byref(self._h)))
+        lw, lh = C.c_int(), C.c_int()
+        load().srmap_problem_lr_size(self._h, C.byref(lw), C.byref(lh))
+        self.w, self.h = lw.value, lh.value
+        self.nreg = 0
+        self._ar = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().srmap_problem_destroy(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_impl(self, impl):
+        self.ctx.check(load().srmap_problem_set_impl(self._h, impl))
+
+    def set_observations(self, lr):
+        a, pa = _d(lr)
+        assert a.size == self.K * self.C * self.h * self.w, (a.shape, self.K, self.C, self.h, self.w)
+        self.ctx.check(load().srmap_set_observations(self._h, pa))
+
+    def set_observations_device(self, ptr):
+        self.ctx.check(load().srmap_set_observations_device(self._h, C.c_void_p(ptr)))
+
+    def add_regularizer(self, kind, lam, btv_range=0, btv_decay=0.0):
+        idx = C.c_int(-1)
+        self.ctx.check(load().srmap_add_regularizer(self._h, kind, lam, btv_range, btv_decay, C.byref(idx)))
+        self.nreg += 1
+        return idx.value
+
+    def clear_regularizers(self):
+        self.ctx.check(load().srmap_clear_regularizers(self._h))
+        self.nreg = 0
+
+    def set_irls_weights(self, reg, w):
+        if w is None:
+            self.ctx.check(load().srmap_set_irls_weights(self._h, reg, None))
+        else:
+            a, pa = _d(w)
+            assert a.size == self.C * self.H * self.W
+            self.ctx.check(load().srmap_set_irls_weights(self._h, reg, pa))
+
+    def update_irls_weights_device(self, reg, x_ptr):
+        self.ctx.check(load().srmap_update_irls_weights_device(self._h, reg, C.c_void_p(x_ptr)))
+
+    def apply(self, hr, k):
+        a, pa = _d(hr)
+        assert a.size == self.C * self.H * self.W
+        out = np.empty((self.C, self.h, self.w))
+        self.ctx.check(load().srmap_apply(self._h, k, pa, out.ctypes.data_as(c_double_p)))
+        return out
+
+    def apply_transpose(self, lr, k):
+        a, pa = _d(lr)
+        assert a.size == self.C * self.h * self.w
+        out = np.empty((self.C, self.H, self.W))
+        self.ctx.check(load().srmap_apply_transpose(self._h, k, pa, out.ctypes.data_as(c_double_p)))
+        return out
+
+    def reg_values(self, reg, x):
+        a, pa = _d(x)
+        out = np.empty((self.C, self.H, self.W))
+        self.ctx.check(load().srmap_reg_values(self._h, reg, pa, out.ctypes.data_as(c_double_p)))
+        return out
+
+    def reg_values_and_gradient(self, reg, x, gc):
+        a, pa = _d(x)
+        g, pg = _d(gc)
+        vals = np.empty((self.C, self.H, self.W))
+        grad = np.empty((self.C, self.H, self.W))
+        self.ctx.check(load().srmap_reg_values_and_gradient(
+            self._h, reg, pa, pg, vals.ctypes.data_as(c_double_p), grad.ctypes.data_as(c_double_p)))
+        return vals, grad
+
+    def eval(self, x, terms=TERM_ALL, want_grad=True):
+        a, pa = _d(x)
+        assert a.size == self.C * self.H * self.W
+        cost = C.c_double()
+        g = np.empty((self.C, self.H, self.W)) if want_grad else None
+        self.ctx.check(load().srmap_eval(self._h, terms, pa, C.byref(cost),
+                                         g.ctypes.data_as(c_double_p) if want_grad else None))
+        return cost.value, g
+
+    def eval_device(self, x_ptr, g_ptr, terms=TERM_ALL, want_cost=False, stream=None):
+        cost = C.c_double()
+        self.ctx.check(load().srmap_eval_device(self._h, terms, C.c_void_p(x_ptr),
+                                                C.c_void_p(g_ptr) if g_ptr else None,
+                                                C.byref(cost) if want_cost else None,
+                                                C.c_void_p(stream) if stream else None))
+        return cost.value if want_cost else None
+
+    def last_cost(self):
+        cost = C.c_double()
+        self.ctx.check(load().srmap_last_cost(self._h, C.byref(cost)))
+        return cost.value
+
+    def solve(self, x0, options=None, allreduce=None):
+        a, pa = _d(x0)
+        assert a.size == self.C * self.H * self.W
+        out = np.empty((self.C, self.H, self.W))
+        rep = SolveReport()
+        o = options if options is not None else default_irls_options()
+        if allreduce is None:
+            st = load().srmap_solve(self._h, C.byref(o), pa, out.ctypes.data_as(c_double_p), C.byref(rep))
+        else:
+            def _cb(ptr, n, _user):
+                arr = np.ctypeslib.as_array(ptr, shape=(n,))
+                allreduce(arr)
+            self._ar = ALLREDUCE_FN(_cb)
+            st = load().srmap_solve_ex(self._h, C.byref(o), pa, out.ctypes.data_as(c_double_p), C.byref(rep),
+                                       self._ar, None)
+        self.ctx.check(st)
+        return out, rep

@@ -1,0 +1,387 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI
+(libsrmap.so), against the CPU oracle on the same seeded inputs, against the
+reference's golden literals, and -- at BASELINE.json's full sizes -- through
+size-independent properties.
+
+Tolerances:
+  f64 mode : |d| / max(1, |ref|) <= 1e-12 per element (summation order / FMA only)
+  f32 mode : <= 2e-5 relative on operators and gradients, 1e-5 on the cost
+             (fp32 storage and arithmetic, fp64 cost reductions)
+  decimation index map: bit-exact.
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-12, 1: 2e-5}
+
+
+def relerr(a, ref):
+    a, ref = np.asarray(a, dtype=float).ravel(), np.asarray(ref, dtype=float).ravel()
+    return float(np.max(np.abs(a - ref) / np.maximum(1.0, np.abs(ref)))) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def sr():
+    import srmap
+    return srmap
+
+
+@pytest.fixture(scope="module")
+def ctx(sr):
+    return sr.Context(0)
+
+
+def make_pair(sr, ctx, rng, W, H, C, s, shifts, b=0, sigma=0.0, dtype=0, with_obs=True):
+    model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=b, blur_sigma=sigma, num_frames=len(shifts) if shifts is not None else 1)
+    K = len(shifts) if shifts is not None else 1
+    p = sr.Problem(ctx, W, H, C, K, s, shifts, b, sigma, dtype)
+    lr = None
+    ref = None
+    if with_obs:
+        gt = rng.random((C, H, W))
+        lr = np.stack([model.apply(gt, k) for k in range(K)]) + 0.01 * rng.standard_normal((K, C, H // s, W // s))
+        p.set_observations(lr)
+        ref = orc.Problem(model, lr)
+    return model, p, ref, lr
+
+
+CASES = [
+    # W, H, C, s, shifts, blur, sigma
+    (16, 12, 1, 2, [[0, 0], [1, 1], [0, 1], [1, 0]], 0, 0.0),
+    (24, 18, 2, 3, [[0, 0], [2, 1], [-1, 2], [-2, -2], [1, 0]], 3, 1.0),
+    (32, 32, 1, 4, [[k % 4, k // 4] for k in range(16)], 3, 1.0),
+    (20, 28, 3, 2, [[5, -7], [-9, 3], [0, 0]], 5, 1.3),
+    (21, 15, 1, 1, [[1, -1], [0, 2]], 3, 0.8),
+    (16, 16, 1, 2, None, 3, 1.0),               # no MotionModule in the chain
+    (28, 20, 1, 4, [[0.5, 0.25], [-1.3, 2.71], [0.01, -0.99], [3.0, -2.5]], 3, 1.0),  # sub-pixel
+    (36, 30, 2, 3, [[0.75, -0.5], [1, 1]], 7, 2.0),
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_apply_and_transpose_match_oracle(sr, ctx, case, dtype):
+    W, H, C, s, shifts, b, sigma = CASES[case]
+    rng = np.random.default_rng(100 + case)
+    model, p, _, _ = make_pair(sr, ctx, rng, W, H, C, s, shifts, b, sigma, dtype, with_obs=False)
+    x = rng.standard_normal((C, H, W))
+    y = rng.standard_normal((C, H // s, W // s))
+    for k in range(p.K):
+        assert relerr(p.apply(x, k), model.apply(x, k)) <= TOL[dtype]
+        assert relerr(p.apply_transpose(y, k), model.apply_transpose(y, k)) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("W,H,s", [(17, 13, 2), (23, 10, 3), (31, 29, 4), (10, 10, 7)])
+def test_apply_on_non_divisible_sizes(sr, ctx, W, H, s):
+    """ImageModel::ApplyToImage on arbitrary sizes (data generation,
+    generate_data.cpp:117-118): LR size (int)(len/s), resize(INTER_NEAREST) map."""
+    rng = np.random.default_rng(W * H)
+    shifts = [[1, -1], [0, 0]]
+    model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=3, blur_sigma=1.0)
+    p = sr.Problem(ctx, W, H, 2, 2, s, shifts, 3, 1.0, sr.F64)
+    x = rng.random((2, H, W))
+    for k in range(2):
+        ref = model.apply(x, k)
+        assert ref.shape == (2, p.h, p.w)
+        assert relerr(p.apply(x, k), ref) <= 1e-12
+
+
+@pytest.mark.parametrize("s", [1, 2, 3, 4, 5])
+def test_decimation_index_map_bit_exact(sr, ctx, s):
+    """Feed an image whose pixel value is its own linear index: the LR output IS
+    the decimation index map.  Must equal cv::resize's map bit for bit."""
+    h, w = 9, 11
+    W, H = w * s, h * s
+    p = sr.Problem(ctx, W, H, 1, 1, s, None, 0, 0.0, sr.F64)
+    idx = np.arange(W * H, dtype=np.float64).reshape(1, H, W)
+    out = p.apply(idx, 0)[0]
+    cm, rm = orc.nearest_map(W, w), orc.nearest_map(H, h)
+    expect = rm[:, None].astype(np.int64) * W + cm[None, :]
+    assert np.array_equal(out.astype(np.int64), expect)
+    assert np.array_equal(cm, np.arange(w) * s) and np.array_equal(rm, np.arange(h) * s)
+    # zero-insertion transpose: hr[s*r][s*c] = lr[r][c], zeros elsewhere
+    lr = np.arange(1, w * h + 1, dtype=np.float64).reshape(1, h, w)
+    up = p.apply_transpose(lr, 0)[0]
+    exp_up = np.zeros((H, W))
+    exp_up[::s, ::s] = lr[0]
+    assert np.array_equal(up, exp_up)
+
+
+def test_reference_literals_through_hip(sr, ctx, literals):
+    img = np.array(literals["small_test_image"]["data"], dtype=float)[None]
+    p = sr.Problem(ctx, 6, 4, 1, 1, 2, None, 0, 0.0, sr.F64)
+    assert np.array_equal(p.apply(img, 0)[0], np.array(literals["downsample_scale2"]["expected"], dtype=float))
+    p2 = sr.Problem(ctx, 12, 8, 1, 1, 2, None, 0, 0.0, sr.F64)
+    assert np.array_equal(p2.apply_transpose(img, 0)[0],
+                          np.array(literals["downsample_transpose_scale2"]["expected"], dtype=float))
+    L = literals["blur_3_0.849321"]
+    pb = sr.Problem(ctx, 6, 4, 1, 1, 1, None, L["ksize"], L["sigma"], sr.F64)
+    assert np.max(np.abs(pb.apply(img, 0)[0] - np.array(L["expected"]))) < L["tol"]
+    assert np.max(np.abs(pb.apply_transpose(img, 0)[0] - np.array(L["expected"]))) < L["tol"]
+    # motion matrices (integer shifts) column by column
+    M = literals["motion_matrices_3x3"]
+    pm = sr.Problem(ctx, 3, 3, 1, 3, 1, M["shifts"], 0, 0.0, sr.F64)
+    for k, ones in enumerate(M["ones"]):
+        mat = np.zeros((9, 9))
+        for o, i in ones:
+            mat[o, i] = 1
+        for j in range(9):
+            e = np.zeros(9); e[j] = 1
+            assert np.array_equal(pm.apply(e.reshape(1, 3, 3), k).ravel(), mat[:, j])
+    # TV / TV3D / BTV value literals
+    T = literals["tv"]
+    pt = sr.Problem(ctx, 3, 3, 3, 1, 1, None, 0, 0.0, sr.F64)
+    r_tv = pt.add_regularizer(sr.REG_TV, 1.0)
+    r_tv3 = pt.add_regularizer(sr.REG_TV3D, 1.0)
+    x3 = np.tile(np.array(T["image"], dtype=float).reshape(1, 3, 3), (3, 1, 1))
+    assert np.array_equal(pt.reg_values(r_tv, x3).reshape(3, 9), np.tile(np.array(T["expected"], dtype=float), (3, 1)))
+    T3 = literals["tv3d"]
+    assert np.array_equal(pt.reg_values(r_tv3, np.array(T3["image"], dtype=float).reshape(3, 3, 3)).ravel(),
+                          np.array(T3["expected"], dtype=float))
+    B = literals["btv"]
+    xb = np.array(B["image"], dtype=float).reshape(1, 5, 5)
+    pbt = sr.Problem(ctx, 5, 5, 1, 1, 1, None, 0, 0.0, sr.F64)
+    rb = pbt.add_regularizer(sr.REG_BTV, 1.0, 2, 0.5)
+    v = pbt.reg_values(rb, xb).ravel()
+    assert v[0] == 2.8125 and v[24] == 0.0
+    pbt2 = sr.Problem(ctx, 5, 5, 2, 1, 1, None, 0, 0.0, sr.F64)
+    rb2 = pbt2.add_regularizer(sr.REG_BTV, 1.0, 1, 0.25)
+    v2 = pbt2.reg_values(rb2, np.repeat(xb, 2, axis=0)).ravel()
+    assert v2[7] == 0.5625 and v2[32] == 0.5625 and v2[24] == 0.0 and v2[49] == 0.0
+
+
+REGS = [("tv", 0, 0, 0.0), ("tv3d", 1, 0, 0.0), ("btv", 2, 1, 0.25), ("btv", 2, 2, 0.5),
+        ("btv", 2, 3, 0.5), ("btv", 2, 3, 1.0), ("btv", 2, 4, 0.7)]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("reg", range(len(REGS)))
+@pytest.mark.parametrize("shape", [(1, 5, 5), (3, 13, 17), (2, 1, 9), (2, 8, 1)])
+def test_regularizer_values_and_gradient(sr, ctx, reg, shape, dtype):
+    """Regularizer::ApplyToImage / ApplyToImageWithDifferentiation incl. the
+    reference's quirks: exclusive BTV gradient window, absolute-(0,0) skip,
+    range 1 => zero gradient, 3-D TV without z self term."""
+    _, kind, rng_, decay = REGS[reg]
+    C, H, W = shape
+    rng = np.random.default_rng(7 * reg + C * H * W)
+    x = np.round(rng.random(shape) * 8) / 8  # ties (equal neighbours) exercise sgn(0) = 0
+    gc = 0.25 + rng.random(shape)
+    p = sr.Problem(ctx, W, H, C, 1, 1, None, 0, 0.0, dtype)
+    r = p.add_regularizer(kind, 1.0, rng_, decay)
+    vals_ref, grad_ref = orc.reg_values_and_gradient(kind, x, gc, rng_, decay)
+    assert relerr(p.reg_values(r, x), vals_ref) <= TOL[dtype]
+    vals, grad = p.reg_values_and_gradient(r, x, gc)
+    assert relerr(vals, vals_ref) <= TOL[dtype]
+    assert relerr(grad, grad_ref) <= 4 * TOL[dtype]
+    if kind == 2 and rng_ == 1:
+        assert np.all(grad == 0)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("regs", [[], [(0, 0.05, 0, 0.0)], [(2, 0.01, 3, 0.5)], [(2, 0.02, 2, 0.6), (1, 0.03, 0, 0.0)]])
+def test_objective_matches_oracle(sr, ctx, case, regs, dtype):
+    """ObjectiveFunction::ComputeAllTerms: cost and gradient, every term mix."""
+    W, H, C, s, shifts, b, sigma = CASES[case]
+    if W % s or H % s:
+        pytest.skip("solver geometry needs HR = LR * scale")
+    rng = np.random.default_rng(1000 + case)
+    model, p, ref, lr = make_pair(sr, ctx, rng, W, H, C, s, shifts, b, sigma, dtype)
+    for kind, lam, rg, dc in regs:
+        i = p.add_regularizer(kind, lam, rg, dc)
+        j = ref.add_regularizer(kind, lam, rg, dc)
+        assert i == j
+        wts = 0.5 + 2 * rng.random((C, H, W))
+        p.set_irls_weights(i, wts)
+        ref.set_irls_weights(j, wts)
+    x = rng.random((C, H, W))
+    f_ref, g_ref = ref.objective(x)
+    f, g = p.eval(x)
+    tol = TOL[dtype]
+    assert abs(f - f_ref) / max(1.0, abs(f_ref)) <= (tol if dtype == 0 else 1e-5)
+    assert relerr(g, g_ref) <= 4 * tol
+    # term selection (ObjectiveTerm granularity) and cost-only calls
+    fd_ref, gd_ref = ref.data_term(x)
+    fd, gd = p.eval(x, sr.TERM_DATA)
+    assert abs(fd - fd_ref) / max(1.0, abs(fd_ref)) <= (tol if dtype == 0 else 1e-5)
+    assert relerr(gd, gd_ref) <= 4 * tol
+    f2, _ = p.eval(x, sr.TERM_ALL, want_grad=False)
+    assert f2 == f
+    fr, gr = p.eval(x, sr.TERM_REG)
+    assert abs((fd + fr) - f) <= 1e-9 * max(1.0, abs(f))
+
+
+def test_lambda_zero_term_is_skipped(sr, ctx):
+    rng = np.random.default_rng(5)
+    model, p, ref, lr = make_pair(sr, ctx, rng, 16, 16, 1, 2, [[0, 0], [1, 0]], 0, 0.0, 0)
+    p.add_regularizer(sr.REG_TV, 0.0)
+    x = rng.random((1, 16, 16))
+    f0, g0 = p.eval(x, sr.TERM_DATA)
+    f1, g1 = p.eval(x)
+    assert f0 == f1 and np.array_equal(g0, g1)
+
+
+def test_error_behaviour(sr, ctx):
+    """CHECK-class violations of the reference map to SRMAP_EINVAL, not aborts."""
+    with pytest.raises(sr.SrmapError) as e:
+        sr.Problem(ctx, 8, 8, 1, 1, 0, None, 0, 0.0, 0)          # scale < 1 (image_model.cpp:66)
+    assert e.value.status == sr.EINVAL
+    with pytest.raises(sr.SrmapError) as e:
+        sr.Problem(ctx, 8, 8, 1, 1, 2, None, 4, 1.0, 0)          # even blur size (blur_module.cpp:18)
+    assert e.value.status == sr.EINVAL
+    p = sr.Problem(ctx, 8, 8, 1, 2, 2, [[0, 0], [1, 1]], 0, 0.0, 0)
+    with pytest.raises(sr.SrmapError) as e:
+        p.add_regularizer(sr.REG_BTV, 0.1, 0, 0.5)               # range < 1 (btv_regularizer.cpp:58)
+    assert e.value.status == sr.EINVAL
+    with pytest.raises(sr.SrmapError) as e:
+        p.add_regularizer(sr.REG_BTV, 0.1, 2, 1.5)               # decay not in (0,1]
+    assert e.value.status == sr.EINVAL
+    with pytest.raises(sr.SrmapError) as e:
+        p.apply(np.zeros((1, 8, 8)), 2)                          # frame index out of range
+    assert e.value.status == sr.EINVAL
+    with pytest.raises(sr.SrmapError) as e:
+        p.eval(np.zeros((1, 8, 8)))                              # no observations
+    assert e.value.status == sr.EINVAL
+    q = sr.Problem(ctx, 9, 9, 1, 1, 2, None, 0, 0.0, 0)
+    with pytest.raises(sr.SrmapError) as e:
+        q.set_observations(np.zeros((1, 1, 4, 4)))               # HR != LR * scale
+    assert e.value.status == sr.EINVAL
+
+
+# ------------------------------------------------------------------ solver
+@pytest.mark.parametrize("channels,split", [(1, False), (10, False), (10, True)])
+def test_map_solver_small_data(sr, ctx, literals, channels, split):
+    """test/test_map_solver.cpp:79-199 on the HIP solver."""
+    L = literals["map_solver_small_data"]
+    lr = np.stack([np.full((channels, 2, 2), v) for v in L["lr_values"]])
+    p = sr.Problem(ctx, 4, 4, channels, 4, L["scale"], L["shifts"], 0, 0.0, sr.F64)
+    p.set_observations(lr)
+    o = sr.default_irls_options()
+    o.split_channels = int(split)
+    x, rep = p.solve(np.zeros((channels, 4, 4)), o)
+    exp = np.array(L["expected"])
+    for c in range(channels):
+        assert np.max(np.abs(x[c] - exp)) < L["tol"]
+    assert rep.evaluations > 0
+
+
+def test_map_solver_icon(sr, ctx, literals, fb_gray):
+    """test/test_map_solver.cpp:205-308: 28x28 icon, interior equals ground truth."""
+    L = literals["map_solver_icon"]
+    model = orc.ImageModel(scale=2, shifts=L["shifts"])
+    lr = np.stack([model.apply(fb_gray[None], k) for k in range(4)])
+    p = sr.Problem(ctx, 28, 28, 1, 4, 2, L["shifts"], 0, 0.0, sr.F64)
+    p.set_observations(lr)
+    x0 = orc.resize_nearest(lr[0, 0], 28, 28)[None]
+    x, rep = p.solve(x0)
+    assert np.max(np.abs(x[0, 1:27, 1:27] - fb_gray[1:27, 1:27])) < L["tol"]
+
+
+@pytest.mark.parametrize("dtype,reg", [(0, (2, 0.01, 3, 0.5)), (0, (0, 0.01, 0, 0.0)), (1, (2, 0.01, 3, 0.5))])
+def test_solver_psnr_parity_with_cpu_reference(sr, ctx, dtype, reg):
+    """End-to-end IRLS solve vs the CPU reference path (oracle objective driven
+    by the reference's ALGLIB when oracle/_ref is available, else by the
+    restatement): PSNR within 0.01 dB, same iteration structure."""
+    rng = np.random.default_rng(42)
+    s, K, h, w = 2, 4, 24, 24
+    H, W = h * s, w * s
+    u, v = np.meshgrid(np.linspace(0, 1, W), np.linspace(0, 1, H))
+    gt = np.clip(0.5 + 0.25 * np.sin(2 * np.pi * 3 * u) * np.cos(2 * np.pi * 5 * v)
+                 + 0.25 * (((u - .5) ** 2 + (v - .5) ** 2) < .09), 0, 1)[None]
+    shifts = [[0, 0], [1, 1], [0, 1], [1, 0]]
+    model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=3, blur_sigma=1.0)
+    lr = np.stack([model.apply(gt, k) for k in range(K)]) + (5 / 255) * rng.standard_normal((K, 1, h, w))
+    x0 = orc.resize_nearest(lr[0, 0], W, H)[None]
+    ref = orc.Problem(model, lr)
+    ref.add_regularizer(*reg)
+    x_ref, rep_ref = ref.solve(x0, use_alglib=orc.have_ref())
+    p = sr.Problem(ctx, W, H, 1, K, s, shifts, 3, 1.0, dtype)
+    p.set_observations(lr)
+    p.add_regularizer(*reg)
+    x, rep = p.solve(x0)
+    psnr_ref, psnr_gpu = orc.psnr(gt, x_ref), orc.psnr(gt, x)
+    print("PSNR cpu %.4f dB gpu %.4f dB; irls %d/%d cg %d/%d nfev %d/%d" % (
+        psnr_ref, psnr_gpu, rep_ref.irls_rounds, rep.irls_rounds, rep_ref.cg_iterations, rep.cg_iterations,
+        rep_ref.nfev, rep.evaluations))
+    assert abs(psnr_ref - psnr_gpu) < 0.01
+    if dtype == 0:
+        assert rep.irls_rounds == rep_ref.irls_rounds
+
+
+# --------------------------------------------- full-size property tests (cfg2)
+def _cfg2(sr, ctx, dtype, K=16):
+    s, w, h = 4, 512, 512
+    shifts = [[k % s, (k // s) % s] for k in range(K)]
+    p = sr.Problem(ctx, w * s, h * s, 1, K, s, shifts, 3, 1.0, dtype)
+    return p, shifts
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_full_size_adjoint_and_linearity(sr, ctx, dtype):
+    """2048x2048, 16 frames, 4x (BASELINE config 2): <A_k x, y> == <x, A_k^T y>
+    for integer shifts, and A_k(a x1 + x2) == a A_k x1 + A_k x2."""
+    p, shifts = _cfg2(sr, ctx, dtype)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((1, p.H, p.W))
+    x2 = rng.standard_normal((1, p.H, p.W))
+    y = rng.standard_normal((1, p.h, p.w))
+    tol = 1e-11 if dtype == 0 else 2e-4
+    for k in (0, 5, 15):
+        Ax = p.apply(x, k)
+        Aty = p.apply_transpose(y, k)
+        lhs, rhs = float((Ax * y).sum()), float((x * Aty).sum())
+        assert abs(lhs - rhs) <= tol * max(1.0, abs(lhs))
+        lin = p.apply(2.5 * x + x2, k)
+        assert relerr(lin, 2.5 * Ax + p.apply(x2, k)) <= (1e-12 if dtype == 0 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_full_size_objective_properties(sr, ctx, dtype):
+    """cfg2 objective: (i) cost(x*) of noise-free data is 0 and the data gradient
+    vanishes; (ii) directional derivative of the data term matches <g, d>;
+    (iii) data term equals the operator form s^2 sum ||A_k x - y_k||^2."""
+    p, shifts = _cfg2(sr, ctx, dtype, K=4)
+    rng = np.random.default_rng(3)
+    gt = rng.random((1, p.H, p.W))
+    lr = np.stack([p.apply(gt, k) for k in range(p.K)])
+    p.set_observations(lr)
+    f, g = p.eval(gt, sr.TERM_DATA)
+    assert f <= (1e-20 if dtype == 0 else 1e-6) and np.max(np.abs(g)) <= (1e-12 if dtype == 0 else 1e-4)
+    x = rng.random((1, p.H, p.W))
+    f0, g0 = p.eval(x, sr.TERM_DATA)
+    f_ops = 16.0 * sum(float(((p.apply(x, k) - lr[k]) ** 2).sum()) for k in range(p.K))
+    assert abs(f0 - f_ops) <= (1e-11 if dtype == 0 else 1e-5) * f_ops
+    d = rng.standard_normal(x.shape)
+    eps = 1e-2  # the data term is quadratic: central differences are exact for any eps
+    fp, _ = p.eval(x + eps * d, sr.TERM_DATA, want_grad=False)
+    fm, _ = p.eval(x - eps * d, sr.TERM_DATA, want_grad=False)
+    dd = float((g0 * d).sum())
+    assert abs((fp - fm) / (2 * eps) - dd) <= (1e-6 if dtype == 0 else 2e-2) * abs(dd)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_full_size_tiled_equals_direct(sr, ctx, dtype):
+    """The LDS-tiled fused kernels and the direct kernels are two independent
+    implementations: at cfg2 size they must agree."""
+    p, shifts = _cfg2(sr, ctx, dtype)
+    rng = np.random.default_rng(4)
+    lr = rng.random((p.K, 1, p.h, p.w))
+    p.set_observations(lr)
+    r = p.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
+    p.set_irls_weights(r, 0.5 + rng.random((1, p.H, p.W)))
+    x = rng.random((1, p.H, p.W))
+    p.set_impl(sr.IMPL_DIRECT)
+    f_d, g_d = p.eval(x)
+    try:
+        p.set_impl(sr.IMPL_TILED)
+        f_t, g_t = p.eval(x)
+    except sr.SrmapError as e:
+        if e.status == sr.EUNSUPPORTED:
+            pytest.skip("tiled kernels not available for this geometry")
+        raise
+    assert abs(f_t - f_d) <= (1e-12 if dtype == 0 else 1e-6) * abs(f_d)
+    assert relerr(g_t, g_d) <= (1e-12 if dtype == 0 else 2e-5)
