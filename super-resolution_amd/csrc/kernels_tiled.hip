@@ -1,16 +1,743 @@
-// kernels_tiled.hip -- LDS-tiled fused evaluation (placeholder until the
-// fused kernel lands; AUTO falls back to the direct kernels).
+// kernels_tiled.hip -- the hot path: ONE fused kernel per MAP gradient
+// iteration (ObjectiveFunction::ComputeAllTerms, objective_function.cpp:5-20)
+// for the common geometry: integer motion shifts, HR = LR * S, S in {2,3,4},
+// blur size B in {1,3}, and at most one regulariser handled in-kernel (2-D TV or
+// BTV with range <= 3); anything else is evaluated by kernels_direct.hip.
+//
+// Design (DESIGN.md "Fused evaluation kernel"):
+//   * A workgroup (256 threads, 4 waves) owns a tile of CH x CW LR cells = one
+//     S x S block of HR pixels per thread ("cell-major"): every thread reads x /
+//     IRLS weights and writes g as S-element vectors -> fully coalesced HBM
+//     traffic, each compulsory byte crosses HBM once (x halo re-reads hit L2).
+//   * The x tile (+halo) is staged in LDS in POLYPHASE layout
+//     xs[row][column phase (c mod S)][cell]: the decimated forward stencil
+//     (stride-S access) and the per-pixel regulariser windows both become
+//     unit-stride across lanes -> no LDS bank conflicts, all tap offsets are
+//     instruction immediates.
+//   * Per chunk of 4 frames: wave w computes the LR residuals r_k = A_k x - y_k
+//     of frame k0+w for the LR pixels the tile needs (warp -> blur -> decimate
+//     fused, objective_data_term.cpp:27-50) into LDS; then every thread gathers
+//     sum_k M_k^T B^T D^T r_k for its cell (image_model.cpp:93-101).  The
+//     frame's shift phase (shift mod S) selects one of S*S fully unrolled code
+//     paths by a wave-uniform switch, so tap positions and register targets
+//     are compile-time and each valid tap costs one FMA.
+//   * The regulariser (tv_regularizer.cpp:135-227 / btv_regularizer.cpp:93-170,
+//     bug-compatible) runs on the same x tile: pass 1 computes r and c*r for the
+//     tile plus an up/left halo into LDS and the self term, pass 2 adds the
+//     neighbour terms.
+//   * Cost partials (s^2 * sum r_k^2 and lambda * w * r^2) are reduced per
+//     workgroup in fp64 with wave shuffles and written to a partials buffer that
+//     the final one-block reduction sums in a fixed order (deterministic).
+// No MFMA: this is a stencil/gather path.
+#include <algorithm>
+#include <climits>
+
 #include "srmap_internal.hpp"
 
 namespace srmap {
 
-bool tiled_plan(srmap_problem*) { return false; }
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kFrameChunk = 4;   // frames per residual/gather round = waves per workgroup
+constexpr int kMaxHaloRows = 12; // max hu + hd of the x tile
+constexpr int kMaxHaloCells = 4; // max hlc + hrc
+
+template <typename T, int S>
+struct TileCfg {
+  static constexpr int CW = 32;                       // LR cells per tile row
+  static constexpr int CH = kThreads / CW;            // 8 cell rows
+  static constexpr int TH = CH * S, TW = CW * S;      // HR tile
+  static constexpr int XR = TH + kMaxHaloRows;        // x rows held in LDS
+  static constexpr int XCELLS = CW + kMaxHaloCells;   // cells per x row
+  static constexpr int XPLANE = XCELLS;               // elements per (row, phase)
+  static constexpr int XROW = S * XPLANE;             // elements per row
+  static constexpr int LRH = CH + 3, LRW = CW + 3;    // LR residual region (max)
+  static constexpr int CRCELLS = CW + 1;              // c*r: one halo cell column
+  static constexpr int CRPLANE = CRCELLS;
+  static constexpr int CRROW = S * CRPLANE;
+  static constexpr int CRR = TH + S;                  // one halo cell row
+  static constexpr int XS_ELEMS = XR * XROW;
+  static constexpr int RS_ELEMS = kFrameChunk * LRH * LRW;
+  static constexpr int CR_ELEMS = CRR * CRROW;
+  // rs (residuals) is dead once the gather is done; c*r reuses its space.
+  static constexpr int SCRATCH_ELEMS = RS_ELEMS > CR_ELEMS ? RS_ELEMS : CR_ELEMS;
+};
+
+// Per-frame shift decomposition, precomputed on the host.
+struct FrameInfo {
+  int frow;   // forward: tile-row offset  S*i0 + oy + hu - hb   (x rows)
+  int fcell;  // forward: cell offset      j0 + hlc + floor(ox / S)
+  int fxm;    // forward: ox mod S  (0..S-1)
+  int gbase;  // gather: (toyq - i0) * LRW + (toxq - j0)
+  int gym;    // gather: toy mod S
+  int gxm;    // gather: tox mod S
+  int toy, tox;  // transpose integer offsets (for the border test)
+};
+
+template <typename T, int B, int NP>
+struct FusedArgs {
+  const T* x;
+  const T* y;
+  const T* w;       // IRLS weights or nullptr
+  T* g;             // nullptr = cost only
+  double* partials;
+  const FrameInfo* frames;
+  int W, H, wl, hl, K;
+  int obs_C, obs_c0;
+  int hu, hlc;          // x tile origin = (R0 - hu, cell CJ0 - hlc)
+  int xrows, xcells;    // loaded extent
+  int i0, j0;           // LR region origin relative to the tile's first cell (<= 0)
+  int lrh, lrw;         // LR region extent
+  int margin;           // tiles closer than this to the image edge take the border path
+  int terms;            // SRMAP_TERM_*
+  T blur[B * B];        // k * k^T (blur_module.cpp:20-22)
+  T lambda;
+  T powtab[NP];         // BTV alpha^(i+j)
+};
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+constexpr int posmod(int a, int b) { return a - floordiv(a, b) * b; }
 
 template <typename T>
-int launch_eval_tiled(srmap_problem* p, const Geometry&, int, unsigned, const T*, T*, double*, int*,
-                      hipStream_t) {
-  return set_error(p->ctx, SRMAP_EUNSUPPORTED, "tiled kernels not built");
+__device__ __forceinline__ T sgnv(T d) { return d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0)); }
+template <typename T>
+__device__ __forceinline__ T absv(T d) { return d < T(0) ? -d : d; }
+
+// ---- forward residual of ONE LR pixel for a frame whose ox mod S == OXM ----
+// addr = element offset of xs[(S*li + 0 - hb + ...)][.][lj + ...] already
+// including the frame's scalar offsets; taps use immediates.
+template <typename T, int S, int B, int OXM, bool BORDER>
+__device__ __forceinline__ T forward_taps(const T* __restrict__ xs, int addr,
+                                          const T (&blur)[B * B], unsigned amask, unsigned emask) {
+  using C = TileCfg<T, S>;
+  constexpr int HB = (B - 1) / 2;
+  T acc = T(0);
+#pragma unroll
+  for (int a = 0; a < B; ++a) {
+#pragma unroll
+    for (int e = 0; e < B; ++e) {
+      const int ph = posmod(e - HB + OXM, S);
+      const int dc = floordiv(e - HB + OXM, S);
+      T v = xs[addr + a * C::XROW + ph * C::XPLANE + dc];
+      if (BORDER) {
+        // filter2D's BORDER_CONSTANT acts on the WARPED image: taps whose
+        // (rr, cc) fall outside the H x W domain contribute 0
+        if (!((amask >> a) & 1u) || !((emask >> e) & 1u)) v = T(0);
+      }
+      acc += blur[a * B + e] * v;
+    }
+  }
+  return acc;
 }
+
+// ---- gather of one frame into the S x S accumulators of one cell ----
+// rsb points at rs[(lci + toyq - i0)][(lcj + toxq - j0)] of the frame.
+template <typename T, int S, int B, int GYM, int GXM, bool BORDER>
+__device__ __forceinline__ void gather_case(T (&acc)[S][S], const T* __restrict__ rsb,
+                                            const T (&blur)[B * B], unsigned rmask, unsigned cmask) {
+  using C = TileCfg<T, S>;
+  constexpr int HB = (B - 1) / 2;
+#pragma unroll
+  for (int pr = 0; pr < S; ++pr) {
+#pragma unroll
+    for (int a = 0; a < B; ++a) {
+      if (posmod(pr + GYM + a - HB, S) != 0) continue;  // zero-insertion: only multiples of S carry data
+      const int dy = floordiv(pr + GYM + a - HB, S);
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) {
+#pragma unroll
+        for (int e = 0; e < B; ++e) {
+          if (posmod(pc + GXM + e - HB, S) != 0) continue;
+          const int dx = floordiv(pc + GXM + e - HB, S);
+          T val = rsb[dy * C::LRW + dx];  // identical addresses are CSE'd by the compiler
+          if (BORDER) {
+            // warpAffine(-dx,-dy) samples v_k at p' = p + (toy, tox); outside -> 0
+            if (!((rmask >> pr) & 1u) || !((cmask >> pc) & 1u)) val = T(0);
+          }
+          // kernel.t() (blur_module.cpp:35): Gt[a][e] = G[e][a]
+          acc[pr][pc] += blur[e * B + a] * val;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int S, int B, int GYM, bool BORDER>
+__device__ __forceinline__ void gather_switch_x(T (&acc)[S][S], const T* rsb, const T (&blur)[B * B],
+                                                int gxm, unsigned rmask, unsigned cmask) {
+  if (S >= 1 && gxm == 0) gather_case<T, S, B, GYM, 0, BORDER>(acc, rsb, blur, rmask, cmask);
+  if (S >= 2 && gxm == 1) gather_case<T, S, B, GYM, (S >= 2 ? 1 : 0), BORDER>(acc, rsb, blur, rmask, cmask);
+  if (S >= 3 && gxm == 2) gather_case<T, S, B, GYM, (S >= 3 ? 2 : 0), BORDER>(acc, rsb, blur, rmask, cmask);
+  if (S >= 4 && gxm == 3) gather_case<T, S, B, GYM, (S >= 4 ? 3 : 0), BORDER>(acc, rsb, blur, rmask, cmask);
+}
+
+template <typename T, int S, int B, bool BORDER>
+__device__ __forceinline__ void gather_switch(T (&acc)[S][S], const T* rsb, const T (&blur)[B * B],
+                                              int gym, int gxm, unsigned rmask, unsigned cmask) {
+  if (S >= 1 && gym == 0) gather_switch_x<T, S, B, 0, BORDER>(acc, rsb, blur, gxm, rmask, cmask);
+  if (S >= 2 && gym == 1) gather_switch_x<T, S, B, (S >= 2 ? 1 : 0), BORDER>(acc, rsb, blur, gxm, rmask, cmask);
+  if (S >= 3 && gym == 2) gather_switch_x<T, S, B, (S >= 3 ? 2 : 0), BORDER>(acc, rsb, blur, gxm, rmask, cmask);
+  if (S >= 4 && gym == 3) gather_switch_x<T, S, B, (S >= 4 ? 3 : 0), BORDER>(acc, rsb, blur, gxm, rmask, cmask);
+}
+
+template <typename T, int S, int B, int OXMAX, bool BORDER>
+__device__ __forceinline__ T forward_switch(const T* xs, int addr, const T (&blur)[B * B], int fxm,
+                                            unsigned amask, unsigned emask) {
+  T r = T(0);
+  if (fxm == 0) r = forward_taps<T, S, B, 0, BORDER>(xs, addr, blur, amask, emask);
+  if (S >= 2 && fxm == 1) r = forward_taps<T, S, B, (S >= 2 ? 1 : 0), BORDER>(xs, addr, blur, amask, emask);
+  if (S >= 3 && fxm == 2) r = forward_taps<T, S, B, (S >= 3 ? 2 : 0), BORDER>(xs, addr, blur, amask, emask);
+  if (S >= 4 && fxm == 3) r = forward_taps<T, S, B, (S >= 4 ? 3 : 0), BORDER>(xs, addr, blur, amask, emask);
+  return r;
+}
+
+// ---- regulariser pass 1 for one cell: values r, c*r products, self term ----
+// cell at tile-relative cell coords (ci, cj) in [-1, CH) x [-1, CW); xcell/xrow
+// locate its first pixel in xs.  Stores 2*c*r (0 for pixels outside the image
+// and for the absolute pixel (0,0), btv_regularizer.cpp:143-146) into cr.
+template <typename T, int S, int REGK, int R, int NP, bool BORDER, bool OWNED>
+__device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T* __restrict__ xs,
+                                          T* __restrict__ cr, const T* __restrict__ wplane,
+                                          int xrow0, int xcell0, int crrow0, int crcell0, int gr0, int gc0,
+                                          int W, int H, T lambda, const T (&pw)[NP]) {
+  using C = TileCfg<T, S>;
+  constexpr int WIN = (REGK == 2) ? R : 1;  // taps extend WIN pixels right/down
+  constexpr int NC = S + WIN;               // columns of x needed per row
+  T win[WIN + 1][NC];
+  // preload rows 0..WIN-1 of the rolling window
+#pragma unroll
+  for (int i = 0; i < WIN; ++i)
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      win[i][j] = xs[(xrow0 + i) * C::XROW + (j % S) * C::XPLANE + xcell0 + j / S];
+#pragma unroll
+  for (int pr = 0; pr < S; ++pr) {
+    // row (pr + WIN) enters the window at slot (pr + WIN) % (WIN + 1)
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      win[(pr + WIN) % (WIN + 1)][j] = xs[(xrow0 + pr + WIN) * C::XROW + (j % S) * C::XPLANE + xcell0 + j / S];
+    const int gr = gr0 + pr;
+    T wv[S];
+    if (wplane != nullptr && gr >= 0 && gr < H && gc0 >= 0 && gc0 < W) {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) wv[pc] = wplane[(size_t)gr * W + gc0 + pc];
+    } else {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) wv[pc] = T(1);
+    }
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      const T x0 = win[pr % (WIN + 1)][pc];
+      T r = T(0), didi = T(0);
+      if (REGK == 2) {
+#pragma unroll
+        for (int i = 0; i <= R; ++i) {
+#pragma unroll
+          for (int j = 0; j <= R; ++j) {
+            if (i == 0 && j == 0) continue;  // |x0 - x0| = 0 and sgn(0) = 0
+            const T d = x0 - win[(pr + i) % (WIN + 1)][pc + j];
+            bool inside = true;
+            if (BORDER) inside = (gr + i < H) && (gc0 + pc + j < W);
+            if (inside) {
+              r += pw[i + j] * absv(d);
+              if (i < R && j < R) didi += pw[i + j] * sgnv(d);  // exclusive window in the gradient
+            }
+          }
+        }
+      } else {
+        const T dyv = win[(pr + 1) % (WIN + 1)][pc] - x0;
+        const T dxv = win[pr % (WIN + 1)][pc + 1] - x0;
+        bool iny = true, inx = true;
+        if (BORDER) { iny = gr + 1 < H; inx = gc0 + pc + 1 < W; }
+        const T yv = iny ? absv(dyv) : T(0);
+        const T xv = inx ? absv(dxv) : T(0);
+        r = yv + xv;
+        if (inx) didi -= sgnv(dxv);
+        if (iny) didi -= sgnv(dyv);
+      }
+      const T c = lambda * wv[pc];
+      T cr2 = T(2) * c * r;
+      const bool in_img = gr >= 0 && gr < H && gc0 + pc >= 0 && gc0 + pc < W;
+      if (OWNED) {
+        acc[pr][pc] += cr2 * didi;
+        if (in_img) cost += (double)c * (double)r * (double)r;
+      }
+      if (!in_img || (gr == 0 && gc0 + pc == 0)) cr2 = T(0);
+      cr[(crrow0 + pr) * C::CRROW + pc * C::CRPLANE + crcell0] = cr2;
+    }
+  }
+}
+
+// ---- regulariser pass 2: contributions of up/left neighbours ----
+template <typename T, int S, int REGK, int R, int NP>
+__device__ __forceinline__ void reg_pass2(T (&acc)[S][S], const T* __restrict__ xs,
+                                          const T* __restrict__ cr, int xrow0, int xcell0, int crrow0,
+                                          int crcell0, const T (&pw)[NP]) {
+  using C = TileCfg<T, S>;
+  constexpr int RU = (REGK == 2) ? R - 1 : 1;  // neighbours reach RU pixels up/left
+  if (RU == 0) return;
+  constexpr int NC = S + RU;
+  // windows cover rows (pr - RU .. pr), columns (-RU .. S-1) of the cell
+  T xw[RU + 1][NC], cw[RU + 1][NC];
+#pragma unroll
+  for (int i = 0; i < RU; ++i) {  // rows -RU .. -1 relative to the cell
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int col = j - RU, ph = posmod(col, S), dc = floordiv(col, S);
+      xw[posmod(i - RU, RU + 1)][j] = xs[(xrow0 + i - RU) * C::XROW + ph * C::XPLANE + xcell0 + dc];
+      cw[posmod(i - RU, RU + 1)][j] = cr[(crrow0 + i - RU) * C::CRROW + ph * C::CRPLANE + crcell0 + dc];
+    }
+  }
+#pragma unroll
+  for (int pr = 0; pr < S; ++pr) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int col = j - RU, ph = posmod(col, S), dc = floordiv(col, S);
+      xw[pr % (RU + 1)][j] = xs[(xrow0 + pr) * C::XROW + ph * C::XPLANE + xcell0 + dc];
+      cw[pr % (RU + 1)][j] = cr[(crrow0 + pr) * C::CRROW + ph * C::CRPLANE + crcell0 + dc];
+    }
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      const T x0 = xw[pr % (RU + 1)][pc + RU];
+      T sum = T(0);
+      if (REGK == 2) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            if (i == 0 && j == 0) continue;
+            const T xq = xw[posmod(pr - i, RU + 1)][pc + RU - j];
+            const T cq = cw[posmod(pr - i, RU + 1)][pc + RU - j];
+            sum += cq * (-sgnv(xq - x0) * pw[i + j]);
+          }
+        }
+      } else {
+        // left and above (tv_regularizer.cpp:172-203)
+        sum += cw[pr % (RU + 1)][pc + RU - 1] * sgnv(x0 - xw[pr % (RU + 1)][pc + RU - 1]);
+        sum += cw[posmod(pr - 1, RU + 1)][pc + RU] * sgnv(x0 - xw[posmod(pr - 1, RU + 1)][pc + RU]);
+      }
+      acc[pr][pc] += sum;
+    }
+  }
+}
+
+template <typename T, int S, int B, int REGK, int R>
+__global__ __launch_bounds__(kThreads) void k_eval_fused(
+    FusedArgs<T, B, (REGK == 2 ? 2 * R + 1 : 1)> A) {
+  using C = TileCfg<T, S>;
+  constexpr int NP = (REGK == 2 ? 2 * R + 1 : 1);
+  constexpr int HB = (B - 1) / 2;
+  __shared__ T xs[C::XS_ELEMS];
+  __shared__ T scratch[C::SCRATCH_ELEMS];
+  __shared__ double red[2][4];
+  T* rs = scratch;
+  T* cr = scratch;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int CI0 = blockIdx.y * C::CH, CJ0 = blockIdx.x * C::CW;
+  const int R0 = CI0 * S, C0 = CJ0 * S;
+  const int ch = blockIdx.z;
+  const size_t N = (size_t)A.W * A.H;
+  const T* xplane = A.x + (size_t)ch * N;
+  const bool border = (R0 < A.margin) || (R0 + C::TH + A.margin > A.H) || (C0 < A.margin) ||
+                      (C0 + C::TW + A.margin > A.W);
+
+  // ---------------- Phase A: x tile (+halo) -> LDS, polyphase ----------------
+  {
+    const int total = A.xrows * A.xcells;
+    const float inv = 1.0f / (float)A.xcells;
+    for (int idx = tid; idx < total; idx += kThreads) {
+      int row = (int)(((float)idx + 0.5f) * inv);
+      int cell = idx - row * A.xcells;
+      const int gr = R0 - A.hu + row;
+      const int gcell = CJ0 - A.hlc + cell;
+      T vals[S];
+      if (gr >= 0 && gr < A.H && gcell >= 0 && gcell < A.wl) {
+        const T* src = xplane + (size_t)gr * A.W + (size_t)gcell * S;
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) vals[pc] = src[pc];
+      } else {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) vals[pc] = T(0);
+      }
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XPLANE + cell] = vals[pc];
+    }
+  }
+  __syncthreads();
+
+  const int lci = tid / C::CW, lcj = tid - lci * C::CW;  // this thread's cell
+  T acc[S][S];
+#pragma unroll
+  for (int i = 0; i < S; ++i)
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[i][j] = T(0);
+  double cost_data = 0.0, cost_reg = 0.0;
+
+  if (A.terms & SRMAP_TERM_DATA) {
+    const int nlr = A.lrh * A.lrw;
+    const float invw = 1.0f / (float)A.lrw;
+    const size_t nl = (size_t)A.wl * A.hl;
+    for (int k0 = 0; k0 < A.K; k0 += kFrameChunk) {
+      // ---------------- Phase B: residuals of frame k0 + wave ----------------
+      const int k = k0 + wv;
+      if (k < A.K) {
+        const FrameInfo fi = A.frames[k];
+        const T* yk = A.y + ((size_t)k * A.obs_C + ch + A.obs_c0) * nl;
+        T* rsk = rs + wv * (C::LRH * C::LRW);
+        for (int idx = lane; idx < nlr; idx += 64) {
+          const int li = (int)(((float)idx + 0.5f) * invw);
+          const int lj = idx - li * A.lrw;
+          const int gi = CI0 + A.i0 + li, gj = CJ0 + A.j0 + lj;
+          T res = T(0);
+          if (gi >= 0 && gi < A.hl && gj >= 0 && gj < A.wl) {
+            const int addr = (S * li + fi.frow) * C::XROW + lj + fi.fcell;
+            unsigned amask = 0xffffffffu, emask = 0xffffffffu;
+            if (border) {
+              amask = 0; emask = 0;
+#pragma unroll
+              for (int a = 0; a < B; ++a) {
+                const int rr = S * gi + a - HB, cc = S * gj + a - HB;
+                if (rr >= 0 && rr < A.H) amask |= 1u << a;
+                if (cc >= 0 && cc < A.W) emask |= 1u << a;
+              }
+              res = forward_switch<T, S, B, S, true>(xs, addr, A.blur, fi.fxm, amask, emask);
+            } else {
+              res = forward_switch<T, S, B, S, false>(xs, addr, A.blur, fi.fxm, amask, emask);
+            }
+            res -= yk[(size_t)gi * A.wl + gj];
+            // each LR pixel is owned by exactly one tile
+            if (gi >= CI0 && gi < CI0 + C::CH && gj >= CJ0 && gj < CJ0 + C::CW)
+              cost_data += (double)res * (double)res;
+          }
+          rsk[li * C::LRW + lj] = res;
+        }
+      }
+      __syncthreads();
+      // ---------------- Phase C: gather into this thread's cell ----------------
+      if (A.g != nullptr) {
+        const int kc = (A.K - k0) < kFrameChunk ? (A.K - k0) : kFrameChunk;
+        for (int kk = 0; kk < kc; ++kk) {
+          const FrameInfo fi = A.frames[k0 + kk];
+          const T* rsb = rs + kk * (C::LRH * C::LRW) + lci * C::LRW + lcj + fi.gbase;
+          if (border) {
+            unsigned rmask = 0, cmask = 0;
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+              const int pr_ = R0 + S * lci + q + fi.toy, pc_ = C0 + S * lcj + q + fi.tox;
+              if (pr_ >= 0 && pr_ < A.H) rmask |= 1u << q;
+              if (pc_ >= 0 && pc_ < A.W) cmask |= 1u << q;
+            }
+            gather_switch<T, S, B, true>(acc, rsb, A.blur, fi.gym, fi.gxm, rmask, cmask);
+          } else {
+            gather_switch<T, S, B, false>(acc, rsb, A.blur, fi.gym, fi.gxm, 0xffffffffu, 0xffffffffu);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+      for (int j = 0; j < S; ++j) acc[i][j] *= sc;
+  }
+
+  // ---------------- Phase D: regulariser ----------------
+  if (REGK != 0 && (A.terms & SRMAP_TERM_REG)) {
+    const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
+    // pass 1: owned cell
+    {
+      const int xrow0 = A.hu + S * lci, xcell0 = A.hlc + lcj;
+      if (border)
+        reg_pass1<T, S, REGK, R, NP, true, true>(acc, cost_reg, xs, cr, wplane, xrow0, xcell0, S * (lci + 1),
+                                                 lcj + 1, R0 + S * lci, C0 + S * lcj, A.W, A.H, A.lambda, A.powtab);
+      else
+        reg_pass1<T, S, REGK, R, NP, false, true>(acc, cost_reg, xs, cr, wplane, xrow0, xcell0, S * (lci + 1),
+                                                  lcj + 1, R0 + S * lci, C0 + S * lcj, A.W, A.H, A.lambda, A.powtab);
+    }
+    // pass 1 for the halo cells: row -1 (cells -1..CW-1) and column -1 (rows 0..CH-1)
+    if (tid < C::CW + 1 + C::CH) {
+      int hci, hcj;
+      if (tid < C::CW + 1) { hci = -1; hcj = tid - 1; } else { hci = tid - (C::CW + 1); hcj = -1; }
+      double dcost = 0;  // OWNED = false: acc and cost are not touched
+      reg_pass1<T, S, REGK, R, NP, true, false>(acc, dcost, xs, cr, wplane, A.hu + S * hci, A.hlc + hcj,
+                                                S * (hci + 1), hcj + 1, R0 + S * hci, C0 + S * hcj, A.W, A.H,
+                                                A.lambda, A.powtab);
+    }
+    __syncthreads();
+    if (A.g != nullptr)
+      reg_pass2<T, S, REGK, R, NP>(acc, xs, cr, A.hu + S * lci, A.hlc + lcj, S * (lci + 1), lcj + 1, A.powtab);
+  }
+
+  // ---------------- write g (S-element rows per thread, coalesced) ----------------
+  if (A.g != nullptr) {
+    const int gcj = CJ0 + lcj;
+    if (gcj < A.wl) {
+#pragma unroll
+      for (int pr = 0; pr < S; ++pr) {
+        const int gr = R0 + S * lci + pr;
+        if (gr < A.H) {
+          T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + (size_t)gcj * S;
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pr][pc];
+        }
+      }
+    }
+  }
+
+  // ---------------- cost partials ----------------
+  {
+    const double sd = wave_sum_d(cost_data);
+    const double sr = wave_sum_d(cost_reg);
+    if (lane == 0) { red[0][wv] = sd; red[1][wv] = sr; }
+    __syncthreads();
+    if (tid == 0) {
+      const double d = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      const double r = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      A.partials[b] = (double)(S * S) * d + r;
+    }
+  }
+}
+
+// integer floor division / modulo on the host
+inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+inline int pmod(int a, int b) { return a - fdiv(a, b) * b; }
+
+struct HostPlan {
+  bool ok = false;
+  int hu = 0, hd = 0, hlc = 0, hrc = 0, i0 = 0, j0 = 0, lrh = 0, lrw = 0, margin = 0;
+  int regk = 0, regr = 0, reg_index = -1;
+  std::vector<FrameInfo> frames;
+};
+
+// Decide whether the fused kernel covers the problem and derive the tile halos.
+template <int S>
+static HostPlan make_plan(const srmap_problem* p, int CH, int CW) {
+  HostPlan pl;
+  const Geometry& g = p->geo;
+  const int B = g.b, hb = g.hb, K = g.K;
+  if (!p->maps_regular) return pl;
+  if (B != 1 && B != 3) return pl;
+  // integer shifts only
+  std::vector<int> ox(K, 0), oy(K, 0), tx(K, 0), ty(K, 0);
+  if (p->has_motion) {
+    for (int k = 0; k < K; ++k) {
+      if (p->fwd_warps[k].ntaps != 1 || p->bwd_warps[k].ntaps != 1) return pl;
+      ox[k] = p->fwd_warps[k].ox; oy[k] = p->fwd_warps[k].oy;
+      tx[k] = p->bwd_warps[k].ox; ty[k] = p->bwd_warps[k].oy;
+    }
+  }
+  // the one regulariser handled in-kernel (first TV / BTV with lambda > 0)
+  for (int r = 0; r < p->nreg && pl.regk == 0; ++r) {
+    const RegSpec& rs = p->reg[r];
+    if (rs.lambda <= 0) continue;
+    if (rs.kind == SRMAP_REG_TV) { pl.regk = 1; pl.reg_index = r; }
+    else if (rs.kind == SRMAP_REG_BTV && rs.range >= 1 && rs.range <= 3 && rs.range - 1 <= S) {
+      pl.regk = 2; pl.regr = rs.range; pl.reg_index = r;
+    }
+    break;  // only the first active regulariser may be fused (order of accumulation)
+  }
+  // LR region needed by the gather (+ the owned pixels)
+  int dimin = 0, dimax = 0, djmin = 0, djmax = 0;
+  int amax = 0;
+  for (int k = 0; k < K; ++k) {
+    dimin = std::min(dimin, -fdiv(-(ty[k] - hb), S));            // ceil((toy-hb)/S)
+    dimax = std::max(dimax, fdiv(ty[k] + S - 1 + B - 1 - hb, S));
+    djmin = std::min(djmin, -fdiv(-(tx[k] - hb), S));
+    djmax = std::max(djmax, fdiv(tx[k] + S - 1 + B - 1 - hb, S));
+    amax = std::max(amax, std::max(std::abs(ty[k]), std::abs(tx[k])));
+    amax = std::max(amax, std::max(std::abs(oy[k]), std::abs(ox[k])));
+  }
+  pl.i0 = dimin; pl.j0 = djmin;
+  pl.lrh = CH + dimax - dimin; pl.lrw = CW + djmax - djmin;
+  if (pl.lrh > CH + 3 || pl.lrw > CW + 3) return pl;
+  // x rows/cols the forward model touches for those LR pixels (tile-relative)
+  int rmin = 0, rmax = CH * S - 1, cmin = 0, cmax = CW * S - 1;
+  for (int k = 0; k < K; ++k) {
+    rmin = std::min(rmin, S * dimin - hb + oy[k]);
+    rmax = std::max(rmax, S * (CH - 1 + dimax) + (B - 1 - hb) + oy[k]);
+    cmin = std::min(cmin, S * djmin - hb + ox[k]);
+    cmax = std::max(cmax, S * (CW - 1 + djmax) + (B - 1 - hb) + ox[k]);
+  }
+  if (pl.regk) {
+    const int win = pl.regk == 2 ? pl.regr : 1;
+    rmin = std::min(rmin, -S);                      // halo cell row / column
+    cmin = std::min(cmin, -S);
+    rmax = std::max(rmax, CH * S - 1 + win);
+    cmax = std::max(cmax, CW * S - 1 + win);
+  }
+  pl.hu = -rmin;
+  pl.hd = rmax - (CH * S - 1);
+  pl.hlc = -fdiv(cmin, S);
+  pl.hrc = fdiv(cmax, S) - (CW - 1);
+  if (pl.hu + pl.hd > kMaxHaloRows || pl.hlc + pl.hrc > kMaxHaloCells) return pl;
+  pl.margin = std::max(std::max(pl.hu, pl.hd), std::max(pl.hlc, pl.hrc) * S) + amax + hb + 4;
+  pl.frames.resize(K);
+  for (int k = 0; k < K; ++k) {
+    FrameInfo& f = pl.frames[k];
+    f.frow = S * pl.i0 + oy[k] + pl.hu - hb;
+    f.fcell = pl.j0 + pl.hlc + fdiv(ox[k], S);
+    f.fxm = pmod(ox[k], S);
+    f.gbase = (fdiv(ty[k], S) - pl.i0) * (CW + 3) + (fdiv(tx[k], S) - pl.j0);
+    f.gym = pmod(ty[k], S);
+    f.gxm = pmod(tx[k], S);
+    f.toy = ty[k]; f.tox = tx[k];
+  }
+  pl.ok = true;
+  return pl;
+}
+
+struct PlanCache {
+  HostPlan plan;
+  FrameInfo* d_frames = nullptr;
+};
+
+}  // namespace
+
+// The plan is rebuilt whenever the regulariser list changes (cheap, host only)
+// and cached on the problem through an opaque pointer table.
+static std::vector<std::pair<const srmap_problem*, PlanCache>>& plan_table() {
+  static std::vector<std::pair<const srmap_problem*, PlanCache>> t;
+  return t;
+}
+
+static PlanCache* find_plan(const srmap_problem* p) {
+  for (auto& e : plan_table()) if (e.first == p) return &e.second;
+  return nullptr;
+}
+
+void tiled_release(srmap_problem* p) {
+  auto& t = plan_table();
+  for (size_t i = 0; i < t.size(); ++i)
+    if (t[i].first == p) {
+      if (t[i].second.d_frames) (void)hipFree(t[i].second.d_frames);
+      t.erase(t.begin() + i);
+      return;
+    }
+}
+
+bool tiled_plan(srmap_problem* p) {
+  tiled_release(p);
+  const int S = p->geo.s;
+  HostPlan pl;
+  if (S == 2) pl = make_plan<2>(p, TileCfg<float, 2>::CH, TileCfg<float, 2>::CW);
+  else if (S == 3) pl = make_plan<3>(p, TileCfg<float, 3>::CH, TileCfg<float, 3>::CW);
+  else if (S == 4) pl = make_plan<4>(p, TileCfg<float, 4>::CH, TileCfg<float, 4>::CW);
+  if (!pl.ok) return false;
+  PlanCache pc;
+  pc.plan = pl;
+  if (hipMalloc((void**)&pc.d_frames, sizeof(FrameInfo) * pl.frames.size()) != hipSuccess) return false;
+  if (hipMemcpy(pc.d_frames, pl.frames.data(), sizeof(FrameInfo) * pl.frames.size(), hipMemcpyHostToDevice) !=
+      hipSuccess) {
+    (void)hipFree(pc.d_frames);
+    return false;
+  }
+  plan_table().push_back({p, pc});
+  return true;
+}
+
+template <typename T, int S, int B, int REGK, int R>
+static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
+                        const T* wts, const PlanCache& pc, double* partials, int* nblocks, hipStream_t st) {
+  using C = TileCfg<T, S>;
+  constexpr int NP = (REGK == 2 ? 2 * R + 1 : 1);
+  const HostPlan& pl = pc.plan;
+  FusedArgs<T, B, NP> A;
+  A.x = x; A.y = (const T*)p->d_obs; A.w = wts; A.g = g; A.partials = partials;
+  A.frames = pc.d_frames;
+  A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h; A.K = geo.K;
+  A.obs_C = p->geo.C; A.obs_c0 = obs_c0;
+  A.hu = pl.hu; A.hlc = pl.hlc;
+  A.xrows = C::TH + pl.hu + pl.hd;
+  A.xcells = C::CW + pl.hlc + pl.hrc;
+  A.i0 = pl.i0; A.j0 = pl.j0; A.lrh = pl.lrh; A.lrw = pl.lrw;
+  A.margin = pl.margin;
+  A.terms = (int)terms;
+  for (int i = 0; i < B * B; ++i) A.blur[i] = (T)p->blur2d[i];
+  A.lambda = T(0);
+  for (int i = 0; i < NP; ++i) A.powtab[i] = T(1);
+  if (REGK != 0) {
+    const RegSpec& rs = p->reg[pl.reg_index];
+    A.lambda = (T)rs.lambda;
+    if (REGK == 2) for (int i = 0; i < NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
+  }
+  dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.h + C::CH - 1) / C::CH, geo.C);
+  hipLaunchKernelGGL((k_eval_fused<T, S, B, REGK, R>), grid, dim3(kThreads), 0, st, A);
+  *nblocks = (int)(grid.x * grid.y * grid.z);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+template <typename T, int S, int B>
+static int dispatch_reg(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
+                        const T* wts, const PlanCache& pc, int regk, int regr, double* partials, int* nb,
+                        hipStream_t st) {
+  if (regk == 1) return launch_fused<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
+  if (regk == 2 && regr == 1) return launch_fused<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
+  if (regk == 2 && regr == 2) return launch_fused<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
+  if (regk == 2 && regr == 3) return launch_fused<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
+  return launch_fused<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
+}
+
+template <typename T>
+int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
+                      double* partials, int* nblocks, hipStream_t st) {
+  PlanCache* pc = find_plan(p);
+  if (!pc) return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile plan");
+  const HostPlan& pl = pc->plan;
+  const size_t N = (size_t)geo.W * geo.H;
+  // which regularisers the fused kernel takes, which go to the direct kernels
+  int regk = 0, regr = 0;
+  const bool want_reg = (terms & SRMAP_TERM_REG) != 0;
+  const T* wts = nullptr;
+  if (want_reg && pl.regk != 0 && !(pl.regk == 2 && geo.s == 2 && pl.regr == 3 && false)) {
+    regk = pl.regk; regr = pl.regr;
+    const RegSpec& rs = p->reg[pl.reg_index];
+    wts = rs.weights ? (const T*)rs.weights + (size_t)obs_c0 * N : nullptr;
+  }
+  unsigned fused_terms = terms & SRMAP_TERM_DATA;
+  if (regk) fused_terms |= SRMAP_TERM_REG;
+  int rc = SRMAP_OK, nb = 0;
+  if (geo.s == 2 && geo.b == 1) rc = dispatch_reg<T, 2, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
+  else if (geo.s == 2 && geo.b == 3) rc = dispatch_reg<T, 2, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
+  else if (geo.s == 3 && geo.b == 1) rc = dispatch_reg<T, 3, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
+  else if (geo.s == 3 && geo.b == 3) rc = dispatch_reg<T, 3, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
+  else if (geo.s == 4 && geo.b == 1) rc = dispatch_reg<T, 4, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
+  else if (geo.s == 4 && geo.b == 3) rc = dispatch_reg<T, 4, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
+  else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no fused kernel for scale %d blur %d", geo.s, geo.b);
+  if (rc) return rc;
+  int total = nb;
+  // remaining regularisers (TV3D, a second regulariser, BTV range > 3): direct kernels
+  if (want_reg) {
+    for (int r = 0; r < p->nreg; ++r) {
+      if (regk && r == pl.reg_index) continue;
+      const RegSpec& rs = p->reg[r];
+      if (rs.lambda <= 0.0) continue;
+      if (!p->d_regvals) SRMAP_HIP(p->ctx, hipMalloc(&p->d_regvals, p->hr_count() * sizeof(T)));
+      rc = launch_reg_values<T>(p, geo, rs, x, (T*)p->d_regvals, st);
+      if (rc) return rc;
+      const T* w2 = rs.weights ? (const T*)rs.weights + (size_t)obs_c0 * N : nullptr;
+      int nb2 = 0;
+      rc = launch_reg_gradient_direct<T>(p, geo, rs, x, w2, rs.lambda, (const T*)p->d_regvals, g, true,
+                                         partials + total, &nb2, st);
+      if (rc) return rc;
+      total += nb2;
+    }
+  }
+  *nblocks = total;
+  return SRMAP_OK;
+}
+
 template int launch_eval_tiled<float>(srmap_problem*, const Geometry&, int, unsigned, const float*, float*,
                                       double*, int*, hipStream_t);
 template int launch_eval_tiled<double>(srmap_problem*, const Geometry&, int, unsigned, const double*,

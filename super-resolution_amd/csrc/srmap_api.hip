@@ -389,6 +389,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
 
 void srmap_problem_destroy(srmap_problem* p) {
   if (!p) return;
+  tiled_release(p);
   void* bufs[] = {p->d_fwd_warps, p->d_bwd_warps, p->d_blur, p->d_blur_t, p->d_col_map, p->d_row_map,
                   p->d_obs, p->d_resid, p->d_regvals, p->d_x, p->d_g, p->d_tmp, p->d_partials, p->d_cost};
   for (void* b : bufs) if (b) (void)hipFree(b);

@@ -143,6 +143,7 @@ int launch_reduce_partials(srmap_problem* p, const double* partials, int n,
 
 // ---- LDS-tiled kernels (kernels_tiled.hip) ----
 bool tiled_plan(srmap_problem* p);
+void tiled_release(srmap_problem* p);
 template <typename T>
 int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,
                       const T* x, T* g, double* partials, int* nblocks, hipStream_t st);

