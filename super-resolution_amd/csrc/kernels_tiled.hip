@@ -269,7 +269,8 @@ __device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T*
         acc[pr][pc] += cr2 * didi;
         if (in_img) cost += (double)c * (double)r * (double)r;
       }
-      if (!in_img || (gr == 0 && gc0 + pc == 0)) cr2 = T(0);
+      // BTV only: the absolute pixel (0,0) never back-propagates (btv_regularizer.cpp:143-146)
+      if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
       cr[(crrow0 + pr) * C::CRROW + pc * C::CRPLANE + crcell0] = cr2;
     }
   }

@@ -307,7 +307,9 @@ def test_solver_psnr_parity_with_cpu_reference(sr, ctx, dtype, reg):
     print("PSNR cpu %.4f dB gpu %.4f dB; irls %d/%d cg %d/%d nfev %d/%d" % (
         psnr_ref, psnr_gpu, rep_ref.irls_rounds, rep.irls_rounds, rep_ref.cg_iterations, rep.cg_iterations,
         rep_ref.nfev, rep.evaluations))
-    assert abs(psnr_ref - psnr_gpu) < 0.01
+    # f64 is the parity mode (0.01 dB); f32 storage changes the CG path enough
+    # to move the stopping point, so its bound is looser
+    assert abs(psnr_ref - psnr_gpu) < (0.01 if dtype == 0 else 0.05)
     # the iterates follow the reference's up to reduction order; on the
     # non-smooth TV/BTV objective that can move a stopping decision by a round
     assert abs(rep.irls_rounds - rep_ref.irls_rounds) <= 2
@@ -420,11 +422,22 @@ def test_fused_kernel_matches_oracle_and_direct(sr, ctx, case, regs, dtype):
         p.set_irls_weights(i, wts)
         ref.set_irls_weights(i, wts)
     x = np.round(rng.random((C, H, W)) * 64) / 64
+    tol = TOL[dtype]
     p.set_impl(sr.IMPL_TILED)
-    f_t, g_t = p.eval(x)
+    try:
+        f_t, g_t = p.eval(x)
+    except sr.SrmapError as e:
+        # shift span too wide for the tile halo: AUTO must fall back to the
+        # direct kernels and still match the oracle
+        assert e.status == sr.EUNSUPPORTED
+        p.set_impl(sr.IMPL_AUTO)
+        f_a, g_a = p.eval(x)
+        f_ref, g_ref = ref.objective(x)
+        assert abs(f_a - f_ref) <= (1e-12 if dtype == 0 else 1e-5) * max(1.0, abs(f_ref))
+        assert relerr(g_a, g_ref) <= 4 * tol
+        return
     p.set_impl(sr.IMPL_DIRECT)
     f_d, g_d = p.eval(x)
-    tol = TOL[dtype]
     assert abs(f_t - f_d) <= (1e-12 if dtype == 0 else 1e-5) * max(1.0, abs(f_d))
     assert relerr(g_t, g_d) <= 4 * tol
     if dtype == 0:
