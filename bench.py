@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--shard", choices=["channels", "frames"], default="channels")
     ap.add_argument("--impl", choices=["auto", "direct", "tiled"], default="auto")
     ap.add_argument("--hr", type=int, default=2048)
+    ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
+                    help="ablation only: evaluate a subset of the objective terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -156,7 +158,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
     cost_buf = torch.zeros(1, dtype=torch.float64, device=dev)
-    terms = srmap.TERM_ALL
+    terms = {"all": srmap.TERM_ALL, "data": srmap.TERM_DATA, "reg": srmap.TERM_REG}[args.terms]
     if world > 1 and args.shard == "frames" and rank != 0:
         terms = srmap.TERM_DATA  # the regulariser term is evaluated once (rank 0)
 

@@ -31,6 +31,7 @@
 // No MFMA: this is a stencil/gather path.
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 #include "srmap_internal.hpp"
 
@@ -105,10 +106,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 constexpr int posmod(int a, int b) { return a - floordiv(a, b) * b; }
 
+// sgn(d) * pw with sgn(0) = 0 (pw > 0).  f32: ldexp pushes every non-zero d
+// (subnormals included) beyond pw, med3 clamps to +-pw: 2 VALU ops, exact.
 template <typename T>
-__device__ __forceinline__ T sgnv(T d) { return d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0)); }
+__device__ __forceinline__ T sgn_scaled(T d, T pw) { return d > T(0) ? pw : (d < T(0) ? -pw : T(0)); }
+template <>
+__device__ __forceinline__ float sgn_scaled<float>(float d, float pw) {
+  return __builtin_amdgcn_fmed3f(__builtin_ldexpf(d, 200), -pw, pw);
+}
+template <typename T>
+__device__ __forceinline__ T sgnv(T d) { return sgn_scaled<T>(d, T(1)); }
 template <typename T>
 __device__ __forceinline__ T absv(T d) { return d < T(0) ? -d : d; }
+template <>
+__device__ __forceinline__ float absv<float>(float d) { return __builtin_fabsf(d); }
+template <>
+__device__ __forceinline__ double absv<double>(double d) { return __builtin_fabs(d); }
 
 // ---- forward residual of ONE LR pixel for a frame whose ox mod S == OXM ----
 // addr = element offset of xs[(S*li + 0 - hb + ...)][.][lj + ...] already
@@ -129,7 +142,7 @@ __device__ __forceinline__ T forward_taps(const T* __restrict__ xs, int addr,
       if (BORDER) {
         // filter2D's BORDER_CONSTANT acts on the WARPED image: taps whose
         // (rr, cc) fall outside the H x W domain contribute 0
-        if (!((amask >> a) & 1u) || !((emask >> e) & 1u)) v = T(0);
+        v = (((amask >> a) & (emask >> e)) & 1u) ? v : T(0);
       }
       acc += blur[a * B + e] * v;
     }
@@ -159,7 +172,7 @@ __device__ __forceinline__ void gather_case(T (&acc)[S][S], const T* __restrict_
           T val = rsb[dy * C::LRW + dx];  // identical addresses are CSE'd by the compiler
           if (BORDER) {
             // warpAffine(-dx,-dy) samples v_k at p' = p + (toy, tox); outside -> 0
-            if (!((rmask >> pr) & 1u) || !((cmask >> pc) & 1u)) val = T(0);
+            val = (((rmask >> pr) & (cmask >> pc)) & 1u) ? val : T(0);
           }
           // kernel.t() (blur_module.cpp:35): Gt[a][e] = G[e][a]
           acc[pr][pc] += blur[e * B + a] * val;
@@ -198,6 +211,68 @@ __device__ __forceinline__ T forward_switch(const T* xs, int addr, const T (&blu
   return r;
 }
 
+// ---- Phase B body: residuals of ONE frame (wave-uniform) for the LR region ----
+// Branch-free per lane (predicates become selects), observation loads
+// software-pipelined one iteration ahead.
+template <typename T, int S, int B, int OXM, bool BORDER, typename ArgsT>
+__device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk,
+                                              const T* __restrict__ yk, int frow, int fcell, int lane,
+                                              int CI0, int CJ0, double& cost_data) {
+  using C = TileCfg<T, S>;
+  constexpr int HB = (B - 1) / 2;
+  const int nlr = A.lrh * A.lrw;
+  const float invw = 1.0f / (float)A.lrw;
+  const int nit = (nlr + 63) >> 6;
+  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
+  // decode of iteration 0 + its observation
+  int idx = lane < nlr ? lane : nlr - 1;
+  int li = (int)(((float)idx + 0.5f) * invw), lj = idx - li * A.lrw;
+  bool valid = (unsigned)(gi0 + li) < (unsigned)A.hl && (unsigned)(gj0 + lj) < (unsigned)A.wl;
+  T ynext = yk[valid ? (size_t)(gi0 + li) * A.wl + (gj0 + lj) : (size_t)0];
+  for (int it = 0; it < nit; ++it) {
+    const int cli = li, clj = lj;
+    const bool cvalid = valid, cact = lane + 64 * it < nlr;
+    const T ycur = ynext;
+    if (it + 1 < nit) {  // uniform: fetch the next observation while this stencil runs
+      const int nidx = lane + 64 * (it + 1);
+      idx = nidx < nlr ? nidx : nlr - 1;
+      li = (int)(((float)idx + 0.5f) * invw);
+      lj = idx - li * A.lrw;
+      valid = (unsigned)(gi0 + li) < (unsigned)A.hl && (unsigned)(gj0 + lj) < (unsigned)A.wl;
+      ynext = yk[valid ? (size_t)(gi0 + li) * A.wl + (gj0 + lj) : (size_t)0];
+    }
+    const int gi = gi0 + cli, gj = gj0 + clj;
+    const int addr = (S * cli + frow) * C::XROW + clj + fcell;
+    unsigned amask = 0xffffffffu, emask = 0xffffffffu;
+    if (BORDER) {
+      amask = 0; emask = 0;
+#pragma unroll
+      for (int a = 0; a < B; ++a) {
+        const int rr = S * gi + a - HB, cc = S * gj + a - HB;
+        amask |= ((unsigned)rr < (unsigned)A.H ? 1u : 0u) << a;
+        emask |= ((unsigned)cc < (unsigned)A.W ? 1u : 0u) << a;
+      }
+    }
+    T res = forward_taps<T, S, B, OXM, BORDER>(xs, addr, A.blur, amask, emask) - ycur;
+    res = cvalid ? res : T(0);
+    // each LR pixel is owned by exactly one tile
+    const bool owned = cact && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gj - CJ0) < (unsigned)C::CW;
+    const double rd = owned ? (double)res : 0.0;
+    cost_data += rd * rd;
+    if (cact) rsk[cli * C::LRW + clj] = res;
+  }
+}
+
+template <typename T, int S, int B, bool BORDER, typename ArgsT>
+__device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk, const T* yk, int frow,
+                                                int fcell, int fxm, int lane, int CI0, int CJ0,
+                                                double& cost_data) {
+  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
+  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
+  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
+  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
+}
+
 // ---- regulariser pass 1 for one cell: values r, c*r products, self term ----
 // cell at tile-relative cell coords (ci, cj) in [-1, CH) x [-1, CW); xcell/xrow
 // locate its first pixel in xs.  Stores 2*c*r (0 for pixels outside the image
@@ -211,6 +286,19 @@ __device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T*
   constexpr int WIN = (REGK == 2) ? R : 1;  // taps extend WIN pixels right/down
   constexpr int NC = S + WIN;               // columns of x needed per row
   T win[WIN + 1][NC];
+  // IRLS weights of the whole cell first: one exposed HBM/L2 latency, not S
+  T wv[S][S];
+#pragma unroll
+  for (int pr = 0; pr < S; ++pr) {
+    const int gr = gr0 + pr;
+    if (wplane != nullptr && gr >= 0 && gr < H && gc0 >= 0 && gc0 < W) {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) wv[pr][pc] = wplane[(size_t)gr * W + gc0 + pc];
+    } else {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) wv[pr][pc] = T(1);
+    }
+  }
   // preload rows 0..WIN-1 of the rolling window
 #pragma unroll
   for (int i = 0; i < WIN; ++i)
@@ -224,14 +312,6 @@ __device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T*
     for (int j = 0; j < NC; ++j)
       win[(pr + WIN) % (WIN + 1)][j] = xs[(xrow0 + pr + WIN) * C::XROW + (j % S) * C::XPLANE + xcell0 + j / S];
     const int gr = gr0 + pr;
-    T wv[S];
-    if (wplane != nullptr && gr >= 0 && gr < H && gc0 >= 0 && gc0 < W) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) wv[pc] = wplane[(size_t)gr * W + gc0 + pc];
-    } else {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) wv[pc] = T(1);
-    }
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
       const T x0 = win[pr % (WIN + 1)][pc];
@@ -247,7 +327,7 @@ __device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T*
             if (BORDER) inside = (gr + i < H) && (gc0 + pc + j < W);
             if (inside) {
               r += pw[i + j] * absv(d);
-              if (i < R && j < R) didi += pw[i + j] * sgnv(d);  // exclusive window in the gradient
+              if (i < R && j < R) didi += sgn_scaled<T>(d, pw[i + j]);  // exclusive window in the gradient
             }
           }
         }
@@ -262,7 +342,7 @@ __device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T*
         if (inx) didi -= sgnv(dxv);
         if (iny) didi -= sgnv(dyv);
       }
-      const T c = lambda * wv[pc];
+      const T c = lambda * wv[pr][pc];
       T cr2 = T(2) * c * r;
       const bool in_img = gr >= 0 && gr < H && gc0 + pc >= 0 && gc0 + pc < W;
       if (OWNED) {
@@ -316,7 +396,7 @@ __device__ __forceinline__ void reg_pass2(T (&acc)[S][S], const T* __restrict__ 
             if (i == 0 && j == 0) continue;
             const T xq = xw[posmod(pr - i, RU + 1)][pc + RU - j];
             const T cq = cw[posmod(pr - i, RU + 1)][pc + RU - j];
-            sum += cq * (-sgnv(xq - x0) * pw[i + j]);
+            sum += cq * sgn_scaled<T>(x0 - xq, pw[i + j]);  // -sgn(x[q]-x[p]) * alpha^(i+j)
           }
         }
       } else {
@@ -326,6 +406,56 @@ __device__ __forceinline__ void reg_pass2(T (&acc)[S][S], const T* __restrict__ 
       }
       acc[pr][pc] += sum;
     }
+  }
+}
+
+// ---- regulariser pass 1 for the up/left halo strips ----
+// pass 2 reads c*r of the RU pixel rows above and RU pixel columns left of the
+// tile; they are recomputed here, one pixel per thread, spread over the whole
+// workgroup (RU*(TW+RU) + RU*TH pixels).
+template <typename T, int S, int REGK, int R, int NP>
+__device__ __forceinline__ void reg_halo(const T* __restrict__ xs, T* __restrict__ cr,
+                                         const T* __restrict__ wplane, int tid, int hu, int hlc, int R0,
+                                         int C0, int W, int H, T lambda, const T (&pw)[NP]) {
+  using C = TileCfg<T, S>;
+  constexpr int RU = (REGK == 2) ? R - 1 : 1;
+  if (RU == 0) return;
+  constexpr int TOPW = C::TW + RU;
+  constexpr int NTOP = RU * TOPW, NH = NTOP + RU * C::TH;
+  for (int h = tid; h < NH; h += kThreads) {
+    int row, col;  // tile-relative pixel coordinates (negative in the halo)
+    if (h < NTOP) { row = h / TOPW - RU; col = h % TOPW - RU; }
+    else { const int h2 = h - NTOP; row = h2 / RU; col = h2 % RU - RU; }
+    const int gr = R0 + row, gc = C0 + col;
+    T cr2 = T(0);
+    if (gr >= 0 && gr < H && gc >= 0 && gc < W && !(REGK == 2 && gr == 0 && gc == 0)) {
+      const int xr = hu + row, xc = col + hlc * S;  // >= 0 by construction of the plan
+      const T x0 = xs[xr * C::XROW + (xc % S) * C::XPLANE + xc / S];
+      T r = T(0);
+      if (REGK == 2) {
+#pragma unroll
+        for (int j = 0; j <= R; ++j) {
+          const int xcj = xc + j;
+          const int cofs = (xcj % S) * C::XPLANE + xcj / S;
+          const bool cin = gc + j < W;
+#pragma unroll
+          for (int i = 0; i <= R; ++i) {
+            if (i == 0 && j == 0) continue;
+            const T v = xs[(xr + i) * C::XROW + cofs];
+            if (cin && gr + i < H) r += pw[i + j] * absv(x0 - v);
+          }
+        }
+      } else {
+        const int xc1 = xc + 1;
+        const T xv = (gc + 1 < W) ? absv(xs[xr * C::XROW + (xc1 % S) * C::XPLANE + xc1 / S] - x0) : T(0);
+        const T yv = (gr + 1 < H) ? absv(xs[(xr + 1) * C::XROW + (xc % S) * C::XPLANE + xc / S] - x0) : T(0);
+        r = yv + xv;
+      }
+      const T wv = wplane ? wplane[(size_t)gr * W + gc] : T(1);
+      cr2 = T(2) * (lambda * wv) * r;
+    }
+    const int crr = row + S, crc = col + S;
+    cr[crr * C::CRROW + (crc % S) * C::CRPLANE + crc / S] = cr2;
   }
 }
 
@@ -342,7 +472,8 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
   T* cr = scratch;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as an SGPR
   const int CI0 = blockIdx.y * C::CH, CJ0 = blockIdx.x * C::CW;
   const int R0 = CI0 * S, C0 = CJ0 * S;
   const int ch = blockIdx.z;
@@ -355,7 +486,7 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
   {
     const int total = A.xrows * A.xcells;
     const float inv = 1.0f / (float)A.xcells;
-    for (int idx = tid; idx < total; idx += kThreads) {
+    for (int idx = tid; idx < ((A.terms & 0x400) ? 0 : total); idx += kThreads) {
       int row = (int)(((float)idx + 0.5f) * inv);
       int cell = idx - row * A.xcells;
       const int gr = R0 - A.hu + row;
@@ -384,62 +515,47 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
   double cost_data = 0.0, cost_reg = 0.0;
 
   if (A.terms & SRMAP_TERM_DATA) {
-    const int nlr = A.lrh * A.lrw;
-    const float invw = 1.0f / (float)A.lrw;
     const size_t nl = (size_t)A.wl * A.hl;
     for (int k0 = 0; k0 < A.K; k0 += kFrameChunk) {
       // ---------------- Phase B: residuals of frame k0 + wave ----------------
-      const int k = k0 + wv;
-      if (k < A.K) {
-        const FrameInfo fi = A.frames[k];
+      const int k = k0 + wv;  // wave-uniform (wv comes from readfirstlane)
+      if (k < A.K && !(A.terms & 0x100)) {
+        // scalar loads: the frame descriptor lives in SGPRs, the phase switch
+        // below is a uniform branch
+        const int frow = A.frames[k].frow, fcell = A.frames[k].fcell, fxm = A.frames[k].fxm;
         const T* yk = A.y + ((size_t)k * A.obs_C + ch + A.obs_c0) * nl;
         T* rsk = rs + wv * (C::LRH * C::LRW);
-        for (int idx = lane; idx < nlr; idx += 64) {
-          const int li = (int)(((float)idx + 0.5f) * invw);
-          const int lj = idx - li * A.lrw;
-          const int gi = CI0 + A.i0 + li, gj = CJ0 + A.j0 + lj;
-          T res = T(0);
-          if (gi >= 0 && gi < A.hl && gj >= 0 && gj < A.wl) {
-            const int addr = (S * li + fi.frow) * C::XROW + lj + fi.fcell;
-            unsigned amask = 0xffffffffu, emask = 0xffffffffu;
-            if (border) {
-              amask = 0; emask = 0;
-#pragma unroll
-              for (int a = 0; a < B; ++a) {
-                const int rr = S * gi + a - HB, cc = S * gj + a - HB;
-                if (rr >= 0 && rr < A.H) amask |= 1u << a;
-                if (cc >= 0 && cc < A.W) emask |= 1u << a;
-              }
-              res = forward_switch<T, S, B, S, true>(xs, addr, A.blur, fi.fxm, amask, emask);
-            } else {
-              res = forward_switch<T, S, B, S, false>(xs, addr, A.blur, fi.fxm, amask, emask);
-            }
-            res -= yk[(size_t)gi * A.wl + gj];
-            // each LR pixel is owned by exactly one tile
-            if (gi >= CI0 && gi < CI0 + C::CH && gj >= CJ0 && gj < CJ0 + C::CW)
-              cost_data += (double)res * (double)res;
-          }
-          rsk[li * C::LRW + lj] = res;
-        }
+        if (border) residual_switch<T, S, B, true>(A, xs, rsk, yk, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
+        else residual_switch<T, S, B, false>(A, xs, rsk, yk, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
       }
       __syncthreads();
       // ---------------- Phase C: gather into this thread's cell ----------------
-      if (A.g != nullptr) {
+      if (A.g != nullptr && !(A.terms & 0x200)) {
         const int kc = (A.K - k0) < kFrameChunk ? (A.K - k0) : kFrameChunk;
-        for (int kk = 0; kk < kc; ++kk) {
-          const FrameInfo fi = A.frames[k0 + kk];
-          const T* rsb = rs + kk * (C::LRH * C::LRW) + lci * C::LRW + lcj + fi.gbase;
-          if (border) {
-            unsigned rmask = 0, cmask = 0;
+        // all scalar loads of the round first: one exposed latency per round
+        int gb[kFrameChunk], gym[kFrameChunk], gxm[kFrameChunk], toy[kFrameChunk], tox[kFrameChunk];
 #pragma unroll
-            for (int q = 0; q < S; ++q) {
-              const int pr_ = R0 + S * lci + q + fi.toy, pc_ = C0 + S * lcj + q + fi.tox;
-              if (pr_ >= 0 && pr_ < A.H) rmask |= 1u << q;
-              if (pc_ >= 0 && pc_ < A.W) cmask |= 1u << q;
+        for (int kk = 0; kk < kFrameChunk; ++kk) {
+          const int kq = (k0 + kk < A.K) ? k0 + kk : A.K - 1;
+          gb[kk] = A.frames[kq].gbase; gym[kk] = A.frames[kq].gym; gxm[kk] = A.frames[kq].gxm;
+          toy[kk] = border ? A.frames[kq].toy : 0; tox[kk] = border ? A.frames[kq].tox : 0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < kFrameChunk; ++kk) {
+          if (kk < kc) {
+            const T* rsb = rs + kk * (C::LRH * C::LRW) + lci * C::LRW + lcj + gb[kk];
+            if (border) {
+              unsigned rmask = 0, cmask = 0;
+#pragma unroll
+              for (int q = 0; q < S; ++q) {
+                const int pr_ = R0 + S * lci + q + toy[kk], pc_ = C0 + S * lcj + q + tox[kk];
+                rmask |= ((unsigned)pr_ < (unsigned)A.H ? 1u : 0u) << q;
+                cmask |= ((unsigned)pc_ < (unsigned)A.W ? 1u : 0u) << q;
+              }
+              gather_switch<T, S, B, true>(acc, rsb, A.blur, gym[kk], gxm[kk], rmask, cmask);
+            } else {
+              gather_switch<T, S, B, false>(acc, rsb, A.blur, gym[kk], gxm[kk], 0xffffffffu, 0xffffffffu);
             }
-            gather_switch<T, S, B, true>(acc, rsb, A.blur, fi.gym, fi.gxm, rmask, cmask);
-          } else {
-            gather_switch<T, S, B, false>(acc, rsb, A.blur, fi.gym, fi.gxm, 0xffffffffu, 0xffffffffu);
           }
         }
       }
@@ -465,15 +581,9 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
         reg_pass1<T, S, REGK, R, NP, false, true>(acc, cost_reg, xs, cr, wplane, xrow0, xcell0, S * (lci + 1),
                                                   lcj + 1, R0 + S * lci, C0 + S * lcj, A.W, A.H, A.lambda, A.powtab);
     }
-    // pass 1 for the halo cells: row -1 (cells -1..CW-1) and column -1 (rows 0..CH-1)
-    if (tid < C::CW + 1 + C::CH) {
-      int hci, hcj;
-      if (tid < C::CW + 1) { hci = -1; hcj = tid - 1; } else { hci = tid - (C::CW + 1); hcj = -1; }
-      double dcost = 0;  // OWNED = false: acc and cost are not touched
-      reg_pass1<T, S, REGK, R, NP, true, false>(acc, dcost, xs, cr, wplane, A.hu + S * hci, A.hlc + hcj,
-                                                S * (hci + 1), hcj + 1, R0 + S * hci, C0 + S * hcj, A.W, A.H,
-                                                A.lambda, A.powtab);
-    }
+    // pass 1 for the halo strips (needed by pass 2 only)
+    if (A.g != nullptr)
+      reg_halo<T, S, REGK, R, NP>(xs, cr, wplane, tid, A.hu, A.hlc, R0, C0, A.W, A.H, A.lambda, A.powtab);
     __syncthreads();
     if (A.g != nullptr)
       reg_pass2<T, S, REGK, R, NP>(acc, xs, cr, A.hu + S * lci, A.hlc + lcj, S * (lci + 1), lcj + 1, A.powtab);
@@ -664,6 +774,7 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
   A.i0 = pl.i0; A.j0 = pl.j0; A.lrh = pl.lrh; A.lrw = pl.lrw;
   A.margin = pl.margin;
   A.terms = (int)terms;
+  if (const char* dbg = getenv("SRMAP_DEBUG_SKIP")) A.terms |= atoi(dbg) << 8;  // ablation aid (profiling only)
   for (int i = 0; i < B * B; ++i) A.blur[i] = (T)p->blur2d[i];
   A.lambda = T(0);
   for (int i = 0; i < NP; ++i) A.powtab[i] = T(1);
