@@ -211,12 +211,34 @@ __device__ __forceinline__ T forward_switch(const T* xs, int addr, const T (&blu
   return r;
 }
 
+// Number of 64-lane sweeps that cover the largest LR residual region.
+template <typename T, int S>
+struct Sweep { static constexpr int MAXIT = (TileCfg<T, S>::LRH * TileCfg<T, S>::LRW + 63) / 64; };
+
+// Issue the observation loads of one frame for the whole LR region (no waits:
+// the values are consumed a full gather phase later).
+template <typename T, int S, typename ArgsT>
+__device__ __forceinline__ void load_observations(const ArgsT& A, const T* __restrict__ yk, int lane, int CI0,
+                                                  int CJ0, T (&yv)[Sweep<T, S>::MAXIT]) {
+  const int nlr = A.lrh * A.lrw;
+  const float invw = 1.0f / (float)A.lrw;
+  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
+#pragma unroll
+  for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
+    const int nidx = lane + 64 * it;
+    const int idx = nidx < nlr ? nidx : nlr - 1;
+    const int li = (int)(((float)idx + 0.5f) * invw), lj = idx - li * A.lrw;
+    const bool valid = (unsigned)(gi0 + li) < (unsigned)A.hl && (unsigned)(gj0 + lj) < (unsigned)A.wl;
+    yv[it] = yk[valid ? (size_t)(gi0 + li) * A.wl + (gj0 + lj) : (size_t)0];  // clamped address, masked later
+  }
+}
+
 // ---- Phase B body: residuals of ONE frame (wave-uniform) for the LR region ----
-// Branch-free per lane (predicates become selects), observation loads
-// software-pipelined one iteration ahead.
+// Branch-free per lane (predicates become selects); observations were loaded
+// a phase earlier.
 template <typename T, int S, int B, int OXM, bool BORDER, typename ArgsT>
 __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk,
-                                              const T* __restrict__ yk, int frow, int fcell, int lane,
+                                              const T (&yv)[Sweep<T, S>::MAXIT], int frow, int fcell, int lane,
                                               int CI0, int CJ0, double& cost_data) {
   using C = TileCfg<T, S>;
   constexpr int HB = (B - 1) / 2;
@@ -224,53 +246,45 @@ __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restric
   const float invw = 1.0f / (float)A.lrw;
   const int nit = (nlr + 63) >> 6;
   const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
-  // decode of iteration 0 + its observation
-  int idx = lane < nlr ? lane : nlr - 1;
-  int li = (int)(((float)idx + 0.5f) * invw), lj = idx - li * A.lrw;
-  bool valid = (unsigned)(gi0 + li) < (unsigned)A.hl && (unsigned)(gj0 + lj) < (unsigned)A.wl;
-  T ynext = yk[valid ? (size_t)(gi0 + li) * A.wl + (gj0 + lj) : (size_t)0];
-  for (int it = 0; it < nit; ++it) {
-    const int cli = li, clj = lj;
-    const bool cvalid = valid, cact = lane + 64 * it < nlr;
-    const T ycur = ynext;
-    if (it + 1 < nit) {  // uniform: fetch the next observation while this stencil runs
-      const int nidx = lane + 64 * (it + 1);
-      idx = nidx < nlr ? nidx : nlr - 1;
-      li = (int)(((float)idx + 0.5f) * invw);
-      lj = idx - li * A.lrw;
-      valid = (unsigned)(gi0 + li) < (unsigned)A.hl && (unsigned)(gj0 + lj) < (unsigned)A.wl;
-      ynext = yk[valid ? (size_t)(gi0 + li) * A.wl + (gj0 + lj) : (size_t)0];
-    }
-    const int gi = gi0 + cli, gj = gj0 + clj;
-    const int addr = (S * cli + frow) * C::XROW + clj + fcell;
-    unsigned amask = 0xffffffffu, emask = 0xffffffffu;
-    if (BORDER) {
-      amask = 0; emask = 0;
 #pragma unroll
-      for (int a = 0; a < B; ++a) {
-        const int rr = S * gi + a - HB, cc = S * gj + a - HB;
-        amask |= ((unsigned)rr < (unsigned)A.H ? 1u : 0u) << a;
-        emask |= ((unsigned)cc < (unsigned)A.W ? 1u : 0u) << a;
+  for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
+    if (it < nit) {  // uniform
+      const int nidx = lane + 64 * it;
+      const bool act = nidx < nlr;
+      const int idx = act ? nidx : nlr - 1;
+      const int li = (int)(((float)idx + 0.5f) * invw), lj = idx - li * A.lrw;
+      const int gi = gi0 + li, gj = gj0 + lj;
+      const bool valid = (unsigned)gi < (unsigned)A.hl && (unsigned)gj < (unsigned)A.wl;
+      const int addr = (S * li + frow) * C::XROW + lj + fcell;
+      unsigned amask = 0xffffffffu, emask = 0xffffffffu;
+      if (BORDER) {
+        amask = 0; emask = 0;
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+          const int rr = S * gi + a - HB, cc = S * gj + a - HB;
+          amask |= ((unsigned)rr < (unsigned)A.H ? 1u : 0u) << a;
+          emask |= ((unsigned)cc < (unsigned)A.W ? 1u : 0u) << a;
+        }
       }
+      T res = forward_taps<T, S, B, OXM, BORDER>(xs, addr, A.blur, amask, emask) - yv[it];
+      res = valid ? res : T(0);
+      // each LR pixel is owned by exactly one tile
+      const bool owned = act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gj - CJ0) < (unsigned)C::CW;
+      const double rd = owned ? (double)res : 0.0;
+      cost_data += rd * rd;
+      if (act) rsk[li * C::LRW + lj] = res;
     }
-    T res = forward_taps<T, S, B, OXM, BORDER>(xs, addr, A.blur, amask, emask) - ycur;
-    res = cvalid ? res : T(0);
-    // each LR pixel is owned by exactly one tile
-    const bool owned = cact && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gj - CJ0) < (unsigned)C::CW;
-    const double rd = owned ? (double)res : 0.0;
-    cost_data += rd * rd;
-    if (cact) rsk[cli * C::LRW + clj] = res;
   }
 }
 
 template <typename T, int S, int B, bool BORDER, typename ArgsT>
-__device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk, const T* yk, int frow,
-                                                int fcell, int fxm, int lane, int CI0, int CJ0,
-                                                double& cost_data) {
-  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
-  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
-  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
-  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, yk, frow, fcell, lane, CI0, CJ0, cost_data);
+__device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk,
+                                                const T (&yv)[Sweep<T, S>::MAXIT], int frow, int fcell, int fxm,
+                                                int lane, int CI0, int CJ0, double& cost_data) {
+  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
+  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
+  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
+  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
 }
 
 // ---- regulariser pass 1 for one cell: values r, c*r products, self term ----
@@ -279,26 +293,13 @@ __device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* 
 // and for the absolute pixel (0,0), btv_regularizer.cpp:143-146) into cr.
 template <typename T, int S, int REGK, int R, int NP, bool BORDER, bool OWNED>
 __device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T* __restrict__ xs,
-                                          T* __restrict__ cr, const T* __restrict__ wplane,
+                                          T* __restrict__ cr, const T (&wv)[S][S],
                                           int xrow0, int xcell0, int crrow0, int crcell0, int gr0, int gc0,
                                           int W, int H, T lambda, const T (&pw)[NP]) {
   using C = TileCfg<T, S>;
   constexpr int WIN = (REGK == 2) ? R : 1;  // taps extend WIN pixels right/down
   constexpr int NC = S + WIN;               // columns of x needed per row
   T win[WIN + 1][NC];
-  // IRLS weights of the whole cell first: one exposed HBM/L2 latency, not S
-  T wv[S][S];
-#pragma unroll
-  for (int pr = 0; pr < S; ++pr) {
-    const int gr = gr0 + pr;
-    if (wplane != nullptr && gr >= 0 && gr < H && gc0 >= 0 && gc0 < W) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) wv[pr][pc] = wplane[(size_t)gr * W + gc0 + pc];
-    } else {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) wv[pr][pc] = T(1);
-    }
-  }
   // preload rows 0..WIN-1 of the rolling window
 #pragma unroll
   for (int i = 0; i < WIN; ++i)
@@ -482,31 +483,64 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
   const bool border = (R0 < A.margin) || (R0 + C::TH + A.margin > A.H) || (C0 < A.margin) ||
                       (C0 + C::TW + A.margin > A.W);
 
+  const int lci = tid / C::CW, lcj = tid - lci * C::CW;  // this thread's cell
+  const size_t nl = (size_t)A.wl * A.hl;
+  constexpr int MAXIT = Sweep<T, S>::MAXIT;
+
+  // ---------------- prefetch: every global load whose address is known now ----------------
+  // HBM/L2 latency (~1 us) is as long as a whole phase of this kernel, so loads
+  // are issued as early as possible and consumed phases later.
+  T yv[MAXIT];  // observations of frame (round 0, this wave)
+  if ((A.terms & SRMAP_TERM_DATA) && wv < A.K)
+    load_observations<T, S>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, lane, CI0, CJ0, yv);
+  T wreg[S][S];  // IRLS weights of this thread's cell
+  if (REGK != 0 && (A.terms & SRMAP_TERM_REG)) {
+    const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
+    const int gc0 = C0 + S * lcj;
+#pragma unroll
+    for (int pr = 0; pr < S; ++pr) {
+      const int gr = R0 + S * lci + pr;
+      const bool in = wplane != nullptr && gr < A.H && gc0 < A.W;
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) wreg[pr][pc] = in ? wplane[(size_t)gr * A.W + gc0 + pc] : T(1);
+    }
+  }
+
   // ---------------- Phase A: x tile (+halo) -> LDS, polyphase ----------------
   {
-    const int total = A.xrows * A.xcells;
+    constexpr int AIT = (C::XR * C::XCELLS + kThreads - 1) / kThreads;
+    const int total = (A.terms & 0x400) ? 0 : A.xrows * A.xcells;
     const float inv = 1.0f / (float)A.xcells;
-    for (int idx = tid; idx < ((A.terms & 0x400) ? 0 : total); idx += kThreads) {
-      int row = (int)(((float)idx + 0.5f) * inv);
-      int cell = idx - row * A.xcells;
+    T vals[AIT][S];
+    // stage 1: all loads in flight
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int idx = tid + it * kThreads;
+      const int row = (int)(((float)idx + 0.5f) * inv);
+      const int cell = idx - row * A.xcells;
       const int gr = R0 - A.hu + row;
       const int gcell = CJ0 - A.hlc + cell;
-      T vals[S];
-      if (gr >= 0 && gr < A.H && gcell >= 0 && gcell < A.wl) {
-        const T* src = xplane + (size_t)gr * A.W + (size_t)gcell * S;
+      const bool in = idx < total && (unsigned)gr < (unsigned)A.H && (unsigned)gcell < (unsigned)A.wl;
+      const T* src = xplane + (in ? (size_t)gr * A.W + (size_t)gcell * S : (size_t)0);
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) vals[pc] = src[pc];
-      } else {
+      for (int pc = 0; pc < S; ++pc) vals[it][pc] = src[pc];
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) vals[pc] = T(0);
+      for (int pc = 0; pc < S; ++pc) vals[it][pc] = in ? vals[it][pc] : T(0);
+    }
+    // stage 2: polyphase scatter into LDS
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int idx = tid + it * kThreads;
+      if (idx < total) {
+        const int row = (int)(((float)idx + 0.5f) * inv);
+        const int cell = idx - row * A.xcells;
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XPLANE + cell] = vals[it][pc];
       }
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XPLANE + cell] = vals[pc];
     }
   }
   __syncthreads();
 
-  const int lci = tid / C::CW, lcj = tid - lci * C::CW;  // this thread's cell
   T acc[S][S];
 #pragma unroll
   for (int i = 0; i < S; ++i)
@@ -515,7 +549,6 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
   double cost_data = 0.0, cost_reg = 0.0;
 
   if (A.terms & SRMAP_TERM_DATA) {
-    const size_t nl = (size_t)A.wl * A.hl;
     for (int k0 = 0; k0 < A.K; k0 += kFrameChunk) {
       // ---------------- Phase B: residuals of frame k0 + wave ----------------
       const int k = k0 + wv;  // wave-uniform (wv comes from readfirstlane)
@@ -523,11 +556,13 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
         // scalar loads: the frame descriptor lives in SGPRs, the phase switch
         // below is a uniform branch
         const int frow = A.frames[k].frow, fcell = A.frames[k].fcell, fxm = A.frames[k].fxm;
-        const T* yk = A.y + ((size_t)k * A.obs_C + ch + A.obs_c0) * nl;
         T* rsk = rs + wv * (C::LRH * C::LRW);
-        if (border) residual_switch<T, S, B, true>(A, xs, rsk, yk, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
-        else residual_switch<T, S, B, false>(A, xs, rsk, yk, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
+        if (border) residual_switch<T, S, B, true>(A, xs, rsk, yv, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
+        else residual_switch<T, S, B, false>(A, xs, rsk, yv, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
       }
+      // observations of the next round: in flight during the gather
+      if (k + kFrameChunk < A.K)
+        load_observations<T, S>(A, A.y + ((size_t)(k + kFrameChunk) * A.obs_C + ch + A.obs_c0) * nl, lane, CI0, CJ0, yv);
       __syncthreads();
       // ---------------- Phase C: gather into this thread's cell ----------------
       if (A.g != nullptr && !(A.terms & 0x200)) {
@@ -571,14 +606,14 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
   // ---------------- Phase D: regulariser ----------------
   if (REGK != 0 && (A.terms & SRMAP_TERM_REG)) {
     const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
-    // pass 1: owned cell
+    // pass 1: owned cell (weights were prefetched at kernel start)
     {
       const int xrow0 = A.hu + S * lci, xcell0 = A.hlc + lcj;
       if (border)
-        reg_pass1<T, S, REGK, R, NP, true, true>(acc, cost_reg, xs, cr, wplane, xrow0, xcell0, S * (lci + 1),
+        reg_pass1<T, S, REGK, R, NP, true, true>(acc, cost_reg, xs, cr, wreg, xrow0, xcell0, S * (lci + 1),
                                                  lcj + 1, R0 + S * lci, C0 + S * lcj, A.W, A.H, A.lambda, A.powtab);
       else
-        reg_pass1<T, S, REGK, R, NP, false, true>(acc, cost_reg, xs, cr, wplane, xrow0, xcell0, S * (lci + 1),
+        reg_pass1<T, S, REGK, R, NP, false, true>(acc, cost_reg, xs, cr, wreg, xrow0, xcell0, S * (lci + 1),
                                                   lcj + 1, R0 + S * lci, C0 + S * lcj, A.W, A.H, A.lambda, A.powtab);
     }
     // pass 1 for the halo strips (needed by pass 2 only)
