@@ -54,6 +54,18 @@ def bilinear_upsample(img, s):
     return torch.nn.functional.interpolate(t, scale_factor=s, mode="bilinear", align_corners=False)[0].numpy()
 
 
+def pmc_traffic(dtype):
+    """HBM bytes per launch of the fused kernel from the committed PMC profile
+    of this same command (bench.py cannot run rocprofv3 on itself)."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)[dtype]
+        return (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, lr, x0, wts, budget_s=20.0):
     """Oracle (CPU restatement of the reference, 1 thread like the reference) on
     a bounded crop of the same workload, scaled by pixel count."""
@@ -128,10 +140,11 @@ def main():
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     E = 8 if args.dtype == "f64" else 4
 
+    import srmap_dist
     frame_ids = list(range(K))
     units_per_step = 1.0
     if world > 1 and args.shard == "frames":
-        frame_ids = [k for k in range(K) if k % world == rank]
+        frame_ids = srmap_dist.frame_shard(K, world, rank)
     shifts = [shifts_all[k] for k in frame_ids]
     Kloc = len(frame_ids)
 
@@ -222,7 +235,10 @@ def main():
                        "frames": K, "scale": s, "channels": C_total, "shard": args.shard if world > 1 else "none",
                        "impl": args.impl, "device_ms_per_step": dev_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.dtype),
+                         "traffic_source": "profiles/r01_bench_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                           "(separate passes) of this command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
+                                           "the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md",
                          "algorithmic_bytes_per_step": b_alg / max(C_total, 1),
                          "kernel": "whole evaluation (all kernels of one step), HIP events on the launch stream"},
         }
