@@ -13,8 +13,8 @@ objective admits:
             (rank 0) before the reduction.
 
 The local evaluator is any callable  local_eval(x, terms) -> (cost, grad)
-working on this rank's shard: srmap.Problem.eval_device on the GPU, the CPU
-oracle in the gloo tests.
+working on this rank's shard: srmap.Problem.eval_device on the GPU (the tests plug
+a CPU evaluator over gloo).
 """
 TERM_DATA, TERM_REG, TERM_ALL = 1, 2, 3
 
