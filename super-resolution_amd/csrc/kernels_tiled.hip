@@ -83,6 +83,8 @@ struct FusedArgs {
   const T* w;       // IRLS weights or nullptr
   T* g;             // nullptr = cost only
   double* partials;
+  unsigned* counter;   // arrival counter for the in-kernel final reduction (nullptr = off)
+  double* cost_out;    // receives the total when counter != nullptr
   const FrameInfo* frames;
   int W, H, wl, hl, K;
   int obs_C, obs_c0;
@@ -215,20 +217,52 @@ __device__ __forceinline__ T forward_switch(const T* xs, int addr, const T (&blu
 template <typename T, int S>
 struct Sweep { static constexpr int MAXIT = (TileCfg<T, S>::LRH * TileCfg<T, S>::LRW + 63) / 64; };
 
-// Issue the observation loads of one frame for the whole LR region (no waits:
-// the values are consumed a full gather phase later).
-template <typename T, int S, typename ArgsT>
-__device__ __forceinline__ void load_observations(const ArgsT& A, const T* __restrict__ yk, int lane, int CI0,
-                                                  int CJ0, T (&yv)[Sweep<T, S>::MAXIT]) {
+// Per-lane description of the LR pixels one lane visits in its 64-lane sweeps
+// over the tile's LR region.  Frame-invariant, so it is decoded once per
+// kernel: bits 0-7 lj, 8-15 li, 16 valid (inside the LR image), 17 owned by
+// this tile, 18 active (inside the region), 19.. warped-domain tap masks
+// (B row bits, then B column bits; only used by border tiles).
+template <typename T, int S, int B, typename ArgsT>
+__device__ __forceinline__ void build_sweep(const ArgsT& A, int lane, int CI0, int CJ0,
+                                            unsigned (&tab)[Sweep<T, S>::MAXIT]) {
+  using C = TileCfg<T, S>;
+  constexpr int HB = (B - 1) / 2;
   const int nlr = A.lrh * A.lrw;
   const float invw = 1.0f / (float)A.lrw;
   const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
 #pragma unroll
   for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
     const int nidx = lane + 64 * it;
-    const int idx = nidx < nlr ? nidx : nlr - 1;
+    const bool act = nidx < nlr;
+    const int idx = act ? nidx : nlr - 1;
     const int li = (int)(((float)idx + 0.5f) * invw), lj = idx - li * A.lrw;
-    const bool valid = (unsigned)(gi0 + li) < (unsigned)A.hl && (unsigned)(gj0 + lj) < (unsigned)A.wl;
+    const int gi = gi0 + li, gj = gj0 + lj;
+    const bool valid = (unsigned)gi < (unsigned)A.hl && (unsigned)gj < (unsigned)A.wl;
+    const bool owned = act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gj - CJ0) < (unsigned)C::CW;
+    unsigned v = (unsigned)lj | ((unsigned)li << 8) | (valid ? 1u << 16 : 0u) | (owned ? 1u << 17 : 0u) |
+                 (act ? 1u << 18 : 0u);
+#pragma unroll
+    for (int a = 0; a < B; ++a) {
+      const int rr = S * gi + a - HB, cc = S * gj + a - HB;
+      v |= ((unsigned)rr < (unsigned)A.H ? 1u : 0u) << (19 + a);
+      v |= ((unsigned)cc < (unsigned)A.W ? 1u : 0u) << (19 + B + a);
+    }
+    tab[it] = v;
+  }
+}
+
+// Issue the observation loads of one frame for the whole LR region (no waits:
+// the values are consumed a full gather phase later).
+template <typename T, int S, typename ArgsT>
+__device__ __forceinline__ void load_observations(const ArgsT& A, const T* __restrict__ yk, int CI0, int CJ0,
+                                                  const unsigned (&tab)[Sweep<T, S>::MAXIT],
+                                                  T (&yv)[Sweep<T, S>::MAXIT]) {
+  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
+#pragma unroll
+  for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
+    const unsigned v = tab[it];
+    const int li = (v >> 8) & 0xff, lj = v & 0xff;
+    const bool valid = (v >> 16) & 1u;
     yv[it] = yk[valid ? (size_t)(gi0 + li) * A.wl + (gj0 + lj) : (size_t)0];  // clamped address, masked later
   }
 }
@@ -238,53 +272,39 @@ __device__ __forceinline__ void load_observations(const ArgsT& A, const T* __res
 // a phase earlier.
 template <typename T, int S, int B, int OXM, bool BORDER, typename ArgsT>
 __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk,
-                                              const T (&yv)[Sweep<T, S>::MAXIT], int frow, int fcell, int lane,
-                                              int CI0, int CJ0, double& cost_data) {
+                                              const unsigned (&tab)[Sweep<T, S>::MAXIT],
+                                              const T (&yv)[Sweep<T, S>::MAXIT], int frow, int fcell,
+                                              double& cost_data) {
   using C = TileCfg<T, S>;
-  constexpr int HB = (B - 1) / 2;
-  const int nlr = A.lrh * A.lrw;
-  const float invw = 1.0f / (float)A.lrw;
-  const int nit = (nlr + 63) >> 6;
-  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
+  const int nit = (A.lrh * A.lrw + 63) >> 6;
+  const int soff = frow * C::XROW + fcell;  // frame-dependent part of the tap address (scalar)
 #pragma unroll
   for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
     if (it < nit) {  // uniform
-      const int nidx = lane + 64 * it;
-      const bool act = nidx < nlr;
-      const int idx = act ? nidx : nlr - 1;
-      const int li = (int)(((float)idx + 0.5f) * invw), lj = idx - li * A.lrw;
-      const int gi = gi0 + li, gj = gj0 + lj;
-      const bool valid = (unsigned)gi < (unsigned)A.hl && (unsigned)gj < (unsigned)A.wl;
-      const int addr = (S * li + frow) * C::XROW + lj + fcell;
-      unsigned amask = 0xffffffffu, emask = 0xffffffffu;
-      if (BORDER) {
-        amask = 0; emask = 0;
-#pragma unroll
-        for (int a = 0; a < B; ++a) {
-          const int rr = S * gi + a - HB, cc = S * gj + a - HB;
-          amask |= ((unsigned)rr < (unsigned)A.H ? 1u : 0u) << a;
-          emask |= ((unsigned)cc < (unsigned)A.W ? 1u : 0u) << a;
-        }
-      }
+      const unsigned v = tab[it];
+      const int li = (v >> 8) & 0xff, lj = v & 0xff;
+      const int addr = li * (S * C::XROW) + lj + soff;
+      const unsigned amask = BORDER ? (v >> 19) : 0xffffffffu;
+      const unsigned emask = BORDER ? (v >> (19 + B)) : 0xffffffffu;
       T res = forward_taps<T, S, B, OXM, BORDER>(xs, addr, A.blur, amask, emask) - yv[it];
-      res = valid ? res : T(0);
+      res = ((v >> 16) & 1u) ? res : T(0);
       // each LR pixel is owned by exactly one tile
-      const bool owned = act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gj - CJ0) < (unsigned)C::CW;
-      const double rd = owned ? (double)res : 0.0;
+      const double rd = ((v >> 17) & 1u) ? (double)res : 0.0;
       cost_data += rd * rd;
-      if (act) rsk[li * C::LRW + lj] = res;
+      if ((v >> 18) & 1u) rsk[li * C::LRW + lj] = res;
     }
   }
 }
 
 template <typename T, int S, int B, bool BORDER, typename ArgsT>
 __device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk,
+                                                const unsigned (&tab)[Sweep<T, S>::MAXIT],
                                                 const T (&yv)[Sweep<T, S>::MAXIT], int frow, int fcell, int fxm,
-                                                int lane, int CI0, int CJ0, double& cost_data) {
-  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
-  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
-  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
-  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, yv, frow, fcell, lane, CI0, CJ0, cost_data);
+                                                double& cost_data) {
+  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
+  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
+  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
+  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
 }
 
 // ---- regulariser pass 1 for one cell: values r, c*r products, self term ----
@@ -490,9 +510,12 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
   // ---------------- prefetch: every global load whose address is known now ----------------
   // HBM/L2 latency (~1 us) is as long as a whole phase of this kernel, so loads
   // are issued as early as possible and consumed phases later.
-  T yv[MAXIT];  // observations of frame (round 0, this wave)
-  if ((A.terms & SRMAP_TERM_DATA) && wv < A.K)
-    load_observations<T, S>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, lane, CI0, CJ0, yv);
+  unsigned sweep[MAXIT];  // this lane's LR pixels in the residual sweeps
+  T yv[MAXIT];            // observations of frame (round 0, this wave)
+  if (A.terms & SRMAP_TERM_DATA) {
+    build_sweep<T, S, B>(A, lane, CI0, CJ0, sweep);
+    if (wv < A.K) load_observations<T, S>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, CI0, CJ0, sweep, yv);
+  }
   T wreg[S][S];  // IRLS weights of this thread's cell
   if (REGK != 0 && (A.terms & SRMAP_TERM_REG)) {
     const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
@@ -557,12 +580,12 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
         // below is a uniform branch
         const int frow = A.frames[k].frow, fcell = A.frames[k].fcell, fxm = A.frames[k].fxm;
         T* rsk = rs + wv * (C::LRH * C::LRW);
-        if (border) residual_switch<T, S, B, true>(A, xs, rsk, yv, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
-        else residual_switch<T, S, B, false>(A, xs, rsk, yv, frow, fcell, fxm, lane, CI0, CJ0, cost_data);
+        if (border) residual_switch<T, S, B, true>(A, xs, rsk, sweep, yv, frow, fcell, fxm, cost_data);
+        else residual_switch<T, S, B, false>(A, xs, rsk, sweep, yv, frow, fcell, fxm, cost_data);
       }
       // observations of the next round: in flight during the gather
       if (k + kFrameChunk < A.K)
-        load_observations<T, S>(A, A.y + ((size_t)(k + kFrameChunk) * A.obs_C + ch + A.obs_c0) * nl, lane, CI0, CJ0, yv);
+        load_observations<T, S>(A, A.y + ((size_t)(k + kFrameChunk) * A.obs_C + ch + A.obs_c0) * nl, CI0, CJ0, sweep, yv);
       __syncthreads();
       // ---------------- Phase C: gather into this thread's cell ----------------
       if (A.g != nullptr && !(A.terms & 0x200)) {
@@ -646,11 +669,39 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
     const double sr = wave_sum_d(cost_reg);
     if (lane == 0) { red[0][wv] = sd; red[1][wv] = sr; }
     __syncthreads();
+    const unsigned nblocks = gridDim.x * gridDim.y * gridDim.z;
     if (tid == 0) {
       const double d = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
       const double r = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
       const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      A.partials[b] = (double)(S * S) * d + r;
+      const double part = (double)(S * S) * d + r;
+      if (A.counter == nullptr) {
+        A.partials[b] = part;
+      } else {
+        // publish write-through (sc1), drain, then take a ticket: the last
+        // arriver sums all partials in index order -> deterministic total
+        // without a second launch (cdna guide, G16 "R1" form)
+        __hip_atomic_store(&A.partials[b], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[0][0] = (ticket == nblocks - 1) ? 1.0 : 0.0;
+      }
+    }
+    if (A.counter != nullptr) {
+      __syncthreads();
+      if (red[0][0] != 0.0) {  // workgroup-uniform: this is the last workgroup
+        __syncthreads();
+        double v = 0.0;
+        for (unsigned i = tid; i < nblocks; i += kThreads)
+          v += __hip_atomic_load(&A.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = wave_sum_d(v);
+        if (lane == 0) red[1][wv] = v;
+        __syncthreads();
+        if (tid == 0) {
+          A.cost_out[0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+          __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+      }
     }
   }
 }
@@ -794,12 +845,15 @@ bool tiled_plan(srmap_problem* p) {
 
 template <typename T, int S, int B, int REGK, int R>
 static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
-                        const T* wts, const PlanCache& pc, double* partials, int* nblocks, hipStream_t st) {
+                        const T* wts, const PlanCache& pc, double* partials, int* nblocks, bool final_reduce,
+                        hipStream_t st) {
   using C = TileCfg<T, S>;
   constexpr int NP = (REGK == 2 ? 2 * R + 1 : 1);
   const HostPlan& pl = pc.plan;
   FusedArgs<T, B, NP> A;
   A.x = x; A.y = (const T*)p->d_obs; A.w = wts; A.g = g; A.partials = partials;
+  A.counter = final_reduce ? (unsigned*)(p->d_cost + 4) : nullptr;  // d_cost[4..] is zero-initialised scratch
+  A.cost_out = p->d_cost;
   A.frames = pc.d_frames;
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h; A.K = geo.K;
   A.obs_C = p->geo.C; A.obs_c0 = obs_c0;
@@ -828,12 +882,12 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
 template <typename T, int S, int B>
 static int dispatch_reg(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                         const T* wts, const PlanCache& pc, int regk, int regr, double* partials, int* nb,
-                        hipStream_t st) {
-  if (regk == 1) return launch_fused<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
-  if (regk == 2 && regr == 1) return launch_fused<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
-  if (regk == 2 && regr == 2) return launch_fused<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
-  if (regk == 2 && regr == 3) return launch_fused<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
-  return launch_fused<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, st);
+                        bool fr, hipStream_t st) {
+  if (regk == 1) return launch_fused<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, fr, st);
+  if (regk == 2 && regr == 1) return launch_fused<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, fr, st);
+  if (regk == 2 && regr == 2) return launch_fused<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, fr, st);
+  if (regk == 2 && regr == 3) return launch_fused<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, fr, st);
+  return launch_fused<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, pc, partials, nb, fr, st);
 }
 
 template <typename T>
@@ -854,15 +908,23 @@ int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   }
   unsigned fused_terms = terms & SRMAP_TERM_DATA;
   if (regk) fused_terms |= SRMAP_TERM_REG;
+  // the fused kernel finishes the cost reduction itself when it is the only
+  // producer of partials
+  bool extra = false;
+  if (want_reg)
+    for (int r = 0; r < p->nreg; ++r)
+      if (!(regk && r == pl.reg_index) && p->reg[r].lambda > 0.0) extra = true;
+  const bool fr = !extra;
   int rc = SRMAP_OK, nb = 0;
-  if (geo.s == 2 && geo.b == 1) rc = dispatch_reg<T, 2, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
-  else if (geo.s == 2 && geo.b == 3) rc = dispatch_reg<T, 2, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
-  else if (geo.s == 3 && geo.b == 1) rc = dispatch_reg<T, 3, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
-  else if (geo.s == 3 && geo.b == 3) rc = dispatch_reg<T, 3, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
-  else if (geo.s == 4 && geo.b == 1) rc = dispatch_reg<T, 4, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
-  else if (geo.s == 4 && geo.b == 3) rc = dispatch_reg<T, 4, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, st);
+  if (geo.s == 2 && geo.b == 1) rc = dispatch_reg<T, 2, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
+  else if (geo.s == 2 && geo.b == 3) rc = dispatch_reg<T, 2, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
+  else if (geo.s == 3 && geo.b == 1) rc = dispatch_reg<T, 3, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
+  else if (geo.s == 3 && geo.b == 3) rc = dispatch_reg<T, 3, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
+  else if (geo.s == 4 && geo.b == 1) rc = dispatch_reg<T, 4, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
+  else if (geo.s == 4 && geo.b == 3) rc = dispatch_reg<T, 4, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
   else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no fused kernel for scale %d blur %d", geo.s, geo.b);
   if (rc) return rc;
+  if (fr) { *nblocks = 0; return SRMAP_OK; }  // total already in d_cost[0]
   int total = nb;
   // remaining regularisers (TV3D, a second regulariser, BTV range > 3): direct kernels
   if (want_reg) {
