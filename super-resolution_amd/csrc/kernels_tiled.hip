@@ -5,32 +5,36 @@
 // BTV with range <= 3); anything else is evaluated by kernels_direct.hip.
 //
 // Design (DESIGN.md "Fused evaluation kernel"):
-//   * A workgroup (256 threads, 4 waves) owns a tile of CH x CW LR cells = one
-//     S x S block of HR pixels per thread ("cell-major"): every thread reads x /
-//     IRLS weights and writes g as S-element vectors -> fully coalesced HBM
-//     traffic, each compulsory byte crosses HBM once (x halo re-reads hit L2).
+//   * Row-major ownership: a workgroup of TH waves (TH = 16 HR rows, 15 for
+//     S = 3) owns a tile of TH x (64*S) HR pixels; wave w owns HR row w, lane l
+//     owns the S pixels of LR cell column l in that row.  x / IRLS weights are
+//     read and g is written as one S-element vector per thread (a wave touches
+//     one contiguous 64*S-element row segment): every compulsory byte crosses
+//     HBM once, x halo re-reads hit L2.  Per-thread state is small (S
+//     accumulators), so many waves per SIMD stay resident and hide the ~1 us
+//     HBM / ~100 cycle LDS latencies that dominate this kernel.
 //   * The x tile (+halo) is staged in LDS in POLYPHASE layout
 //     xs[row][column phase (c mod S)][cell]: the decimated forward stencil
-//     (stride-S access) and the per-pixel regulariser windows both become
-//     unit-stride across lanes -> no LDS bank conflicts, all tap offsets are
-//     instruction immediates.
-//   * Per chunk of 4 frames: wave w computes the LR residuals r_k = A_k x - y_k
-//     of frame k0+w for the LR pixels the tile needs (warp -> blur -> decimate
-//     fused, objective_data_term.cpp:27-50) into LDS; then every thread gathers
-//     sum_k M_k^T B^T D^T r_k for its cell (image_model.cpp:93-101).  The
-//     frame's shift phase (shift mod S) selects one of S*S fully unrolled code
-//     paths by a wave-uniform switch, so tap positions and register targets
-//     are compile-time and each valid tap costs one FMA.
+//     (stride-S access) and the per-pixel regulariser windows are unit-stride
+//     across lanes -> no LDS bank conflicts, every tap offset an immediate.
+//   * Per round of FR frames: the waves sweep the LR region the tile needs and
+//     compute the residuals r_k = A_k x - y_k (warp -> blur -> decimate fused,
+//     objective_data_term.cpp:27-50) into LDS; then every thread gathers
+//     sum_k M_k^T B^T D^T r_k for its S pixels (image_model.cpp:93-101).  The
+//     frame's shift phase (shift mod S, combined with the row phase) selects
+//     one of S*S fully unrolled code paths by a wave-uniform switch: tap
+//     positions and register targets are compile-time, a valid tap is one FMA.
 //   * The regulariser (tv_regularizer.cpp:135-227 / btv_regularizer.cpp:93-170,
-//     bug-compatible) runs on the same x tile: pass 1 computes r and c*r for the
-//     tile plus an up/left halo into LDS and the self term, pass 2 adds the
-//     neighbour terms.
-//   * Cost partials (s^2 * sum r_k^2 and lambda * w * r^2) are reduced per
-//     workgroup in fp64 with wave shuffles and written to a partials buffer that
-//     the final one-block reduction sums in a fixed order (deterministic).
+//     bug-compatible) runs on the same x tile: pass 1 computes r, the self term
+//     and 2*lambda*w*r for the tile plus an up/left halo strip into LDS, pass 2
+//     adds the neighbour terms.
+//   * Cost: fp64 wave-shuffle + workgroup reduction -> partials; the last
+//     workgroup to arrive (agent-scope ticket) sums them in index order, so the
+//     total is deterministic without a second launch.
 // No MFMA: this is a stencil/gather path.
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 
 #include "srmap_internal.hpp"
@@ -39,30 +43,33 @@ namespace srmap {
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kFrameChunk = 4;   // frames per residual/gather round = waves per workgroup
-constexpr int kMaxHaloRows = 12; // max hu + hd of the x tile
-constexpr int kMaxHaloCells = 4; // max hlc + hrc
+constexpr int kMaxHaloRows = 12;  // max hu + hd of the x tile
+constexpr int kMaxHaloCells = 4;  // max hlc + hrc
+constexpr int kTabFrames = 32;         // frames whose gather weights are staged in LDS
+constexpr unsigned kSubCounters = 32;  // first-level arrival counters of the in-kernel cost reduction
+
+constexpr int cmax_(int a, int b) { return a > b ? a : b; }
 
 template <typename T, int S>
 struct TileCfg {
-  static constexpr int CW = 32;                       // LR cells per tile row
-  static constexpr int CH = kThreads / CW;            // 8 cell rows
-  static constexpr int TH = CH * S, TW = CW * S;      // HR tile
-  static constexpr int XR = TH + kMaxHaloRows;        // x rows held in LDS
-  static constexpr int XCELLS = CW + kMaxHaloCells;   // cells per x row
-  static constexpr int XPLANE = XCELLS;               // elements per (row, phase)
-  static constexpr int XROW = S * XPLANE;             // elements per row
-  static constexpr int LRH = CH + 3, LRW = CW + 3;    // LR residual region (max)
-  static constexpr int CRCELLS = CW + 1;              // c*r: one halo cell column
-  static constexpr int CRPLANE = CRCELLS;
+  static constexpr int CW = 64;                        // LR cells per tile row = lanes
+  static constexpr int TH = (S == 3) ? 9 : 8;          // HR rows per tile = waves
+  static constexpr int NW = TH;
+  static constexpr int NT = 64 * NW;                   // threads per workgroup
+  static constexpr int CH = TH / S;                    // LR cell rows per tile
+  static constexpr int TW = CW * S;
+  static constexpr int XR = TH + kMaxHaloRows;         // x rows held in LDS
+  static constexpr int XCELLS = CW + kMaxHaloCells;    // cells per x row
+  static constexpr int XPLANE = XCELLS;                // elements per (row, phase)
+  static constexpr int XROW = S * XPLANE;              // elements per row
+  static constexpr int LRH = CH + 3, LRW = CW + 3;     // LR residual region (max)
+  static constexpr int FR = NW;                        // frames per round (one frame per wave)
+  static constexpr int MAXJ = LRH + 1;                 // sweeps per wave: one per LR row (lanes = first 64
+                                                       // LR columns) + one tail sweep for columns 64..LRW-1
+  static constexpr int CRPLANE = CW + 1;               // 2*lambda*w*r: one halo cell column
   static constexpr int CRROW = S * CRPLANE;
-  static constexpr int CRR = TH + S;                  // one halo cell row
   static constexpr int XS_ELEMS = XR * XROW;
-  static constexpr int RS_ELEMS = kFrameChunk * LRH * LRW;
-  static constexpr int CR_ELEMS = CRR * CRROW;
-  // rs (residuals) is dead once the gather is done; c*r reuses its space.
-  static constexpr int SCRATCH_ELEMS = RS_ELEMS > CR_ELEMS ? RS_ELEMS : CR_ELEMS;
+  static constexpr int RS_ELEMS = FR * LRH * LRW;
 };
 
 // Per-frame shift decomposition, precomputed on the host.
@@ -86,6 +93,9 @@ struct FusedArgs {
   unsigned* counter;   // arrival counter for the in-kernel final reduction (nullptr = off)
   double* cost_out;    // receives the total when counter != nullptr
   const FrameInfo* frames;
+  const int* gb;        // [K][S]   rs offset of the first LR tap of (frame, row phase)
+  const T* wr;          // [K][S][2] 1-D blur weights of the (up to two) LR rows a pixel row receives from
+  const T* wc;          // [K][S][2] the same per pixel column phase
   int W, H, wl, hl, K;
   int obs_C, obs_c0;
   int hu, hlc;          // x tile origin = (R0 - hu, cell CJ0 - hlc)
@@ -93,7 +103,7 @@ struct FusedArgs {
   int i0, j0;           // LR region origin relative to the tile's first cell (<= 0)
   int lrh, lrw;         // LR region extent
   int margin;           // tiles closer than this to the image edge take the border path
-  int terms;            // SRMAP_TERM_*
+  int terms;            // SRMAP_TERM_* (| ablation bits << 8, profiling only)
   T blur[B * B];        // k * k^T (blur_module.cpp:20-22)
   T lambda;
   T powtab[NP];         // BTV alpha^(i+j)
@@ -126,8 +136,6 @@ template <>
 __device__ __forceinline__ double absv<double>(double d) { return __builtin_fabs(d); }
 
 // ---- forward residual of ONE LR pixel for a frame whose ox mod S == OXM ----
-// addr = element offset of xs[(S*li + 0 - hb + ...)][.][lj + ...] already
-// including the frame's scalar offsets; taps use immediates.
 template <typename T, int S, int B, int OXM, bool BORDER>
 __device__ __forceinline__ T forward_taps(const T* __restrict__ xs, int addr,
                                           const T (&blur)[B * B], unsigned amask, unsigned emask) {
@@ -152,288 +160,193 @@ __device__ __forceinline__ T forward_taps(const T* __restrict__ xs, int addr,
   return acc;
 }
 
-// ---- gather of one frame into the S x S accumulators of one cell ----
-// rsb points at rs[(lci + toyq - i0)][(lcj + toxq - j0)] of the frame.
-template <typename T, int S, int B, int GYM, int GXM, bool BORDER>
-__device__ __forceinline__ void gather_case(T (&acc)[S][S], const T* __restrict__ rsb,
-                                            const T (&blur)[B * B], unsigned rmask, unsigned cmask) {
-  using C = TileCfg<T, S>;
-  constexpr int HB = (B - 1) / 2;
-#pragma unroll
-  for (int pr = 0; pr < S; ++pr) {
-#pragma unroll
-    for (int a = 0; a < B; ++a) {
-      if (posmod(pr + GYM + a - HB, S) != 0) continue;  // zero-insertion: only multiples of S carry data
-      const int dy = floordiv(pr + GYM + a - HB, S);
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) {
-#pragma unroll
-        for (int e = 0; e < B; ++e) {
-          if (posmod(pc + GXM + e - HB, S) != 0) continue;
-          const int dx = floordiv(pc + GXM + e - HB, S);
-          T val = rsb[dy * C::LRW + dx];  // identical addresses are CSE'd by the compiler
-          if (BORDER) {
-            // warpAffine(-dx,-dy) samples v_k at p' = p + (toy, tox); outside -> 0
-            val = (((rmask >> pr) & (cmask >> pc)) & 1u) ? val : T(0);
-          }
-          // kernel.t() (blur_module.cpp:35): Gt[a][e] = G[e][a]
-          acc[pr][pc] += blur[e * B + a] * val;
-        }
-      }
-    }
-  }
+// Sweeps of the LR region by one wave: sweep j < lrh covers LR row j, lane =
+// LR column (0..63); the tail sweep covers the remaining lrw - 64 (<= 3) columns
+// of every row, lane -> (row, column).  No per-pixel division, row predicates
+// are wave-uniform.
+struct LaneTail {
+  int li, lj;   // LR row / column of this lane in the tail sweep
+  bool act;
+};
+__device__ __forceinline__ LaneTail tail_lane(int lane, int lrh, int lrw) {
+  const int rem = lrw - 64;  // 1..3 (0 when the region is exactly 64 wide)
+  LaneTail t;
+  int li = lane, c = 0;
+  if (rem == 2) { li = lane >> 1; c = lane & 1; }
+  if (rem == 3) { li = (lane * 171) >> 9; c = lane - 3 * li; }
+  t.li = li; t.lj = 64 + c;
+  t.act = rem > 0 && li < lrh;
+  if (!t.act) { t.li = 0; t.lj = 0; }
+  return t;
 }
 
-template <typename T, int S, int B, int GYM, bool BORDER>
-__device__ __forceinline__ void gather_switch_x(T (&acc)[S][S], const T* rsb, const T (&blur)[B * B],
-                                                int gxm, unsigned rmask, unsigned cmask) {
-  if (S >= 1 && gxm == 0) gather_case<T, S, B, GYM, 0, BORDER>(acc, rsb, blur, rmask, cmask);
-  if (S >= 2 && gxm == 1) gather_case<T, S, B, GYM, (S >= 2 ? 1 : 0), BORDER>(acc, rsb, blur, rmask, cmask);
-  if (S >= 3 && gxm == 2) gather_case<T, S, B, GYM, (S >= 3 ? 2 : 0), BORDER>(acc, rsb, blur, rmask, cmask);
-  if (S >= 4 && gxm == 3) gather_case<T, S, B, GYM, (S >= 4 ? 3 : 0), BORDER>(acc, rsb, blur, rmask, cmask);
-}
-
-template <typename T, int S, int B, bool BORDER>
-__device__ __forceinline__ void gather_switch(T (&acc)[S][S], const T* rsb, const T (&blur)[B * B],
-                                              int gym, int gxm, unsigned rmask, unsigned cmask) {
-  if (S >= 1 && gym == 0) gather_switch_x<T, S, B, 0, BORDER>(acc, rsb, blur, gxm, rmask, cmask);
-  if (S >= 2 && gym == 1) gather_switch_x<T, S, B, (S >= 2 ? 1 : 0), BORDER>(acc, rsb, blur, gxm, rmask, cmask);
-  if (S >= 3 && gym == 2) gather_switch_x<T, S, B, (S >= 3 ? 2 : 0), BORDER>(acc, rsb, blur, gxm, rmask, cmask);
-  if (S >= 4 && gym == 3) gather_switch_x<T, S, B, (S >= 4 ? 3 : 0), BORDER>(acc, rsb, blur, gxm, rmask, cmask);
-}
-
-template <typename T, int S, int B, int OXMAX, bool BORDER>
-__device__ __forceinline__ T forward_switch(const T* xs, int addr, const T (&blur)[B * B], int fxm,
-                                            unsigned amask, unsigned emask) {
-  T r = T(0);
-  if (fxm == 0) r = forward_taps<T, S, B, 0, BORDER>(xs, addr, blur, amask, emask);
-  if (S >= 2 && fxm == 1) r = forward_taps<T, S, B, (S >= 2 ? 1 : 0), BORDER>(xs, addr, blur, amask, emask);
-  if (S >= 3 && fxm == 2) r = forward_taps<T, S, B, (S >= 3 ? 2 : 0), BORDER>(xs, addr, blur, amask, emask);
-  if (S >= 4 && fxm == 3) r = forward_taps<T, S, B, (S >= 4 ? 3 : 0), BORDER>(xs, addr, blur, amask, emask);
-  return r;
-}
-
-// Number of 64-lane sweeps that cover the largest LR residual region.
-template <typename T, int S>
-struct Sweep { static constexpr int MAXIT = (TileCfg<T, S>::LRH * TileCfg<T, S>::LRW + 63) / 64; };
-
-// Per-lane description of the LR pixels one lane visits in its 64-lane sweeps
-// over the tile's LR region.  Frame-invariant, so it is decoded once per
-// kernel: bits 0-7 lj, 8-15 li, 16 valid (inside the LR image), 17 owned by
-// this tile, 18 active (inside the region), 19.. warped-domain tap masks
-// (B row bits, then B column bits; only used by border tiles).
-template <typename T, int S, int B, typename ArgsT>
-__device__ __forceinline__ void build_sweep(const ArgsT& A, int lane, int CI0, int CJ0,
-                                            unsigned (&tab)[Sweep<T, S>::MAXIT]) {
-  using C = TileCfg<T, S>;
-  constexpr int HB = (B - 1) / 2;
-  const int nlr = A.lrh * A.lrw;
-  const float invw = 1.0f / (float)A.lrw;
-  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
-#pragma unroll
-  for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
-    const int nidx = lane + 64 * it;
-    const bool act = nidx < nlr;
-    const int idx = act ? nidx : nlr - 1;
-    const int li = (int)(((float)idx + 0.5f) * invw), lj = idx - li * A.lrw;
-    const int gi = gi0 + li, gj = gj0 + lj;
-    const bool valid = (unsigned)gi < (unsigned)A.hl && (unsigned)gj < (unsigned)A.wl;
-    const bool owned = act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gj - CJ0) < (unsigned)C::CW;
-    unsigned v = (unsigned)lj | ((unsigned)li << 8) | (valid ? 1u << 16 : 0u) | (owned ? 1u << 17 : 0u) |
-                 (act ? 1u << 18 : 0u);
-#pragma unroll
-    for (int a = 0; a < B; ++a) {
-      const int rr = S * gi + a - HB, cc = S * gj + a - HB;
-      v |= ((unsigned)rr < (unsigned)A.H ? 1u : 0u) << (19 + a);
-      v |= ((unsigned)cc < (unsigned)A.W ? 1u : 0u) << (19 + B + a);
-    }
-    tab[it] = v;
-  }
-}
-
-// Issue the observation loads of one frame for the whole LR region (no waits:
-// the values are consumed a full gather phase later).
+// Observation loads of one frame for this wave's sweeps (no waits: consumed a
+// gather phase later).  Addresses of pixels outside the LR image are clamped
+// (the residual is masked to 0 later).
 template <typename T, int S, typename ArgsT>
-__device__ __forceinline__ void load_observations(const ArgsT& A, const T* __restrict__ yk, int CI0, int CJ0,
-                                                  const unsigned (&tab)[Sweep<T, S>::MAXIT],
-                                                  T (&yv)[Sweep<T, S>::MAXIT]) {
-  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;
+__device__ __forceinline__ void load_observations(const ArgsT& A, const T* __restrict__ yk, int lane,
+                                                  const LaneTail& tl, int gi0, int gj0,
+                                                  T (&yv)[TileCfg<T, S>::MAXJ]) {
+  using C = TileCfg<T, S>;
+  const bool col_ok = (unsigned)(gj0 + lane) < (unsigned)A.wl;
 #pragma unroll
-  for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
-    const unsigned v = tab[it];
-    const int li = (v >> 8) & 0xff, lj = v & 0xff;
-    const bool valid = (v >> 16) & 1u;
-    yv[it] = yk[valid ? (size_t)(gi0 + li) * A.wl + (gj0 + lj) : (size_t)0];  // clamped address, masked later
+  for (int j = 0; j < C::LRH; ++j) {
+    const bool ok = j < A.lrh && col_ok && (unsigned)(gi0 + j) < (unsigned)A.hl;
+    yv[j] = yk[ok ? (size_t)(gi0 + j) * A.wl + (gj0 + lane) : (size_t)0];
   }
+  const bool okt = tl.act && (unsigned)(gi0 + tl.li) < (unsigned)A.hl && (unsigned)(gj0 + tl.lj) < (unsigned)A.wl;
+  yv[C::LRH] = yk[okt ? (size_t)(gi0 + tl.li) * A.wl + (gj0 + tl.lj) : (size_t)0];
 }
 
-// ---- Phase B body: residuals of ONE frame (wave-uniform) for the LR region ----
-// Branch-free per lane (predicates become selects); observations were loaded
-// a phase earlier.
+// One residual: stencil, minus observation, masks, cost, store.
+template <typename T, int S, int B, int OXM, bool BORDER, typename ArgsT>
+__device__ __forceinline__ void residual_one(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk, T yval,
+                                             int li, int lj, int soff, bool act, bool valid, bool owned,
+                                             unsigned amask, unsigned emask, double& cost_data) {
+  using C = TileCfg<T, S>;
+  const int addr = li * (S * C::XROW) + lj + soff;
+  T res = forward_taps<T, S, B, OXM, BORDER>(xs, addr, A.blur, amask, emask) - yval;
+  res = valid ? res : T(0);
+  const double rd = owned ? (double)res : 0.0;  // each LR pixel is owned by exactly one tile
+  cost_data += rd * rd;
+  if (act) rsk[li * C::LRW + lj] = res;
+}
+
+// ---- Phase B: residuals of ONE frame (this wave) over the tile's LR region ----
 template <typename T, int S, int B, int OXM, bool BORDER, typename ArgsT>
 __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk,
-                                              const unsigned (&tab)[Sweep<T, S>::MAXIT],
-                                              const T (&yv)[Sweep<T, S>::MAXIT], int frow, int fcell,
-                                              double& cost_data) {
+                                              const T (&yv)[TileCfg<T, S>::MAXJ], int lane, const LaneTail& tl,
+                                              int gi0, int gj0, int CI0, int CJ0, int soff, double& cost_data) {
   using C = TileCfg<T, S>;
-  const int nit = (A.lrh * A.lrw + 63) >> 6;
-  const int soff = frow * C::XROW + fcell;  // frame-dependent part of the tap address (scalar)
+  constexpr int HB = (B - 1) / 2;
+  const int gj = gj0 + lane;
+  const bool col_act = lane < A.lrw;  // lrw >= 64 always (CW = 64), kept for clarity
+  const bool col_valid = (unsigned)gj < (unsigned)A.wl;
+  const bool col_owned = (unsigned)(gj - CJ0) < (unsigned)C::CW;
+  unsigned emask = 0xffffffffu;
+  if (BORDER) {
+    emask = 0;
 #pragma unroll
-  for (int it = 0; it < Sweep<T, S>::MAXIT; ++it) {
-    if (it < nit) {  // uniform
-      const unsigned v = tab[it];
-      const int li = (v >> 8) & 0xff, lj = v & 0xff;
-      const int addr = li * (S * C::XROW) + lj + soff;
-      const unsigned amask = BORDER ? (v >> 19) : 0xffffffffu;
-      const unsigned emask = BORDER ? (v >> (19 + B)) : 0xffffffffu;
-      T res = forward_taps<T, S, B, OXM, BORDER>(xs, addr, A.blur, amask, emask) - yv[it];
-      res = ((v >> 16) & 1u) ? res : T(0);
-      // each LR pixel is owned by exactly one tile
-      const double rd = ((v >> 17) & 1u) ? (double)res : 0.0;
-      cost_data += rd * rd;
-      if ((v >> 18) & 1u) rsk[li * C::LRW + lj] = res;
+    for (int e = 0; e < B; ++e) emask |= ((unsigned)(S * gj + e - HB) < (unsigned)A.W ? 1u : 0u) << e;
+  }
+#pragma unroll
+  for (int j = 0; j < C::LRH; ++j) {
+    if (j < A.lrh) {  // uniform
+      const int gi = gi0 + j;
+      const bool row_valid = (unsigned)gi < (unsigned)A.hl;      // uniform
+      const bool row_owned = (unsigned)(gi - CI0) < (unsigned)C::CH;
+      unsigned amask = 0xffffffffu;
+      if (BORDER) {
+        amask = 0;
+#pragma unroll
+        for (int a = 0; a < B; ++a) amask |= ((unsigned)(S * gi + a - HB) < (unsigned)A.H ? 1u : 0u) << a;
+      }
+      residual_one<T, S, B, OXM, BORDER>(A, xs, rsk, yv[j], j, lane, soff, col_act, row_valid && col_valid,
+                                         row_owned && col_owned && col_act, amask, emask, cost_data);
     }
+  }
+  if (A.lrw > 64) {  // uniform: tail columns 64..lrw-1 of every row
+    const int gi = gi0 + tl.li, gjt = gj0 + tl.lj;
+    const bool valid = tl.act && (unsigned)gi < (unsigned)A.hl && (unsigned)gjt < (unsigned)A.wl;
+    const bool owned = tl.act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gjt - CJ0) < (unsigned)C::CW;
+    unsigned amask = 0xffffffffu, em = 0xffffffffu;
+    if (BORDER) {
+      amask = 0; em = 0;
+#pragma unroll
+      for (int a = 0; a < B; ++a) {
+        amask |= ((unsigned)(S * gi + a - HB) < (unsigned)A.H ? 1u : 0u) << a;
+        em |= ((unsigned)(S * gjt + a - HB) < (unsigned)A.W ? 1u : 0u) << a;
+      }
+    }
+    residual_one<T, S, B, OXM, BORDER>(A, xs, rsk, yv[C::LRH], tl.li, tl.lj, soff, tl.act, valid, owned, amask, em,
+                                       cost_data);
   }
 }
 
 template <typename T, int S, int B, bool BORDER, typename ArgsT>
 __device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk,
-                                                const unsigned (&tab)[Sweep<T, S>::MAXIT],
-                                                const T (&yv)[Sweep<T, S>::MAXIT], int frow, int fcell, int fxm,
+                                                const T (&yv)[TileCfg<T, S>::MAXJ], int lane, const LaneTail& tl,
+                                                int gi0, int gj0, int CI0, int CJ0, int soff, int fxm,
                                                 double& cost_data) {
-  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
-  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
-  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
-  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, tab, yv, frow, fcell, cost_data);
+  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
 }
 
-// ---- regulariser pass 1 for one cell: values r, c*r products, self term ----
-// cell at tile-relative cell coords (ci, cj) in [-1, CH) x [-1, CW); xcell/xrow
-// locate its first pixel in xs.  Stores 2*c*r (0 for pixels outside the image
-// and for the absolute pixel (0,0), btv_regularizer.cpp:143-146) into cr.
-template <typename T, int S, int REGK, int R, int NP, bool BORDER, bool OWNED>
-__device__ __forceinline__ void reg_pass1(T (&acc)[S][S], double& cost, const T* __restrict__ xs,
-                                          T* __restrict__ cr, const T (&wv)[S][S],
-                                          int xrow0, int xcell0, int crrow0, int crcell0, int gr0, int gc0,
-                                          int W, int H, T lambda, const T (&pw)[NP]) {
+// ---- Phase C: gather of one frame into the S accumulators of one row thread ----
+// Zero-insertion + blur^T + shift^T in gather form (image_model.cpp:93-101):
+// with B <= S + 1 a pixel row receives from at most two LR rows and a pixel
+// column from at most two LR columns, so the frame's contribution is
+//   acc[pc] += sum_{dy,dx in {0,1}} wr[dy] * wc[pc][dx] * r_k[li + dy][lj + dx]
+// with wave-uniform weights (1-D blur taps, or 0) that the host tabulates per
+// (frame, row phase) and (frame, column phase): no branches, no per-phase code.
+template <typename T, int S, bool BORDER>
+__device__ __forceinline__ void gather_frame(T (&acc)[S], const T* __restrict__ rsb, T wr0, T wr1,
+                                             const T* __restrict__ wc, unsigned cmask) {
+  using C = TileCfg<T, S>;
+  const T v00 = rsb[0], v01 = rsb[1], v10 = rsb[C::LRW], v11 = rsb[C::LRW + 1];
+  const T t0 = wr0 * v00 + wr1 * v10;
+  const T t1 = wr0 * v01 + wr1 * v11;
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) {
+    T c = wc[2 * pc] * t0 + wc[2 * pc + 1] * t1;
+    if (BORDER) c = ((cmask >> pc) & 1u) ? c : T(0);  // p' column outside the image -> 0
+    acc[pc] += c;
+  }
+}
+
+// ---- regulariser pass 1 for the S pixels of one row thread ----
+// Stores 2*lambda*w*r (0 for pixels outside the image and, BTV only, for the
+// absolute pixel (0,0), btv_regularizer.cpp:143-146) into cr.
+template <typename T, int S, int REGK, int R, int NP, bool BORDER>
+__device__ __forceinline__ void reg_pass1(T (&acc)[S], double& cost, const T* __restrict__ xs,
+                                          T* __restrict__ cr, const T (&wv)[S], int xrow, int xcell, int crrow,
+                                          int crcell, int gr, int gc0, int W, int H, T lambda,
+                                          const T (&pw)[NP]) {
   using C = TileCfg<T, S>;
   constexpr int WIN = (REGK == 2) ? R : 1;  // taps extend WIN pixels right/down
-  constexpr int NC = S + WIN;               // columns of x needed per row
+  constexpr int NC = S + WIN;
   T win[WIN + 1][NC];
-  // preload rows 0..WIN-1 of the rolling window
 #pragma unroll
-  for (int i = 0; i < WIN; ++i)
+  for (int i = 0; i <= WIN; ++i)
 #pragma unroll
-    for (int j = 0; j < NC; ++j)
-      win[i][j] = xs[(xrow0 + i) * C::XROW + (j % S) * C::XPLANE + xcell0 + j / S];
+    for (int j = 0; j < NC; ++j) win[i][j] = xs[(xrow + i) * C::XROW + (j % S) * C::XPLANE + xcell + j / S];
 #pragma unroll
-  for (int pr = 0; pr < S; ++pr) {
-    // row (pr + WIN) enters the window at slot (pr + WIN) % (WIN + 1)
+  for (int pc = 0; pc < S; ++pc) {
+    const T x0 = win[0][pc];
+    T r = T(0), didi = T(0);
+    if (REGK == 2) {
 #pragma unroll
-    for (int j = 0; j < NC; ++j)
-      win[(pr + WIN) % (WIN + 1)][j] = xs[(xrow0 + pr + WIN) * C::XROW + (j % S) * C::XPLANE + xcell0 + j / S];
-    const int gr = gr0 + pr;
+      for (int i = 0; i <= R; ++i) {
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      const T x0 = win[pr % (WIN + 1)][pc];
-      T r = T(0), didi = T(0);
-      if (REGK == 2) {
-#pragma unroll
-        for (int i = 0; i <= R; ++i) {
-#pragma unroll
-          for (int j = 0; j <= R; ++j) {
-            if (i == 0 && j == 0) continue;  // |x0 - x0| = 0 and sgn(0) = 0
-            const T d = x0 - win[(pr + i) % (WIN + 1)][pc + j];
-            bool inside = true;
-            if (BORDER) inside = (gr + i < H) && (gc0 + pc + j < W);
-            if (inside) {
-              r += pw[i + j] * absv(d);
-              if (i < R && j < R) didi += sgn_scaled<T>(d, pw[i + j]);  // exclusive window in the gradient
-            }
-          }
+        for (int j = 0; j <= R; ++j) {
+          if (i == 0 && j == 0) continue;  // |x0 - x0| = 0 and sgn(0) = 0
+          T d = x0 - win[i][pc + j];
+          if (BORDER) d = ((gr + i < H) && (gc0 + pc + j < W)) ? d : T(0);  // skipped tap == zero difference
+          r += pw[i + j] * absv(d);
+          if (i < R && j < R) didi += sgn_scaled<T>(d, pw[i + j]);  // exclusive window in the gradient
         }
-      } else {
-        const T dyv = win[(pr + 1) % (WIN + 1)][pc] - x0;
-        const T dxv = win[pr % (WIN + 1)][pc + 1] - x0;
-        bool iny = true, inx = true;
-        if (BORDER) { iny = gr + 1 < H; inx = gc0 + pc + 1 < W; }
-        const T yv = iny ? absv(dyv) : T(0);
-        const T xv = inx ? absv(dxv) : T(0);
-        r = yv + xv;
-        if (inx) didi -= sgnv(dxv);
-        if (iny) didi -= sgnv(dyv);
       }
-      const T c = lambda * wv[pr][pc];
-      T cr2 = T(2) * c * r;
-      const bool in_img = gr >= 0 && gr < H && gc0 + pc >= 0 && gc0 + pc < W;
-      if (OWNED) {
-        acc[pr][pc] += cr2 * didi;
-        if (in_img) cost += (double)c * (double)r * (double)r;
-      }
-      // BTV only: the absolute pixel (0,0) never back-propagates (btv_regularizer.cpp:143-146)
-      if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
-      cr[(crrow0 + pr) * C::CRROW + pc * C::CRPLANE + crcell0] = cr2;
+    } else {
+      T dyv = win[1][pc] - x0;
+      T dxv = win[0][pc + 1] - x0;
+      if (BORDER) { dyv = (gr + 1 < H) ? dyv : T(0); dxv = (gc0 + pc + 1 < W) ? dxv : T(0); }
+      r = absv(dyv) + absv(dxv);
+      didi = -sgnv(dxv) - sgnv(dyv);
     }
+    const T c = lambda * wv[pc];
+    T cr2 = T(2) * c * r;
+    acc[pc] += cr2 * didi;
+    const bool in_img = gr < H && gc0 + pc < W;
+    const double cd = in_img ? (double)c * (double)r * (double)r : 0.0;
+    cost += cd;
+    if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
+    cr[crrow * C::CRROW + pc * C::CRPLANE + crcell] = cr2;
   }
 }
 
-// ---- regulariser pass 2: contributions of up/left neighbours ----
-template <typename T, int S, int REGK, int R, int NP>
-__device__ __forceinline__ void reg_pass2(T (&acc)[S][S], const T* __restrict__ xs,
-                                          const T* __restrict__ cr, int xrow0, int xcell0, int crrow0,
-                                          int crcell0, const T (&pw)[NP]) {
-  using C = TileCfg<T, S>;
-  constexpr int RU = (REGK == 2) ? R - 1 : 1;  // neighbours reach RU pixels up/left
-  if (RU == 0) return;
-  constexpr int NC = S + RU;
-  // windows cover rows (pr - RU .. pr), columns (-RU .. S-1) of the cell
-  T xw[RU + 1][NC], cw[RU + 1][NC];
-#pragma unroll
-  for (int i = 0; i < RU; ++i) {  // rows -RU .. -1 relative to the cell
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      const int col = j - RU, ph = posmod(col, S), dc = floordiv(col, S);
-      xw[posmod(i - RU, RU + 1)][j] = xs[(xrow0 + i - RU) * C::XROW + ph * C::XPLANE + xcell0 + dc];
-      cw[posmod(i - RU, RU + 1)][j] = cr[(crrow0 + i - RU) * C::CRROW + ph * C::CRPLANE + crcell0 + dc];
-    }
-  }
-#pragma unroll
-  for (int pr = 0; pr < S; ++pr) {
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      const int col = j - RU, ph = posmod(col, S), dc = floordiv(col, S);
-      xw[pr % (RU + 1)][j] = xs[(xrow0 + pr) * C::XROW + ph * C::XPLANE + xcell0 + dc];
-      cw[pr % (RU + 1)][j] = cr[(crrow0 + pr) * C::CRROW + ph * C::CRPLANE + crcell0 + dc];
-    }
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      const T x0 = xw[pr % (RU + 1)][pc + RU];
-      T sum = T(0);
-      if (REGK == 2) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-#pragma unroll
-          for (int j = 0; j < R; ++j) {
-            if (i == 0 && j == 0) continue;
-            const T xq = xw[posmod(pr - i, RU + 1)][pc + RU - j];
-            const T cq = cw[posmod(pr - i, RU + 1)][pc + RU - j];
-            sum += cq * sgn_scaled<T>(x0 - xq, pw[i + j]);  // -sgn(x[q]-x[p]) * alpha^(i+j)
-          }
-        }
-      } else {
-        // left and above (tv_regularizer.cpp:172-203)
-        sum += cw[pr % (RU + 1)][pc + RU - 1] * sgnv(x0 - xw[pr % (RU + 1)][pc + RU - 1]);
-        sum += cw[posmod(pr - 1, RU + 1)][pc + RU] * sgnv(x0 - xw[posmod(pr - 1, RU + 1)][pc + RU]);
-      }
-      acc[pr][pc] += sum;
-    }
-  }
-}
-
-// ---- regulariser pass 1 for the up/left halo strips ----
-// pass 2 reads c*r of the RU pixel rows above and RU pixel columns left of the
-// tile; they are recomputed here, one pixel per thread, spread over the whole
-// workgroup (RU*(TW+RU) + RU*TH pixels).
+// ---- regulariser pass 1 for the up/left halo strips (one pixel per thread) ----
 template <typename T, int S, int REGK, int R, int NP>
 __device__ __forceinline__ void reg_halo(const T* __restrict__ xs, T* __restrict__ cr,
                                          const T* __restrict__ wplane, int tid, int hu, int hlc, int R0,
@@ -443,7 +356,7 @@ __device__ __forceinline__ void reg_halo(const T* __restrict__ xs, T* __restrict
   if (RU == 0) return;
   constexpr int TOPW = C::TW + RU;
   constexpr int NTOP = RU * TOPW, NH = NTOP + RU * C::TH;
-  for (int h = tid; h < NH; h += kThreads) {
+  for (int h = tid; h < NH; h += C::NT) {
     int row, col;  // tile-relative pixel coordinates (negative in the halo)
     if (h < NTOP) { row = h / TOPW - RU; col = h % TOPW - RU; }
     else { const int h2 = h - NTOP; row = h2 / RU; col = h2 % RU - RU; }
@@ -475,145 +388,205 @@ __device__ __forceinline__ void reg_halo(const T* __restrict__ xs, T* __restrict
       const T wv = wplane ? wplane[(size_t)gr * W + gc] : T(1);
       cr2 = T(2) * (lambda * wv) * r;
     }
-    const int crr = row + S, crc = col + S;
+    const int crr = row + RU, crc = col + S;
     cr[crr * C::CRROW + (crc % S) * C::CRPLANE + crc / S] = cr2;
   }
 }
 
+// ---- regulariser pass 2: contributions of the up/left neighbours ----
+template <typename T, int S, int REGK, int R, int NP>
+__device__ __forceinline__ void reg_pass2(T (&acc)[S], const T* __restrict__ xs, const T* __restrict__ cr,
+                                          int xrow, int xcell, int crrow, int crcell, const T (&pw)[NP]) {
+  using C = TileCfg<T, S>;
+  constexpr int RU = (REGK == 2) ? R - 1 : 1;  // neighbours reach RU pixels up/left
+  if (RU == 0) return;
+  constexpr int NC = S + RU;
+  T xw[RU + 1][NC], cw[RU + 1][NC];  // rows r-RU..r (index RU = own row), columns -RU..S-1
+#pragma unroll
+  for (int i = 0; i <= RU; ++i) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int col = j - RU, ph = posmod(col, S), dc = floordiv(col, S);
+      xw[i][j] = xs[(xrow + i - RU) * C::XROW + ph * C::XPLANE + xcell + dc];
+      cw[i][j] = cr[(crrow + i - RU) * C::CRROW + ph * C::CRPLANE + crcell + dc];
+    }
+  }
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) {
+    const T x0 = xw[RU][pc + RU];
+    T sum = T(0);
+    if (REGK == 2) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (i == 0 && j == 0) continue;
+          // -sgn(x[q] - x[p]) * alpha^(i+j) * 2 c[q] r[q],  q = p - (i, j)
+          sum += cw[RU - i][pc + RU - j] * sgn_scaled<T>(x0 - xw[RU - i][pc + RU - j], pw[i + j]);
+        }
+      }
+    } else {
+      // left and above (tv_regularizer.cpp:172-203)
+      sum += cw[RU][pc + RU - 1] * sgnv(x0 - xw[RU][pc + RU - 1]);
+      sum += cw[RU - 1][pc + RU] * sgnv(x0 - xw[RU - 1][pc + RU]);
+    }
+    acc[pc] += sum;
+  }
+}
+
 template <typename T, int S, int B, int REGK, int R>
-__global__ __launch_bounds__(kThreads) void k_eval_fused(
+__global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
     FusedArgs<T, B, (REGK == 2 ? 2 * R + 1 : 1)> A) {
   using C = TileCfg<T, S>;
   constexpr int NP = (REGK == 2 ? 2 * R + 1 : 1);
-  constexpr int HB = (B - 1) / 2;
+  constexpr int RU = (REGK == 2) ? R - 1 : (REGK == 1 ? 1 : 0);
+  constexpr int CR_ELEMS = (C::TH + RU) * C::CRROW;
+  constexpr int SCRATCH_ELEMS = cmax_(C::RS_ELEMS, CR_ELEMS);
   __shared__ T xs[C::XS_ELEMS];
-  __shared__ T scratch[C::SCRATCH_ELEMS];
-  __shared__ double red[2][4];
+  __shared__ T scratch[SCRATCH_ELEMS];  // residuals during the data term, then 2*lambda*w*r
+  __shared__ T gtw[kTabFrames * 4 * S];  // per frame: wr[S][2] then wc[S][2]
+  __shared__ int gtb[kTabFrames * S];    // per frame and row phase: rs offset
+  __shared__ double red[2][C::NW];
+  __shared__ int last_flag;
   T* rs = scratch;
   T* cr = scratch;
 
+  if (A.terms & 0x800) return;  // ablation aid
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index as an SGPR
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index = HR row of the tile (SGPR)
   const int CI0 = blockIdx.y * C::CH, CJ0 = blockIdx.x * C::CW;
   const int R0 = CI0 * S, C0 = CJ0 * S;
   const int ch = blockIdx.z;
   const size_t N = (size_t)A.W * A.H;
+  const size_t nl = (size_t)A.wl * A.hl;
   const T* xplane = A.x + (size_t)ch * N;
   const bool border = (R0 < A.margin) || (R0 + C::TH + A.margin > A.H) || (C0 < A.margin) ||
                       (C0 + C::TW + A.margin > A.W);
-
-  const int lci = tid / C::CW, lcj = tid - lci * C::CW;  // this thread's cell
-  const size_t nl = (size_t)A.wl * A.hl;
-  constexpr int MAXIT = Sweep<T, S>::MAXIT;
+  const int pr = wv % S, lci = wv / S;  // row phase and cell row of this wave (uniform)
+  const int gr = R0 + wv;               // global HR row of this thread
+  const int gc0 = C0 + S * lane;        // first global HR column of this thread
+  const bool want_data = (A.terms & SRMAP_TERM_DATA) != 0;
+  const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0;
 
   // ---------------- prefetch: every global load whose address is known now ----------------
   // HBM/L2 latency (~1 us) is as long as a whole phase of this kernel, so loads
   // are issued as early as possible and consumed phases later.
-  unsigned sweep[MAXIT];  // this lane's LR pixels in the residual sweeps
-  T yv[MAXIT];            // observations of frame (round 0, this wave)
-  if (A.terms & SRMAP_TERM_DATA) {
-    build_sweep<T, S, B>(A, lane, CI0, CJ0, sweep);
-    if (wv < A.K) load_observations<T, S>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, CI0, CJ0, sweep, yv);
-  }
-  T wreg[S][S];  // IRLS weights of this thread's cell
-  if (REGK != 0 && (A.terms & SRMAP_TERM_REG)) {
-    const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
-    const int gc0 = C0 + S * lcj;
-#pragma unroll
-    for (int pr = 0; pr < S; ++pr) {
-      const int gr = R0 + S * lci + pr;
-      const bool in = wplane != nullptr && gr < A.H && gc0 < A.W;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) wreg[pr][pc] = in ? wplane[(size_t)gr * A.W + gc0 + pc] : T(1);
+  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;  // LR region origin
+  const LaneTail tl = tail_lane(lane, A.lrh, A.lrw);
+  T yv[C::MAXJ];
+  if (want_data && wv < A.K && !(A.terms & 0x1000))
+    load_observations<T, S>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0, yv);
+  if (want_data && A.g != nullptr) {
+    const int kt = A.K < kTabFrames ? A.K : kTabFrames;
+    for (int t = tid; t < kt * 4 * S; t += C::NT) {
+      const int k = t / (4 * S), i = t - k * 4 * S;
+      gtw[t] = i < 2 * S ? A.wr[k * 2 * S + i] : A.wc[k * 2 * S + i - 2 * S];
     }
+    for (int t = tid; t < kt * S; t += C::NT) gtb[t] = A.gb[t];
+  }
+  T wreg[S];  // IRLS weights of this thread's pixels
+  if (want_reg) {
+    const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
+    const bool in = wplane != nullptr && gr < A.H && gc0 < A.W;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) wreg[pc] = in ? wplane[(size_t)gr * A.W + gc0 + pc] : T(1);
   }
 
   // ---------------- Phase A: x tile (+halo) -> LDS, polyphase ----------------
+  // wave w stages rows w, w + NW, ...; lane = cell (0..63), the few cells beyond
+  // 64 by the first lanes.  All loads are issued before the first LDS write.
   {
-    constexpr int AIT = (C::XR * C::XCELLS + kThreads - 1) / kThreads;
-    const int total = (A.terms & 0x400) ? 0 : A.xrows * A.xcells;
-    const float inv = 1.0f / (float)A.xcells;
-    T vals[AIT][S];
-    // stage 1: all loads in flight
+    constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // row iterations per wave
+    const bool skipA = (A.terms & 0x400) != 0;
+    const int extra = A.xcells - 64;                  // 0..kMaxHaloCells
+    T va[ARI][S], vb[ARI][S];
 #pragma unroll
-    for (int it = 0; it < AIT; ++it) {
-      const int idx = tid + it * kThreads;
-      const int row = (int)(((float)idx + 0.5f) * inv);
-      const int cell = idx - row * A.xcells;
-      const int gr = R0 - A.hu + row;
-      const int gcell = CJ0 - A.hlc + cell;
-      const bool in = idx < total && (unsigned)gr < (unsigned)A.H && (unsigned)gcell < (unsigned)A.wl;
-      const T* src = xplane + (in ? (size_t)gr * A.W + (size_t)gcell * S : (size_t)0);
+    for (int it = 0; it < ARI; ++it) {
+      const int row = wv + it * C::NW;
+      const int grr = R0 - A.hu + row;
+      const bool row_in = !skipA && row < A.xrows && (unsigned)grr < (unsigned)A.H;  // uniform
+      const int gca = CJ0 - A.hlc + lane, gcb = gca + 64;
+      const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
+      const bool inb = row_in && lane < extra && (unsigned)gcb < (unsigned)A.wl;
+      const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
+      const T* sb = xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) vals[it][pc] = src[pc];
+      for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) vals[it][pc] = in ? vals[it][pc] : T(0);
+      for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) { va[it][pc] = ina ? va[it][pc] : T(0); vb[it][pc] = inb ? vb[it][pc] : T(0); }
     }
-    // stage 2: polyphase scatter into LDS
 #pragma unroll
-    for (int it = 0; it < AIT; ++it) {
-      const int idx = tid + it * kThreads;
-      if (idx < total) {
-        const int row = (int)(((float)idx + 0.5f) * inv);
-        const int cell = idx - row * A.xcells;
+    for (int it = 0; it < ARI; ++it) {
+      const int row = wv + it * C::NW;
+      if (row < A.xrows) {  // uniform
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XPLANE + cell] = vals[it][pc];
+        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XPLANE + lane] = va[it][pc];
+        if (lane < extra) {
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XPLANE + 64 + lane] = vb[it][pc];
+        }
       }
     }
   }
   __syncthreads();
 
-  T acc[S][S];
+  if (A.terms & 0x4000) return;  // ablation aid
+  T acc[S];
 #pragma unroll
-  for (int i = 0; i < S; ++i)
-#pragma unroll
-    for (int j = 0; j < S; ++j) acc[i][j] = T(0);
+  for (int j = 0; j < S; ++j) acc[j] = T(0);
   double cost_data = 0.0, cost_reg = 0.0;
 
-  if (A.terms & SRMAP_TERM_DATA) {
-    for (int k0 = 0; k0 < A.K; k0 += kFrameChunk) {
+  if (want_data) {
+    for (int k0 = 0; k0 < A.K; k0 += C::FR) {
       // ---------------- Phase B: residuals of frame k0 + wave ----------------
-      const int k = k0 + wv;  // wave-uniform (wv comes from readfirstlane)
+      const int k = k0 + wv;  // wave-uniform
       if (k < A.K && !(A.terms & 0x100)) {
-        // scalar loads: the frame descriptor lives in SGPRs, the phase switch
-        // below is a uniform branch
-        const int frow = A.frames[k].frow, fcell = A.frames[k].fcell, fxm = A.frames[k].fxm;
+        const int soff = A.frames[k].frow * C::XROW + A.frames[k].fcell;  // scalar loads
+        const int fxm = A.frames[k].fxm;
         T* rsk = rs + wv * (C::LRH * C::LRW);
-        if (border) residual_switch<T, S, B, true>(A, xs, rsk, sweep, yv, frow, fcell, fxm, cost_data);
-        else residual_switch<T, S, B, false>(A, xs, rsk, sweep, yv, frow, fcell, fxm, cost_data);
+        if (border) residual_switch<T, S, B, true>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
+        else residual_switch<T, S, B, false>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
       }
       // observations of the next round: in flight during the gather
-      if (k + kFrameChunk < A.K)
-        load_observations<T, S>(A, A.y + ((size_t)(k + kFrameChunk) * A.obs_C + ch + A.obs_c0) * nl, CI0, CJ0, sweep, yv);
+      if (k + C::FR < A.K)
+        load_observations<T, S>(A, A.y + ((size_t)(k + C::FR) * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0, yv);
       __syncthreads();
-      // ---------------- Phase C: gather into this thread's cell ----------------
+      // ---------------- Phase C: gather into this thread's S pixels ----------------
       if (A.g != nullptr && !(A.terms & 0x200)) {
-        const int kc = (A.K - k0) < kFrameChunk ? (A.K - k0) : kFrameChunk;
-        // all scalar loads of the round first: one exposed latency per round
-        int gb[kFrameChunk], gym[kFrameChunk], gxm[kFrameChunk], toy[kFrameChunk], tox[kFrameChunk];
+        const int kc = (A.K - k0) < C::FR ? (A.K - k0) : C::FR;
+        const T* rs_row = rs + lci * C::LRW + lane;
+#pragma unroll 4
+        for (int kk = 0; kk < kc; ++kk) {
+          const int k = k0 + kk;  // uniform
+          int gbk;
+          T wr0, wr1, wcv[2 * S];
+          if (k < kTabFrames) {
+            // LDS broadcast reads (same address in every lane): no scalar-memory
+            // round trip, and the compiler can hoist them across frames
+            const T* gw = gtw + k * 4 * S;
+            gbk = gtb[k * S + pr];
+            wr0 = gw[2 * pr]; wr1 = gw[2 * pr + 1];
 #pragma unroll
-        for (int kk = 0; kk < kFrameChunk; ++kk) {
-          const int kq = (k0 + kk < A.K) ? k0 + kk : A.K - 1;
-          gb[kk] = A.frames[kq].gbase; gym[kk] = A.frames[kq].gym; gxm[kk] = A.frames[kq].gxm;
-          toy[kk] = border ? A.frames[kq].toy : 0; tox[kk] = border ? A.frames[kq].tox : 0;
-        }
+            for (int i = 0; i < 2 * S; ++i) wcv[i] = gw[2 * S + i];
+          } else {
+            gbk = A.gb[k * S + pr];
+            wr0 = A.wr[(k * S + pr) * 2]; wr1 = A.wr[(k * S + pr) * 2 + 1];
 #pragma unroll
-        for (int kk = 0; kk < kFrameChunk; ++kk) {
-          if (kk < kc) {
-            const T* rsb = rs + kk * (C::LRH * C::LRW) + lci * C::LRW + lcj + gb[kk];
-            if (border) {
-              unsigned rmask = 0, cmask = 0;
+            for (int i = 0; i < 2 * S; ++i) wcv[i] = A.wc[(size_t)k * 2 * S + i];
+          }
+          const T* rsb = rs_row + kk * (C::LRH * C::LRW) + gbk;
+          if (border) {
+            const int toy = A.frames[k].toy, tox = A.frames[k].tox;
+            if ((unsigned)(gr + toy) >= (unsigned)A.H) continue;  // p' row outside the image
+            unsigned cmask = 0;
 #pragma unroll
-              for (int q = 0; q < S; ++q) {
-                const int pr_ = R0 + S * lci + q + toy[kk], pc_ = C0 + S * lcj + q + tox[kk];
-                rmask |= ((unsigned)pr_ < (unsigned)A.H ? 1u : 0u) << q;
-                cmask |= ((unsigned)pc_ < (unsigned)A.W ? 1u : 0u) << q;
-              }
-              gather_switch<T, S, B, true>(acc, rsb, A.blur, gym[kk], gxm[kk], rmask, cmask);
-            } else {
-              gather_switch<T, S, B, false>(acc, rsb, A.blur, gym[kk], gxm[kk], 0xffffffffu, 0xffffffffu);
-            }
+            for (int pc = 0; pc < S; ++pc) cmask |= ((unsigned)(gc0 + pc + tox) < (unsigned)A.W ? 1u : 0u) << pc;
+            gather_frame<T, S, true>(acc, rsb, wr0, wr1, wcv, cmask);
+          } else {
+            gather_frame<T, S, false>(acc, rsb, wr0, wr1, wcv, 0xffffffffu);
           }
         }
       }
@@ -621,48 +594,34 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
     }
     const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
 #pragma unroll
-    for (int i = 0; i < S; ++i)
-#pragma unroll
-      for (int j = 0; j < S; ++j) acc[i][j] *= sc;
+    for (int j = 0; j < S; ++j) acc[j] *= sc;
   }
 
   // ---------------- Phase D: regulariser ----------------
-  if (REGK != 0 && (A.terms & SRMAP_TERM_REG)) {
+  if (want_reg) {
     const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
-    // pass 1: owned cell (weights were prefetched at kernel start)
-    {
-      const int xrow0 = A.hu + S * lci, xcell0 = A.hlc + lcj;
-      if (border)
-        reg_pass1<T, S, REGK, R, NP, true, true>(acc, cost_reg, xs, cr, wreg, xrow0, xcell0, S * (lci + 1),
-                                                 lcj + 1, R0 + S * lci, C0 + S * lcj, A.W, A.H, A.lambda, A.powtab);
-      else
-        reg_pass1<T, S, REGK, R, NP, false, true>(acc, cost_reg, xs, cr, wreg, xrow0, xcell0, S * (lci + 1),
-                                                  lcj + 1, R0 + S * lci, C0 + S * lcj, A.W, A.H, A.lambda, A.powtab);
-    }
-    // pass 1 for the halo strips (needed by pass 2 only)
-    if (A.g != nullptr)
+    const int xrow = A.hu + wv, xcell = A.hlc + lane;
+    if (border)
+      reg_pass1<T, S, REGK, R, NP, true>(acc, cost_reg, xs, cr, wreg, xrow, xcell, wv + RU, lane + 1, gr, gc0, A.W,
+                                         A.H, A.lambda, A.powtab);
+    else
+      reg_pass1<T, S, REGK, R, NP, false>(acc, cost_reg, xs, cr, wreg, xrow, xcell, wv + RU, lane + 1, gr, gc0, A.W,
+                                          A.H, A.lambda, A.powtab);
+    if (A.g != nullptr)  // halo strips are needed by pass 2 only
       reg_halo<T, S, REGK, R, NP>(xs, cr, wplane, tid, A.hu, A.hlc, R0, C0, A.W, A.H, A.lambda, A.powtab);
     __syncthreads();
     if (A.g != nullptr)
-      reg_pass2<T, S, REGK, R, NP>(acc, xs, cr, A.hu + S * lci, A.hlc + lcj, S * (lci + 1), lcj + 1, A.powtab);
+      reg_pass2<T, S, REGK, R, NP>(acc, xs, cr, xrow, xcell, wv + RU, lane + 1, A.powtab);
   }
 
-  // ---------------- write g (S-element rows per thread, coalesced) ----------------
-  if (A.g != nullptr) {
-    const int gcj = CJ0 + lcj;
-    if (gcj < A.wl) {
+  // ---------------- write g: one S-element vector per thread, a wave = one row segment ----------------
+  if (A.g != nullptr && gr < A.H && gc0 < A.W && !(A.terms & 0x2000)) {
+    T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
 #pragma unroll
-      for (int pr = 0; pr < S; ++pr) {
-        const int gr = R0 + S * lci + pr;
-        if (gr < A.H) {
-          T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + (size_t)gcj * S;
-#pragma unroll
-          for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pr][pc];
-        }
-      }
-    }
+    for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pc];
   }
 
+  if (A.terms & 0x8000) return;  // ablation aid
   // ---------------- cost partials ----------------
   {
     const double sd = wave_sum_d(cost_data);
@@ -671,36 +630,49 @@ __global__ __launch_bounds__(kThreads) void k_eval_fused(
     __syncthreads();
     const unsigned nblocks = gridDim.x * gridDim.y * gridDim.z;
     if (tid == 0) {
-      const double d = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-      const double r = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      double d = 0.0, r = 0.0;
+#pragma unroll
+      for (int i = 0; i < C::NW; ++i) { d += red[0][i]; r += red[1][i]; }
       const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       const double part = (double)(S * S) * d + r;
+      int last = 0;
       if (A.counter == nullptr) {
         A.partials[b] = part;
       } else {
         // publish write-through (sc1), drain, then take a ticket: the last
         // arriver sums all partials in index order -> deterministic total
-        // without a second launch (cdna guide, G16 "R1" form)
+        // without a second launch (cdna guide, G16 "R1" form).  One counter
+        // saturates at ~88 atomics/us, so arrivals are spread over kSubCounters
+        // words (256 B apart) with a second-level counter on top.
         __hip_atomic_store(&A.partials[b], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned ticket = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        red[0][0] = (ticket == nblocks - 1) ? 1.0 : 0.0;
-      }
-    }
-    if (A.counter != nullptr) {
-      __syncthreads();
-      if (red[0][0] != 0.0) {  // workgroup-uniform: this is the last workgroup
-        __syncthreads();
-        double v = 0.0;
-        for (unsigned i = tid; i < nblocks; i += kThreads)
-          v += __hip_atomic_load(&A.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = wave_sum_d(v);
-        if (lane == 0) red[1][wv] = v;
-        __syncthreads();
-        if (tid == 0) {
-          A.cost_out[0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-          __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        const unsigned sub = (unsigned)b % kSubCounters;
+        const unsigned expect = (nblocks - sub + kSubCounters - 1) / kSubCounters;  // blocks mapped to this word
+        const unsigned nsub = nblocks < kSubCounters ? nblocks : kSubCounters;
+        const unsigned t1 = __hip_atomic_fetch_add(A.counter + 64 * (1 + sub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t1 == expect - 1) {
+          __hip_atomic_store(A.counter + 64 * (1 + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned t2 = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = (t2 == nsub - 1) ? 1 : 0;
         }
+      }
+      last_flag = last;
+    }
+    __syncthreads();
+    if (last_flag) {  // workgroup-uniform: this is the last workgroup
+      double v = 0.0;
+      for (unsigned i = tid; i < nblocks; i += C::NT)
+        v += __hip_atomic_load(&A.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = wave_sum_d(v);
+      __syncthreads();
+      if (lane == 0) red[0][wv] = v;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < C::NW; ++i) t += red[0][i];
+        A.cost_out[0] = t;
+        __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
       }
     }
   }
@@ -718,11 +690,11 @@ struct HostPlan {
 };
 
 // Decide whether the fused kernel covers the problem and derive the tile halos.
-template <int S>
-static HostPlan make_plan(const srmap_problem* p, int CH, int CW) {
+static HostPlan make_plan(const srmap_problem* p, int S, int CH, int CW) {
   HostPlan pl;
   const Geometry& g = p->geo;
   const int B = g.b, hb = g.hb, K = g.K;
+  const int TH = CH * S;
   if (!p->maps_regular) return pl;
   if (B != 1 && B != 3) return pl;
   // integer shifts only
@@ -732,6 +704,7 @@ static HostPlan make_plan(const srmap_problem* p, int CH, int CW) {
       if (p->fwd_warps[k].ntaps != 1 || p->bwd_warps[k].ntaps != 1) return pl;
       ox[k] = p->fwd_warps[k].ox; oy[k] = p->fwd_warps[k].oy;
       tx[k] = p->bwd_warps[k].ox; ty[k] = p->bwd_warps[k].oy;
+      if (std::abs(tx[k]) > 30000 || std::abs(ty[k]) > 30000) return pl;
     }
   }
   // the one regulariser handled in-kernel (first TV / BTV with lambda > 0)
@@ -750,6 +723,10 @@ static HostPlan make_plan(const srmap_problem* p, int CH, int CW) {
   for (int k = 0; k < K; ++k) {
     dimin = std::min(dimin, -fdiv(-(ty[k] - hb), S));            // ceil((toy-hb)/S)
     dimax = std::max(dimax, fdiv(ty[k] + S - 1 + B - 1 - hb, S));
+    dimax = std::max(dimax, fdiv(ty[k], S) + 1);   // the gather reads the whole 2 x 2 LR patch of a frame
+    djmax = std::max(djmax, fdiv(tx[k], S) + 1);
+    dimin = std::min(dimin, fdiv(ty[k], S));
+    djmin = std::min(djmin, fdiv(tx[k], S));
     djmin = std::min(djmin, -fdiv(-(tx[k] - hb), S));
     djmax = std::max(djmax, fdiv(tx[k] + S - 1 + B - 1 - hb, S));
     amax = std::max(amax, std::max(std::abs(ty[k]), std::abs(tx[k])));
@@ -759,7 +736,7 @@ static HostPlan make_plan(const srmap_problem* p, int CH, int CW) {
   pl.lrh = CH + dimax - dimin; pl.lrw = CW + djmax - djmin;
   if (pl.lrh > CH + 3 || pl.lrw > CW + 3) return pl;
   // x rows/cols the forward model touches for those LR pixels (tile-relative)
-  int rmin = 0, rmax = CH * S - 1, cmin = 0, cmax = CW * S - 1;
+  int rmin = 0, rmax = TH - 1, cmin = 0, cmax = CW * S - 1;
   for (int k = 0; k < K; ++k) {
     rmin = std::min(rmin, S * dimin - hb + oy[k]);
     rmax = std::max(rmax, S * (CH - 1 + dimax) + (B - 1 - hb) + oy[k]);
@@ -768,13 +745,14 @@ static HostPlan make_plan(const srmap_problem* p, int CH, int CW) {
   }
   if (pl.regk) {
     const int win = pl.regk == 2 ? pl.regr : 1;
-    rmin = std::min(rmin, -S);                      // halo cell row / column
-    cmin = std::min(cmin, -S);
-    rmax = std::max(rmax, CH * S - 1 + win);
+    const int ru = pl.regk == 2 ? pl.regr - 1 : 1;
+    rmin = std::min(rmin, -ru);                     // halo strip rows
+    if (ru > 0) cmin = std::min(cmin, -S);          // halo strip columns live in one halo cell
+    rmax = std::max(rmax, TH - 1 + win);
     cmax = std::max(cmax, CW * S - 1 + win);
   }
   pl.hu = -rmin;
-  pl.hd = rmax - (CH * S - 1);
+  pl.hd = rmax - (TH - 1);
   pl.hlc = -fdiv(cmin, S);
   pl.hrc = fdiv(cmax, S) - (CW - 1);
   if (pl.hu + pl.hd > kMaxHaloRows || pl.hlc + pl.hrc > kMaxHaloCells) return pl;
@@ -797,12 +775,15 @@ static HostPlan make_plan(const srmap_problem* p, int CH, int CW) {
 struct PlanCache {
   HostPlan plan;
   FrameInfo* d_frames = nullptr;
+  int* d_gb = nullptr;   // [K][S]
+  void* d_wr = nullptr;  // [K][S][2] dtype
+  void* d_wc = nullptr;  // [K][S][2] dtype
 };
 
 }  // namespace
 
 // The plan is rebuilt whenever the regulariser list changes (cheap, host only)
-// and cached on the problem through an opaque pointer table.
+// and cached per problem.
 static std::vector<std::pair<const srmap_problem*, PlanCache>>& plan_table() {
   static std::vector<std::pair<const srmap_problem*, PlanCache>> t;
   return t;
@@ -818,6 +799,9 @@ void tiled_release(srmap_problem* p) {
   for (size_t i = 0; i < t.size(); ++i)
     if (t[i].first == p) {
       if (t[i].second.d_frames) (void)hipFree(t[i].second.d_frames);
+      if (t[i].second.d_gb) (void)hipFree(t[i].second.d_gb);
+      if (t[i].second.d_wr) (void)hipFree(t[i].second.d_wr);
+      if (t[i].second.d_wc) (void)hipFree(t[i].second.d_wc);
       t.erase(t.begin() + i);
       return;
     }
@@ -827,16 +811,60 @@ bool tiled_plan(srmap_problem* p) {
   tiled_release(p);
   const int S = p->geo.s;
   HostPlan pl;
-  if (S == 2) pl = make_plan<2>(p, TileCfg<float, 2>::CH, TileCfg<float, 2>::CW);
-  else if (S == 3) pl = make_plan<3>(p, TileCfg<float, 3>::CH, TileCfg<float, 3>::CW);
-  else if (S == 4) pl = make_plan<4>(p, TileCfg<float, 4>::CH, TileCfg<float, 4>::CW);
+  if (S == 2) pl = make_plan(p, 2, TileCfg<float, 2>::CH, TileCfg<float, 2>::CW);
+  else if (S == 3) pl = make_plan(p, 3, TileCfg<float, 3>::CH, TileCfg<float, 3>::CW);
+  else if (S == 4) pl = make_plan(p, 4, TileCfg<float, 4>::CH, TileCfg<float, 4>::CW);
   if (!pl.ok) return false;
   PlanCache pc;
   pc.plan = pl;
-  if (hipMalloc((void**)&pc.d_frames, sizeof(FrameInfo) * pl.frames.size()) != hipSuccess) return false;
-  if (hipMemcpy(pc.d_frames, pl.frames.data(), sizeof(FrameInfo) * pl.frames.size(), hipMemcpyHostToDevice) !=
-      hipSuccess) {
-    (void)hipFree(pc.d_frames);
+  // gather tables: for (frame k, row phase pr) the first LR row a pixel row
+  // receives from and the 1-D blur weights of that row and the next one; the
+  // same per column phase.  R = phase + toy_mod + a - hb must be a multiple of S
+  // (zero insertion); its quotient selects LR row 0 or 1 of the 2 x 2 patch.
+  const int K = p->geo.K, B = p->geo.b, hb = p->geo.hb;
+  const int LRW = TileCfg<float, 2>::LRW;  // CW + 3 for every S
+  const std::vector<double>& k1 = p->blur1d;
+  std::vector<int> gb((size_t)K * S);
+  std::vector<double> wr((size_t)K * S * 2, 0.0), wc((size_t)K * S * 2, 0.0);
+  bool patch_ok = true;
+  for (int k = 0; k < K; ++k) {
+    const FrameInfo& f = pl.frames[k];
+    for (int ph = 0; ph < S; ++ph) {
+      for (int a = 0; a < B; ++a) {
+        const int R = ph + f.gym + a - hb;  // row of the zero-inserted image relative to S*(li base)
+        if (pmod(R, S) != 0) continue;
+        const int d = fdiv(R, S);
+        if (d < 0 || d > 1) { patch_ok = false; continue; }
+        wr[((size_t)k * S + ph) * 2 + d] += k1[a];
+      }
+      for (int e = 0; e < B; ++e) {
+        const int Cc = ph + f.gxm + e - hb;
+        if (pmod(Cc, S) != 0) continue;
+        const int d = fdiv(Cc, S);
+        if (d < 0 || d > 1) { patch_ok = false; continue; }
+        wc[((size_t)k * S + ph) * 2 + d] += k1[e];
+      }
+      gb[(size_t)k * S + ph] = f.gbase;
+    }
+  }
+  if (!patch_ok) return false;
+  auto up = [&](const std::vector<double>& v, void** d) {
+    if (p->dtype == SRMAP_F32) {
+      std::vector<float> t(v.begin(), v.end());
+      return hipMalloc(d, t.size() * 4) == hipSuccess && hipMemcpy(*d, t.data(), t.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    return hipMalloc(d, v.size() * 8) == hipSuccess && hipMemcpy(*d, v.data(), v.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool ok = hipMalloc((void**)&pc.d_frames, sizeof(FrameInfo) * pl.frames.size()) == hipSuccess &&
+            hipMemcpy(pc.d_frames, pl.frames.data(), sizeof(FrameInfo) * pl.frames.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void**)&pc.d_gb, sizeof(int) * gb.size()) == hipSuccess &&
+            hipMemcpy(pc.d_gb, gb.data(), sizeof(int) * gb.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            up(wr, &pc.d_wr) && up(wc, &pc.d_wc);
+  if (!ok) {
+    if (pc.d_frames) (void)hipFree(pc.d_frames);
+    if (pc.d_gb) (void)hipFree(pc.d_gb);
+    if (pc.d_wr) (void)hipFree(pc.d_wr);
+    if (pc.d_wc) (void)hipFree(pc.d_wc);
     return false;
   }
   plan_table().push_back({p, pc});
@@ -852,9 +880,10 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
   const HostPlan& pl = pc.plan;
   FusedArgs<T, B, NP> A;
   A.x = x; A.y = (const T*)p->d_obs; A.w = wts; A.g = g; A.partials = partials;
-  A.counter = final_reduce ? (unsigned*)(p->d_cost + 4) : nullptr;  // d_cost[4..] is zero-initialised scratch
+  A.counter = final_reduce ? p->d_counters : nullptr;  // zero-initialised, reset by the last workgroup
   A.cost_out = p->d_cost;
   A.frames = pc.d_frames;
+  A.gb = pc.d_gb; A.wr = (const T*)pc.d_wr; A.wc = (const T*)pc.d_wc;
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h; A.K = geo.K;
   A.obs_C = p->geo.C; A.obs_c0 = obs_c0;
   A.hu = pl.hu; A.hlc = pl.hlc;
@@ -873,7 +902,7 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
     if (REGK == 2) for (int i = 0; i < NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
   }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.h + C::CH - 1) / C::CH, geo.C);
-  hipLaunchKernelGGL((k_eval_fused<T, S, B, REGK, R>), grid, dim3(kThreads), 0, st, A);
+  hipLaunchKernelGGL((k_eval_fused<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A);
   *nblocks = (int)(grid.x * grid.y * grid.z);
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
@@ -901,7 +930,7 @@ int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   int regk = 0, regr = 0;
   const bool want_reg = (terms & SRMAP_TERM_REG) != 0;
   const T* wts = nullptr;
-  if (want_reg && pl.regk != 0 && !(pl.regk == 2 && geo.s == 2 && pl.regr == 3 && false)) {
+  if (want_reg && pl.regk != 0) {
     regk = pl.regk; regr = pl.regr;
     const RegSpec& rs = p->reg[pl.reg_index];
     wts = rs.weights ? (const T*)rs.weights + (size_t)obs_c0 * N : nullptr;
@@ -914,7 +943,7 @@ int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (want_reg)
     for (int r = 0; r < p->nreg; ++r)
       if (!(regk && r == pl.reg_index) && p->reg[r].lambda > 0.0) extra = true;
-  const bool fr = !extra;
+  const bool fr = !extra && !getenv("SRMAP_NO_INKERNEL_REDUCE");
   int rc = SRMAP_OK, nb = 0;
   if (geo.s == 2 && geo.b == 1) rc = dispatch_reg<T, 2, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
   else if (geo.s == 2 && geo.b == 3) rc = dispatch_reg<T, 2, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);

@@ -317,6 +317,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   g.hb = (g.b - 1) / 2;
   // Gaussian kernel: cv::getGaussianKernel (sigma > 0) and k * k^T, blur_module.cpp:20-22
   p->blur2d.assign((size_t)g.b * g.b, 1.0);
+  p->blur1d.assign((size_t)g.b, 1.0);
   if (blur) {
     std::vector<double> k1(g.b);
     const double scale2x = -0.5 / (d->blur_sigma * d->blur_sigma);
@@ -328,6 +329,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
     }
     sum = 1.0 / sum;
     for (int i = 0; i < g.b; ++i) k1[i] *= sum;
+    p->blur1d = k1;
     for (int a = 0; a < g.b; ++a)
       for (int e = 0; e < g.b; ++e) p->blur2d[(size_t)a * g.b + e] = k1[a] * k1[e];
   }
@@ -378,11 +380,13 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   }
   if (hipMalloc((void**)&p->d_col_map, sizeof(int) * g.w) != hipSuccess ||
       hipMalloc((void**)&p->d_row_map, sizeof(int) * g.h) != hipSuccess ||
-      hipMalloc((void**)&p->d_cost, sizeof(double) * 8) != hipSuccess)
+      hipMalloc((void**)&p->d_cost, sizeof(double) * 8) != hipSuccess ||
+      hipMalloc((void**)&p->d_counters, sizeof(unsigned) * 64 * 34) != hipSuccess)
     return fail(set_error(ctx, SRMAP_ENOMEM, "hipMalloc failed"));
   (void)hipMemcpy(p->d_col_map, cmap.data(), sizeof(int) * g.w, hipMemcpyHostToDevice);
   (void)hipMemcpy(p->d_row_map, rmap.data(), sizeof(int) * g.h, hipMemcpyHostToDevice);
   (void)hipMemset(p->d_cost, 0, sizeof(double) * 8);
+  (void)hipMemset(p->d_counters, 0, sizeof(unsigned) * 64 * 34);
   p->plan.usable = tiled_plan(p);
   *out = p;
   return SRMAP_OK;
@@ -392,7 +396,7 @@ void srmap_problem_destroy(srmap_problem* p) {
   if (!p) return;
   tiled_release(p);
   void* bufs[] = {p->d_fwd_warps, p->d_bwd_warps, p->d_blur, p->d_blur_t, p->d_col_map, p->d_row_map,
-                  p->d_obs, p->d_resid, p->d_regvals, p->d_x, p->d_g, p->d_tmp, p->d_partials, p->d_cost};
+                  p->d_obs, p->d_resid, p->d_regvals, p->d_x, p->d_g, p->d_tmp, p->d_partials, p->d_cost, p->d_counters};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) (void)hipFree(p->reg[r].weights);
   delete p;

@@ -68,6 +68,7 @@ struct srmap_problem {
   std::vector<double> shifts;     // K x 2
   std::vector<double> blur2d;     // b*b (double); transposed copy in blur2d_t
   std::vector<double> blur2d_t;
+  std::vector<double> blur1d;     // b (the separable factor: blur2d = blur1d * blur1d^T)
   // device constants
   void* d_fwd_warps = nullptr;    // WarpTaps<T>[K]
   void* d_bwd_warps = nullptr;    // WarpTaps<T>[K]
@@ -88,6 +89,7 @@ struct srmap_problem {
   double* d_partials = nullptr;   // per-block cost partials
   size_t partials_cap = 0;
   double* d_cost = nullptr;       // [4] reduced scalars
+  unsigned* d_counters = nullptr; // arrival counters of the fused kernel's in-kernel reduction (33 x 256 B)
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
   srmap::TilePlan plan;
