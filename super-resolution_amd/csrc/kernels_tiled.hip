@@ -92,6 +92,7 @@ struct FusedArgs {
   double* partials;
   unsigned* counter;   // arrival counter for the in-kernel final reduction (nullptr = off)
   double* cost_out;    // receives the total when counter != nullptr
+  unsigned long long* dbg;  // phase timeline (profiling aid, nullptr normally)
   const FrameInfo* frames;
   const int* gb;        // [K][S]   rs offset of the first LR tap of (frame, row phase)
   const T* wr;          // [K][S][2] 1-D blur weights of the (up to two) LR rows a pixel row receives from
@@ -180,32 +181,37 @@ __device__ __forceinline__ LaneTail tail_lane(int lane, int lrh, int lrw) {
   return t;
 }
 
-// Observation loads of one frame for this wave's sweeps (no waits: consumed a
-// gather phase later).  Addresses of pixels outside the LR image are clamped
-// (the residual is masked to 0 later).
-template <typename T, int S, typename ArgsT>
-__device__ __forceinline__ void load_observations(const ArgsT& A, const T* __restrict__ yk, int lane,
-                                                  const LaneTail& tl, int gi0, int gj0,
-                                                  T (&yv)[TileCfg<T, S>::MAXJ]) {
-  using C = TileCfg<T, S>;
-  const bool col_ok = (unsigned)(gj0 + lane) < (unsigned)A.wl;
-#pragma unroll
-  for (int j = 0; j < C::LRH; ++j) {
-    const bool ok = j < A.lrh && col_ok && (unsigned)(gi0 + j) < (unsigned)A.hl;
-    yv[j] = yk[ok ? (size_t)(gi0 + j) * A.wl + (gj0 + lane) : (size_t)0];
-  }
-  const bool okt = tl.act && (unsigned)(gi0 + tl.li) < (unsigned)A.hl && (unsigned)(gj0 + tl.lj) < (unsigned)A.wl;
-  yv[C::LRH] = yk[okt ? (size_t)(gi0 + tl.li) * A.wl + (gj0 + tl.lj) : (size_t)0];
+// Observation of LR pixel (gi, gj) of one frame; addresses outside the LR image
+// are clamped (the residual is masked to 0 later).
+template <typename T, typename ArgsT>
+__device__ __forceinline__ T load_obs(const ArgsT& A, const T* __restrict__ yk, int gi, int gj) {
+  const bool ok = (unsigned)gi < (unsigned)A.hl && (unsigned)gj < (unsigned)A.wl;
+  return yk[ok ? (size_t)gi * A.wl + gj : (size_t)0];
+}
+
+// Observations a wave needs first for its frame: LR rows 0 and 1 of the region
+// and the tail sweep.  Issued a phase ahead of their use.
+template <typename T>
+struct ObsPrefetch { T y0, y1, yt; };
+
+template <typename T, typename ArgsT>
+__device__ __forceinline__ ObsPrefetch<T> prefetch_obs(const ArgsT& A, const T* __restrict__ yk, int lane,
+                                                       const LaneTail& tl, int gi0, int gj0) {
+  ObsPrefetch<T> o;
+  o.y0 = load_obs<T>(A, yk, gi0, gj0 + lane);
+  o.y1 = load_obs<T>(A, yk, gi0 + 1, gj0 + lane);
+  o.yt = load_obs<T>(A, yk, gi0 + tl.li, gj0 + tl.lj);
+  return o;
 }
 
 // One residual: stencil, minus observation, masks, cost, store.
-template <typename T, int S, int B, int OXM, bool BORDER, typename ArgsT>
+template <typename T, int S, int B, int OXM, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void residual_one(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk, T yval,
                                              int li, int lj, int soff, bool act, bool valid, bool owned,
                                              unsigned amask, unsigned emask, double& cost_data) {
   using C = TileCfg<T, S>;
   const int addr = li * (S * C::XROW) + lj + soff;
-  T res = forward_taps<T, S, B, OXM, BORDER>(xs, addr, A.blur, amask, emask) - yval;
+  T res = forward_taps<T, S, B, OXM, EDGE>(xs, addr, A.blur, amask, emask) - yval;
   res = valid ? res : T(0);
   const double rd = owned ? (double)res : 0.0;  // each LR pixel is owned by exactly one tile
   cost_data += rd * rd;
@@ -213,44 +219,52 @@ __device__ __forceinline__ void residual_one(const ArgsT& A, const T* __restrict
 }
 
 // ---- Phase B: residuals of ONE frame (this wave) over the tile's LR region ----
-template <typename T, int S, int B, int OXM, bool BORDER, typename ArgsT>
+// One sweep per LR row (lane = LR column 0..63, row predicates wave-uniform)
+// plus a tail sweep for columns 64..lrw-1.  The row loop is NOT unrolled (code
+// size: the kernel must stay inside the instruction cache); the observation of
+// row j+2 is loaded while row j is evaluated.  EDGE: the region contains LR row
+// 0 or LR column 0, the only pixels whose blur taps reach outside the warped
+// image (filter2D BORDER_CONSTANT), so only those tiles carry tap masks.
+template <typename T, int S, int B, int OXM, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk,
-                                              const T (&yv)[TileCfg<T, S>::MAXJ], int lane, const LaneTail& tl,
-                                              int gi0, int gj0, int CI0, int CJ0, int soff, double& cost_data) {
+                                              const T* __restrict__ yk, const ObsPrefetch<T>& op, int lane,
+                                              const LaneTail& tl, int gi0, int gj0, int CI0, int CJ0, int soff,
+                                              double& cost_data) {
   using C = TileCfg<T, S>;
   constexpr int HB = (B - 1) / 2;
   const int gj = gj0 + lane;
-  const bool col_act = lane < A.lrw;  // lrw >= 64 always (CW = 64), kept for clarity
   const bool col_valid = (unsigned)gj < (unsigned)A.wl;
   const bool col_owned = (unsigned)(gj - CJ0) < (unsigned)C::CW;
   unsigned emask = 0xffffffffu;
-  if (BORDER) {
+  if (EDGE) {
     emask = 0;
 #pragma unroll
     for (int e = 0; e < B; ++e) emask |= ((unsigned)(S * gj + e - HB) < (unsigned)A.W ? 1u : 0u) << e;
   }
+  T y0 = op.y0, y1 = op.y1;
+#pragma unroll 1
+  for (int j = 0; j < A.lrh; ++j) {
+    const T ycur = y0;
+    y0 = y1;
+    if (j + 2 < A.lrh) y1 = load_obs<T>(A, yk, gi0 + j + 2, gj);  // uniform branch
+    const int gi = gi0 + j;
+    const bool row_valid = (unsigned)gi < (unsigned)A.hl;      // uniform
+    const bool row_owned = (unsigned)(gi - CI0) < (unsigned)C::CH;
+    unsigned amask = 0xffffffffu;
+    if (EDGE) {
+      amask = 0;
 #pragma unroll
-  for (int j = 0; j < C::LRH; ++j) {
-    if (j < A.lrh) {  // uniform
-      const int gi = gi0 + j;
-      const bool row_valid = (unsigned)gi < (unsigned)A.hl;      // uniform
-      const bool row_owned = (unsigned)(gi - CI0) < (unsigned)C::CH;
-      unsigned amask = 0xffffffffu;
-      if (BORDER) {
-        amask = 0;
-#pragma unroll
-        for (int a = 0; a < B; ++a) amask |= ((unsigned)(S * gi + a - HB) < (unsigned)A.H ? 1u : 0u) << a;
-      }
-      residual_one<T, S, B, OXM, BORDER>(A, xs, rsk, yv[j], j, lane, soff, col_act, row_valid && col_valid,
-                                         row_owned && col_owned && col_act, amask, emask, cost_data);
+      for (int a = 0; a < B; ++a) amask |= ((unsigned)(S * gi + a - HB) < (unsigned)A.H ? 1u : 0u) << a;
     }
+    residual_one<T, S, B, OXM, EDGE>(A, xs, rsk, ycur, j, lane, soff, true, row_valid && col_valid,
+                                     row_owned && col_owned, amask, emask, cost_data);
   }
   if (A.lrw > 64) {  // uniform: tail columns 64..lrw-1 of every row
     const int gi = gi0 + tl.li, gjt = gj0 + tl.lj;
     const bool valid = tl.act && (unsigned)gi < (unsigned)A.hl && (unsigned)gjt < (unsigned)A.wl;
     const bool owned = tl.act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gjt - CJ0) < (unsigned)C::CW;
     unsigned amask = 0xffffffffu, em = 0xffffffffu;
-    if (BORDER) {
+    if (EDGE) {
       amask = 0; em = 0;
 #pragma unroll
       for (int a = 0; a < B; ++a) {
@@ -258,20 +272,19 @@ __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restric
         em |= ((unsigned)(S * gjt + a - HB) < (unsigned)A.W ? 1u : 0u) << a;
       }
     }
-    residual_one<T, S, B, OXM, BORDER>(A, xs, rsk, yv[C::LRH], tl.li, tl.lj, soff, tl.act, valid, owned, amask, em,
-                                       cost_data);
+    residual_one<T, S, B, OXM, EDGE>(A, xs, rsk, op.yt, tl.li, tl.lj, soff, tl.act, valid, owned, amask, em,
+                                     cost_data);
   }
 }
 
-template <typename T, int S, int B, bool BORDER, typename ArgsT>
-__device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk,
-                                                const T (&yv)[TileCfg<T, S>::MAXJ], int lane, const LaneTail& tl,
-                                                int gi0, int gj0, int CI0, int CJ0, int soff, int fxm,
-                                                double& cost_data) {
-  if (fxm == 0) residual_pass<T, S, B, 0, BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
-  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
-  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
-  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), BORDER>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+template <typename T, int S, int B, bool EDGE, typename ArgsT>
+__device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk, const T* yk,
+                                                const ObsPrefetch<T>& op, int lane, const LaneTail& tl, int gi0,
+                                                int gj0, int CI0, int CJ0, int soff, int fxm, double& cost_data) {
+  if (fxm == 0) residual_pass<T, S, B, 0, EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
 }
 
 // ---- Phase C: gather of one frame into the S accumulators of one row thread ----
@@ -346,20 +359,43 @@ __device__ __forceinline__ void reg_pass1(T (&acc)[S], double& cost, const T* __
   }
 }
 
-// ---- regulariser pass 1 for the up/left halo strips (one pixel per thread) ----
+// ---- regulariser pass 1 for the up/left halo strips ----
+// pass 2 reads 2*lambda*w*r of the RU pixel rows above and RU pixel columns left
+// of the tile; they are recomputed here, one pixel per thread.  Task h < NTOP
+// is a pixel of the top strip (rows -RU..-1, columns 0..TW-1: exactly RU * TW
+// = a multiple of 64 tasks), the remaining RU * (TH + RU) tasks are the left
+// strip including the corner.  The pixel's IRLS weight is prefetched at kernel
+// start (halo_pixel + the caller), so no global latency sits in this phase.
+template <typename T, int S, int REGK, int R>
+struct HaloGeom {
+  static constexpr int RU = (REGK == 2) ? R - 1 : (REGK == 1 ? 1 : 0);
+  static constexpr int NTOP = RU * TileCfg<T, S>::TW;
+  static constexpr int NH = NTOP + RU * (TileCfg<T, S>::TH + RU);
+  static constexpr int NIT = NH > 0 ? (NH + TileCfg<T, S>::NT - 1) / TileCfg<T, S>::NT : 1;
+};
+
+template <typename T, int S, int REGK, int R>
+__device__ __forceinline__ void halo_pixel(int h, int& row, int& col) {
+  using G = HaloGeom<T, S, REGK, R>;
+  using C = TileCfg<T, S>;
+  if (h < G::NTOP) { row = h / C::TW - G::RU; col = h % C::TW; }
+  else if (G::RU > 0) { const int h2 = h - G::NTOP; row = h2 / (G::RU > 0 ? G::RU : 1) - G::RU; col = h2 % (G::RU > 0 ? G::RU : 1) - G::RU; }
+  else { row = 0; col = 0; }
+}
+
 template <typename T, int S, int REGK, int R, int NP>
 __device__ __forceinline__ void reg_halo(const T* __restrict__ xs, T* __restrict__ cr,
-                                         const T* __restrict__ wplane, int tid, int hu, int hlc, int R0,
-                                         int C0, int W, int H, T lambda, const T (&pw)[NP]) {
+                                         const T (&whalo)[HaloGeom<T, S, REGK, R>::NIT], int tid, int hu, int hlc,
+                                         int R0, int C0, int W, int H, T lambda, const T (&pw)[NP]) {
   using C = TileCfg<T, S>;
-  constexpr int RU = (REGK == 2) ? R - 1 : 1;
-  if (RU == 0) return;
-  constexpr int TOPW = C::TW + RU;
-  constexpr int NTOP = RU * TOPW, NH = NTOP + RU * C::TH;
-  for (int h = tid; h < NH; h += C::NT) {
+  using G = HaloGeom<T, S, REGK, R>;
+  if (G::RU == 0) return;
+#pragma unroll
+  for (int it = 0; it < G::NIT; ++it) {
+    const int h = tid + it * C::NT;
+    if (h >= G::NH) break;
     int row, col;  // tile-relative pixel coordinates (negative in the halo)
-    if (h < NTOP) { row = h / TOPW - RU; col = h % TOPW - RU; }
-    else { const int h2 = h - NTOP; row = h2 / RU; col = h2 % RU - RU; }
+    halo_pixel<T, S, REGK, R>(h, row, col);
     const int gr = R0 + row, gc = C0 + col;
     T cr2 = T(0);
     if (gr >= 0 && gr < H && gc >= 0 && gc < W && !(REGK == 2 && gr == 0 && gc == 0)) {
@@ -376,7 +412,8 @@ __device__ __forceinline__ void reg_halo(const T* __restrict__ xs, T* __restrict
           for (int i = 0; i <= R; ++i) {
             if (i == 0 && j == 0) continue;
             const T v = xs[(xr + i) * C::XROW + cofs];
-            if (cin && gr + i < H) r += pw[i + j] * absv(x0 - v);
+            const T d = (cin && gr + i < H) ? x0 - v : T(0);
+            r += pw[i + j] * absv(d);
           }
         }
       } else {
@@ -385,10 +422,9 @@ __device__ __forceinline__ void reg_halo(const T* __restrict__ xs, T* __restrict
         const T yv = (gr + 1 < H) ? absv(xs[(xr + 1) * C::XROW + (xc % S) * C::XPLANE + xc / S] - x0) : T(0);
         r = yv + xv;
       }
-      const T wv = wplane ? wplane[(size_t)gr * W + gc] : T(1);
-      cr2 = T(2) * (lambda * wv) * r;
+      cr2 = T(2) * (lambda * whalo[it]) * r;
     }
-    const int crr = row + RU, crc = col + S;
+    const int crr = row + G::RU, crc = col + S;
     cr[crr * C::CRROW + (crc % S) * C::CRPLANE + crc / S] = cr2;
   }
 }
@@ -434,8 +470,15 @@ __device__ __forceinline__ void reg_pass2(T (&acc)[S], const T* __restrict__ xs,
   }
 }
 
+#define SRMAP_STAMP(i)                                                                     \
+  do {                                                                                     \
+    if (A.dbg != nullptr && threadIdx.x == STAMP_TID)                                      \
+      A.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = \
+          __builtin_amdgcn_s_memtime();                                                    \
+  } while (0)
+
 template <typename T, int S, int B, int REGK, int R>
-__global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
+__global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_fused(
     FusedArgs<T, B, (REGK == 2 ? 2 * R + 1 : 1)> A) {
   using C = TileCfg<T, S>;
   constexpr int NP = (REGK == 2 ? 2 * R + 1 : 1);
@@ -447,10 +490,11 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
   __shared__ T gtw[kTabFrames * 4 * S];  // per frame: wr[S][2] then wc[S][2]
   __shared__ int gtb[kTabFrames * S];    // per frame and row phase: rs offset
   __shared__ double red[2][C::NW];
-  __shared__ int last_flag;
   T* rs = scratch;
   T* cr = scratch;
 
+  constexpr int STAMP_TID = 64 * (TileCfg<T, S>::NW - 1);  // last wave, lane 0
+  SRMAP_STAMP(0);
   if (A.terms & 0x800) return;  // ablation aid
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -472,35 +516,13 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
   // ---------------- prefetch: every global load whose address is known now ----------------
   // HBM/L2 latency (~1 us) is as long as a whole phase of this kernel, so loads
   // are issued as early as possible and consumed phases later.
-  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;  // LR region origin
-  const LaneTail tl = tail_lane(lane, A.lrh, A.lrw);
-  T yv[C::MAXJ];
-  if (want_data && wv < A.K && !(A.terms & 0x1000))
-    load_observations<T, S>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0, yv);
-  if (want_data && A.g != nullptr) {
-    const int kt = A.K < kTabFrames ? A.K : kTabFrames;
-    for (int t = tid; t < kt * 4 * S; t += C::NT) {
-      const int k = t / (4 * S), i = t - k * 4 * S;
-      gtw[t] = i < 2 * S ? A.wr[k * 2 * S + i] : A.wc[k * 2 * S + i - 2 * S];
-    }
-    for (int t = tid; t < kt * S; t += C::NT) gtb[t] = A.gb[t];
-  }
-  T wreg[S];  // IRLS weights of this thread's pixels
-  if (want_reg) {
-    const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
-    const bool in = wplane != nullptr && gr < A.H && gc0 < A.W;
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) wreg[pc] = in ? wplane[(size_t)gr * A.W + gc0 + pc] : T(1);
-  }
-
   // ---------------- Phase A: x tile (+halo) -> LDS, polyphase ----------------
   // wave w stages rows w, w + NW, ...; lane = cell (0..63), the few cells beyond
   // 64 by the first lanes.  All loads are issued before the first LDS write.
-  {
-    constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // row iterations per wave
-    const bool skipA = (A.terms & 0x400) != 0;
-    const int extra = A.xcells - 64;                  // 0..kMaxHaloCells
-    T va[ARI][S], vb[ARI][S];
+  constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // row iterations per wave
+  const bool skipA = (A.terms & 0x400) != 0;
+  const int extra = A.xcells - 64;                  // 0..kMaxHaloCells
+  T va[ARI][S], vb[ARI][S];
 #pragma unroll
     for (int it = 0; it < ARI; ++it) {
       const int row = wv + it * C::NW;
@@ -518,6 +540,52 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) { va[it][pc] = ina ? va[it][pc] : T(0); vb[it][pc] = inb ? vb[it][pc] : T(0); }
     }
+
+  // ---- the other prefetches go out behind the x tile (loads return in order) ----
+  const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;  // LR region origin
+  const LaneTail tl = tail_lane(lane, A.lrh, A.lrw);
+  ObsPrefetch<T> op = {T(0), T(0), T(0)};
+  if (want_data && wv < A.K && !(A.terms & 0x1000))
+    op = prefetch_obs<T>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0);
+  // only tiles whose LR region contains LR row 0 or column 0 need blur-tap masks
+  const bool edge_tl = (gi0 <= 0) || (gj0 <= 0);
+  // gather tables: one element per thread into a register now, into LDS after
+  // the x tile (kTabFrames * 4 * S <= NT)
+  static_assert(kTabFrames * 4 * S <= C::NT, "gather table does not fit one element per thread");
+  const int kt = A.K < kTabFrames ? A.K : kTabFrames;
+  const bool tab_on = want_data && A.g != nullptr;
+  T tabw = T(0);
+  int tabb = 0;
+  if (tab_on) {
+    const int tk = tid / (4 * S), ti = tid - tk * 4 * S;
+    const bool okw = tid < kt * 4 * S;
+    tabw = ti < 2 * S ? A.wr[okw ? tk * 2 * S + ti : 0] : A.wc[okw ? tk * 2 * S + ti - 2 * S : 0];
+    tabb = A.gb[tid < kt * S ? tid : 0];
+  }
+  T wreg[S];  // IRLS weights of this thread's pixels
+  using HG = HaloGeom<T, S, REGK, R>;
+  T whalo[HG::NIT];  // ... and of its halo-strip pixel(s)
+  if (want_reg) {
+    const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
+    const bool in = wplane != nullptr && gr < A.H && gc0 < A.W;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) wreg[pc] = in ? wplane[(size_t)gr * A.W + gc0 + pc] : T(1);
+#pragma unroll
+    for (int it = 0; it < HG::NIT; ++it) {
+      int hrow = 0, hcol = 0;
+      const int h = tid + it * C::NT;
+      halo_pixel<T, S, REGK, R>(h < HG::NH ? h : 0, hrow, hcol);
+      const int hgr = R0 + hrow, hgc = C0 + hcol;
+      const bool hin = wplane != nullptr && A.g != nullptr && h < HG::NH && (unsigned)hgr < (unsigned)A.H &&
+                       (unsigned)hgc < (unsigned)A.W;
+      whalo[it] = wplane != nullptr ? wplane[hin ? (size_t)hgr * A.W + hgc : (size_t)0] : T(1);
+      if (!hin && wplane != nullptr) whalo[it] = T(1);
+    }
+  }
+
+  SRMAP_STAMP(1);
+  // stage 2 of Phase A: polyphase scatter into LDS
+  {
 #pragma unroll
     for (int it = 0; it < ARI; ++it) {
       const int row = wv + it * C::NW;
@@ -531,7 +599,13 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
       }
     }
   }
+  if (tab_on) {
+    if (tid < kt * 4 * S) gtw[tid] = tabw;
+    if (tid < kt * S) gtb[tid] = tabb;
+  }
+  SRMAP_STAMP(2);
   __syncthreads();
+  SRMAP_STAMP(3);
 
   if (A.terms & 0x4000) return;  // ablation aid
   T acc[S];
@@ -547,13 +621,16 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
         const int soff = A.frames[k].frow * C::XROW + A.frames[k].fcell;  // scalar loads
         const int fxm = A.frames[k].fxm;
         T* rsk = rs + wv * (C::LRH * C::LRW);
-        if (border) residual_switch<T, S, B, true>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
-        else residual_switch<T, S, B, false>(A, xs, rsk, yv, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
+        const T* yk = A.y + ((size_t)k * A.obs_C + ch + A.obs_c0) * nl;
+        if (edge_tl) residual_switch<T, S, B, true>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
+        else residual_switch<T, S, B, false>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
       }
+      if (k0 == 0) SRMAP_STAMP(4);
       // observations of the next round: in flight during the gather
       if (k + C::FR < A.K)
-        load_observations<T, S>(A, A.y + ((size_t)(k + C::FR) * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0, yv);
+        op = prefetch_obs<T>(A, A.y + ((size_t)(k + C::FR) * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0);
       __syncthreads();
+      if (k0 == 0) SRMAP_STAMP(5);
       // ---------------- Phase C: gather into this thread's S pixels ----------------
       if (A.g != nullptr && !(A.terms & 0x200)) {
         const int kc = (A.K - k0) < C::FR ? (A.K - k0) : C::FR;
@@ -590,8 +667,11 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
           }
         }
       }
+      if (k0 == 0) SRMAP_STAMP(6);
       __syncthreads();
+      if (k0 == 0) SRMAP_STAMP(7);
     }
+    SRMAP_STAMP(8);
     const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
 #pragma unroll
     for (int j = 0; j < S; ++j) acc[j] *= sc;
@@ -607,13 +687,17 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
     else
       reg_pass1<T, S, REGK, R, NP, false>(acc, cost_reg, xs, cr, wreg, xrow, xcell, wv + RU, lane + 1, gr, gc0, A.W,
                                           A.H, A.lambda, A.powtab);
+    SRMAP_STAMP(9);
     if (A.g != nullptr)  // halo strips are needed by pass 2 only
-      reg_halo<T, S, REGK, R, NP>(xs, cr, wplane, tid, A.hu, A.hlc, R0, C0, A.W, A.H, A.lambda, A.powtab);
+      reg_halo<T, S, REGK, R, NP>(xs, cr, whalo, tid, A.hu, A.hlc, R0, C0, A.W, A.H, A.lambda, A.powtab);
+    SRMAP_STAMP(10);
     __syncthreads();
+    SRMAP_STAMP(11);
     if (A.g != nullptr)
       reg_pass2<T, S, REGK, R, NP>(acc, xs, cr, xrow, xcell, wv + RU, lane + 1, A.powtab);
   }
 
+  SRMAP_STAMP(12);
   // ---------------- write g: one S-element vector per thread, a wave = one row segment ----------------
   if (A.g != nullptr && gr < A.H && gc0 < A.W && !(A.terms & 0x2000)) {
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
@@ -621,6 +705,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
     for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pc];
   }
 
+  SRMAP_STAMP(13);
   if (A.terms & 0x8000) return;  // ablation aid
   // ---------------- cost partials ----------------
   {
@@ -628,54 +713,52 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT)) void k_eval_fused(
     const double sr = wave_sum_d(cost_reg);
     if (lane == 0) { red[0][wv] = sd; red[1][wv] = sr; }
     __syncthreads();
-    const unsigned nblocks = gridDim.x * gridDim.y * gridDim.z;
-    if (tid == 0) {
+    // Only wave 0 continues: the other waves retire here, so nothing waits for
+    // the device-scope round trips below.
+    if (wv == 0) {
+      const unsigned nblocks = gridDim.x * gridDim.y * gridDim.z;
       double d = 0.0, r = 0.0;
 #pragma unroll
       for (int i = 0; i < C::NW; ++i) { d += red[0][i]; r += red[1][i]; }
       const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       const double part = (double)(S * S) * d + r;
-      int last = 0;
       if (A.counter == nullptr) {
-        A.partials[b] = part;
+        if (lane == 0) A.partials[b] = part;
       } else {
         // publish write-through (sc1), drain, then take a ticket: the last
         // arriver sums all partials in index order -> deterministic total
         // without a second launch (cdna guide, G16 "R1" form).  One counter
         // saturates at ~88 atomics/us, so arrivals are spread over kSubCounters
         // words (256 B apart) with a second-level counter on top.
-        __hip_atomic_store(&A.partials[b], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned sub = (unsigned)b % kSubCounters;
-        const unsigned expect = (nblocks - sub + kSubCounters - 1) / kSubCounters;  // blocks mapped to this word
-        const unsigned nsub = nblocks < kSubCounters ? nblocks : kSubCounters;
-        const unsigned t1 = __hip_atomic_fetch_add(A.counter + 64 * (1 + sub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t1 == expect - 1) {
-          __hip_atomic_store(A.counter + 64 * (1 + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned t2 = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          last = (t2 == nsub - 1) ? 1 : 0;
+        int last = 0;
+        if (lane == 0) {
+          __hip_atomic_store(&A.partials[b], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned sub = (unsigned)b % kSubCounters;
+          const unsigned expect = (nblocks - sub + kSubCounters - 1) / kSubCounters;  // blocks mapped to this word
+          const unsigned nsub = nblocks < kSubCounters ? nblocks : kSubCounters;
+          const unsigned t1 = __hip_atomic_fetch_add(A.counter + 64 * (1 + sub), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (t1 == expect - 1) {
+            __hip_atomic_store(A.counter + 64 * (1 + sub), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned t2 = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (t2 == nsub - 1) ? 1 : 0;
+          }
         }
-      }
-      last_flag = last;
-    }
-    __syncthreads();
-    if (last_flag) {  // workgroup-uniform: this is the last workgroup
-      double v = 0.0;
-      for (unsigned i = tid; i < nblocks; i += C::NT)
-        v += __hip_atomic_load(&A.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v = wave_sum_d(v);
-      __syncthreads();
-      if (lane == 0) red[0][wv] = v;
-      __syncthreads();
-      if (tid == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < C::NW; ++i) t += red[0][i];
-        A.cost_out[0] = t;
-        __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (last) {  // this wave belongs to the last workgroup: fixed-order sum of all partials
+          double v = 0.0;
+          for (unsigned i = lane; i < nblocks; i += 64)
+            v += __hip_atomic_load(&A.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = wave_sum_d(v);
+          if (lane == 0) {
+            A.cost_out[0] = v;
+            __hip_atomic_store(A.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+          }
+        }
       }
     }
   }
+  SRMAP_STAMP(14);
 }
 
 // integer floor division / modulo on the host
@@ -902,7 +985,32 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
     if (REGK == 2) for (int i = 0; i < NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
   }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.h + C::CH - 1) / C::CH, geo.C);
+  A.dbg = nullptr;
+  static int tl_calls = 0;
+  const bool timeline = getenv("SRMAP_DEBUG_TIMELINE") != nullptr && ++tl_calls == 30;
+  const size_t nb_ = (size_t)grid.x * grid.y * grid.z;
+  if (timeline) { (void)hipMalloc((void**)&A.dbg, nb_ * 16 * 8); (void)hipMemset(A.dbg, 0, nb_ * 16 * 8); }
   hipLaunchKernelGGL((k_eval_fused<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A);
+  if (timeline) {
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h(nb_ * 16);
+    (void)hipMemcpy(h.data(), A.dbg, nb_ * 16 * 8, hipMemcpyDeviceToHost);
+    double sum[16] = {0}; unsigned long long t0 = ~0ull, t1 = 0;
+    size_t nint = 0;
+    for (size_t b = 0; b < nb_; ++b) {
+      const size_t bx = b % grid.x, by = (b / grid.x) % grid.y;
+      if (getenv("SRMAP_TIMELINE_INTERIOR") && (bx == 0 || bx + 1 >= grid.x || by < 3 || by + 3 >= grid.y)) continue;
+      ++nint;
+      for (int i = 1; i < 15; ++i) { unsigned long long prev = 0; for (int j = i - 1; j >= 0; --j) if (h[b * 16 + j]) { prev = h[b * 16 + j]; break; } if (h[b * 16 + i] && prev) sum[i] += (double)(h[b * 16 + i] - prev); }
+      if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
+      for (int i = 0; i < 15; ++i) t1 = std::max(t1, h[b * 16 + i]);
+    }
+    fprintf(stderr, "[timeline] blocks %zu, span %llu ticks (s_memtime, 100 MHz => x10 ns); mean delta per stamp:", nb_, t1 - t0);
+    for (int i = 1; i < 15; ++i) fprintf(stderr, " %d:%.0f", i, sum[i] / (nint ? nint : 1));
+    fprintf(stderr, " (over %zu blocks)", nint);
+    fprintf(stderr, "\n");
+    (void)hipFree(A.dbg);
+  }
   *nblocks = (int)(grid.x * grid.y * grid.z);
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;

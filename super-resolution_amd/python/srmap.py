@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsrmap.so")
+LIB_PATH = os.environ.get("SRMAP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libsrmap.so")
 
 OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
