@@ -69,7 +69,8 @@ struct TileCfg {
   static constexpr int CRPLANE = CW + 1;               // 2*lambda*w*r: one halo cell column
   static constexpr int CRROW = S * CRPLANE;
   static constexpr int XS_ELEMS = XR * XROW;
-  static constexpr int RS_ELEMS = FR * LRH * LRW;
+  static constexpr int GRH = CH + 2, GRW = CW + 2;     // residuals as the gather reads them (frame-aligned)
+  static constexpr int RS_ELEMS = FR * GRH * GRW;
 };
 
 // Per-frame shift decomposition, precomputed on the host.
@@ -77,7 +78,8 @@ struct FrameInfo {
   int frow;   // forward: tile-row offset  S*i0 + oy + hu - hb   (x rows)
   int fcell;  // forward: cell offset      j0 + hlc + floor(ox / S)
   int fxm;    // forward: ox mod S  (0..S-1)
-  int gbase;  // gather: (toyq - i0) * LRW + (toxq - j0)
+  int sy, sx; // gather: residual (li, lj) of the LR region is stored at (li - sy, lj - sx) so that every
+              // frame's 2 x 2 patch of cell (ci, cj) sits at rows ci, ci+1 / columns cj, cj+1
   int gym;    // gather: toy mod S
   int gxm;    // gather: tox mod S
   int toy, tox;  // transpose integer offsets (for the border test)
@@ -207,15 +209,17 @@ __device__ __forceinline__ ObsPrefetch<T> prefetch_obs(const ArgsT& A, const T* 
 // One residual: stencil, minus observation, masks, cost, store.
 template <typename T, int S, int B, int OXM, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void residual_one(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk, T yval,
-                                             int li, int lj, int soff, bool act, bool valid, bool owned,
-                                             unsigned amask, unsigned emask, double& cost_data) {
+                                             int li, int lj, int soff, int sy, int sx, bool act, bool valid,
+                                             bool owned, unsigned amask, unsigned emask, double& cost_data) {
   using C = TileCfg<T, S>;
   const int addr = li * (S * C::XROW) + lj + soff;
   T res = forward_taps<T, S, B, OXM, EDGE>(xs, addr, A.blur, amask, emask) - yval;
   res = valid ? res : T(0);
   const double rd = owned ? (double)res : 0.0;  // each LR pixel is owned by exactly one tile
   cost_data += rd * rd;
-  if (act) rsk[li * C::LRW + lj] = res;
+  // stored frame-aligned (see FrameInfo::sy/sx); pixels the gather never reads are only costed
+  const int ls = li - sy, lt = lj - sx;
+  if (act && (unsigned)ls < (unsigned)C::GRH && (unsigned)lt < (unsigned)C::GRW) rsk[ls * C::GRW + lt] = res;
 }
 
 // ---- Phase B: residuals of ONE frame (this wave) over the tile's LR region ----
@@ -229,7 +233,7 @@ template <typename T, int S, int B, int OXM, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ rsk,
                                               const T* __restrict__ yk, const ObsPrefetch<T>& op, int lane,
                                               const LaneTail& tl, int gi0, int gj0, int CI0, int CJ0, int soff,
-                                              double& cost_data) {
+                                              int sy, int sx, double& cost_data) {
   using C = TileCfg<T, S>;
   constexpr int HB = (B - 1) / 2;
   const int gj = gj0 + lane;
@@ -256,7 +260,7 @@ __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restric
 #pragma unroll
       for (int a = 0; a < B; ++a) amask |= ((unsigned)(S * gi + a - HB) < (unsigned)A.H ? 1u : 0u) << a;
     }
-    residual_one<T, S, B, OXM, EDGE>(A, xs, rsk, ycur, j, lane, soff, true, row_valid && col_valid,
+    residual_one<T, S, B, OXM, EDGE>(A, xs, rsk, ycur, j, lane, soff, sy, sx, true, row_valid && col_valid,
                                      row_owned && col_owned, amask, emask, cost_data);
   }
   if (A.lrw > 64) {  // uniform: tail columns 64..lrw-1 of every row
@@ -272,7 +276,7 @@ __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restric
         em |= ((unsigned)(S * gjt + a - HB) < (unsigned)A.W ? 1u : 0u) << a;
       }
     }
-    residual_one<T, S, B, OXM, EDGE>(A, xs, rsk, op.yt, tl.li, tl.lj, soff, tl.act, valid, owned, amask, em,
+    residual_one<T, S, B, OXM, EDGE>(A, xs, rsk, op.yt, tl.li, tl.lj, soff, sy, sx, tl.act, valid, owned, amask, em,
                                      cost_data);
   }
 }
@@ -280,11 +284,12 @@ __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restric
 template <typename T, int S, int B, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void residual_switch(const ArgsT& A, const T* xs, T* rsk, const T* yk,
                                                 const ObsPrefetch<T>& op, int lane, const LaneTail& tl, int gi0,
-                                                int gj0, int CI0, int CJ0, int soff, int fxm, double& cost_data) {
-  if (fxm == 0) residual_pass<T, S, B, 0, EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
-  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
-  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
-  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, cost_data);
+                                                int gj0, int CI0, int CJ0, int soff, int sy, int sx, int fxm,
+                                                double& cost_data) {
+  if (fxm == 0) residual_pass<T, S, B, 0, EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, sy, sx, cost_data);
+  if (S >= 2 && fxm == 1) residual_pass<T, S, B, (S >= 2 ? 1 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, sy, sx, cost_data);
+  if (S >= 3 && fxm == 2) residual_pass<T, S, B, (S >= 3 ? 2 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, sy, sx, cost_data);
+  if (S >= 4 && fxm == 3) residual_pass<T, S, B, (S >= 4 ? 3 : 0), EDGE>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, sy, sx, cost_data);
 }
 
 // ---- Phase C: gather of one frame into the S accumulators of one row thread ----
@@ -298,7 +303,7 @@ template <typename T, int S, bool BORDER>
 __device__ __forceinline__ void gather_frame(T (&acc)[S], const T* __restrict__ rsb, T wr0, T wr1,
                                              const T* __restrict__ wc, unsigned cmask) {
   using C = TileCfg<T, S>;
-  const T v00 = rsb[0], v01 = rsb[1], v10 = rsb[C::LRW], v11 = rsb[C::LRW + 1];
+  const T v00 = rsb[0], v01 = rsb[1], v10 = rsb[C::GRW], v11 = rsb[C::GRW + 1];
   const T t0 = wr0 * v00 + wr1 * v10;
   const T t1 = wr0 * v01 + wr1 * v11;
 #pragma unroll
@@ -488,7 +493,6 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   __shared__ T xs[C::XS_ELEMS];
   __shared__ T scratch[SCRATCH_ELEMS];  // residuals during the data term, then 2*lambda*w*r
   __shared__ T gtw[kTabFrames * 4 * S];  // per frame: wr[S][2] then wc[S][2]
-  __shared__ int gtb[kTabFrames * S];    // per frame and row phase: rs offset
   __shared__ double red[2][C::NW];
   T* rs = scratch;
   T* cr = scratch;
@@ -555,12 +559,10 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   const int kt = A.K < kTabFrames ? A.K : kTabFrames;
   const bool tab_on = want_data && A.g != nullptr;
   T tabw = T(0);
-  int tabb = 0;
   if (tab_on) {
     const int tk = tid / (4 * S), ti = tid - tk * 4 * S;
     const bool okw = tid < kt * 4 * S;
     tabw = ti < 2 * S ? A.wr[okw ? tk * 2 * S + ti : 0] : A.wc[okw ? tk * 2 * S + ti - 2 * S : 0];
-    tabb = A.gb[tid < kt * S ? tid : 0];
   }
   T wreg[S];  // IRLS weights of this thread's pixels
   using HG = HaloGeom<T, S, REGK, R>;
@@ -601,7 +603,6 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   }
   if (tab_on) {
     if (tid < kt * 4 * S) gtw[tid] = tabw;
-    if (tid < kt * S) gtb[tid] = tabb;
   }
   SRMAP_STAMP(2);
   __syncthreads();
@@ -620,10 +621,11 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
       if (k < A.K && !(A.terms & 0x100)) {
         const int soff = A.frames[k].frow * C::XROW + A.frames[k].fcell;  // scalar loads
         const int fxm = A.frames[k].fxm;
-        T* rsk = rs + wv * (C::LRH * C::LRW);
+        const int sy = A.frames[k].sy, sx = A.frames[k].sx;
+        T* rsk = rs + wv * (C::GRH * C::GRW);
         const T* yk = A.y + ((size_t)k * A.obs_C + ch + A.obs_c0) * nl;
-        if (edge_tl) residual_switch<T, S, B, true>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
-        else residual_switch<T, S, B, false>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, fxm, cost_data);
+        if (edge_tl) residual_switch<T, S, B, true>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, sy, sx, fxm, cost_data);
+        else residual_switch<T, S, B, false>(A, xs, rsk, yk, op, lane, tl, gi0, gj0, CI0, CJ0, soff, sy, sx, fxm, cost_data);
       }
       if (k0 == 0) SRMAP_STAMP(4);
       // observations of the next round: in flight during the gather
@@ -634,36 +636,33 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
       // ---------------- Phase C: gather into this thread's S pixels ----------------
       if (A.g != nullptr && !(A.terms & 0x200)) {
         const int kc = (A.K - k0) < C::FR ? (A.K - k0) : C::FR;
-        const T* rs_row = rs + lci * C::LRW + lane;
+        // every frame's 2 x 2 LR patch of this thread sits at the same LDS
+        // offsets (frame-aligned storage), the weights are LDS broadcasts: no
+        // dependent address chain, the unrolled loop keeps 4 frames in flight
+        const T* rs_row = rs + lci * C::GRW + lane;
+        const T* gwr = gtw + 2 * pr;
+        if (!border) {
 #pragma unroll 4
-        for (int kk = 0; kk < kc; ++kk) {
-          const int k = k0 + kk;  // uniform
-          int gbk;
-          T wr0, wr1, wcv[2 * S];
-          if (k < kTabFrames) {
-            // LDS broadcast reads (same address in every lane): no scalar-memory
-            // round trip, and the compiler can hoist them across frames
-            const T* gw = gtw + k * 4 * S;
-            gbk = gtb[k * S + pr];
-            wr0 = gw[2 * pr]; wr1 = gw[2 * pr + 1];
+          for (int kk = 0; kk < kc; ++kk) {
+            const T* gw = gwr + (k0 + kk) * 4 * S;
+            T wcv[2 * S];
 #pragma unroll
-            for (int i = 0; i < 2 * S; ++i) wcv[i] = gw[2 * S + i];
-          } else {
-            gbk = A.gb[k * S + pr];
-            wr0 = A.wr[(k * S + pr) * 2]; wr1 = A.wr[(k * S + pr) * 2 + 1];
-#pragma unroll
-            for (int i = 0; i < 2 * S; ++i) wcv[i] = A.wc[(size_t)k * 2 * S + i];
+            for (int i = 0; i < 2 * S; ++i) wcv[i] = gw[2 * S - 2 * pr + i];
+            gather_frame<T, S, false>(acc, rs_row + kk * (C::GRH * C::GRW), gw[0], gw[1], wcv, 0xffffffffu);
           }
-          const T* rsb = rs_row + kk * (C::LRH * C::LRW) + gbk;
-          if (border) {
+        } else {
+          for (int kk = 0; kk < kc; ++kk) {
+            const int k = k0 + kk;
             const int toy = A.frames[k].toy, tox = A.frames[k].tox;
-            if ((unsigned)(gr + toy) >= (unsigned)A.H) continue;  // p' row outside the image
+            if ((unsigned)(gr + toy) >= (unsigned)A.H) continue;  // p' row outside the image (uniform)
             unsigned cmask = 0;
 #pragma unroll
             for (int pc = 0; pc < S; ++pc) cmask |= ((unsigned)(gc0 + pc + tox) < (unsigned)A.W ? 1u : 0u) << pc;
-            gather_frame<T, S, true>(acc, rsb, wr0, wr1, wcv, cmask);
-          } else {
-            gather_frame<T, S, false>(acc, rsb, wr0, wr1, wcv, 0xffffffffu);
+            const T* gw = gwr + k * 4 * S;
+            T wcv[2 * S];
+#pragma unroll
+            for (int i = 0; i < 2 * S; ++i) wcv[i] = gw[2 * S - 2 * pr + i];
+            gather_frame<T, S, true>(acc, rs_row + kk * (C::GRH * C::GRW), gw[0], gw[1], wcv, cmask);
           }
         }
       }
@@ -780,6 +779,7 @@ static HostPlan make_plan(const srmap_problem* p, int S, int CH, int CW) {
   const int TH = CH * S;
   if (!p->maps_regular) return pl;
   if (B != 1 && B != 3) return pl;
+  if (K > kTabFrames) return pl;  // gather weights of every frame are staged in LDS
   // integer shifts only
   std::vector<int> ox(K, 0), oy(K, 0), tx(K, 0), ty(K, 0);
   if (p->has_motion) {
@@ -846,7 +846,8 @@ static HostPlan make_plan(const srmap_problem* p, int S, int CH, int CW) {
     f.frow = S * pl.i0 + oy[k] + pl.hu - hb;
     f.fcell = pl.j0 + pl.hlc + fdiv(ox[k], S);
     f.fxm = pmod(ox[k], S);
-    f.gbase = (fdiv(ty[k], S) - pl.i0) * (CW + 3) + (fdiv(tx[k], S) - pl.j0);
+    f.sy = fdiv(ty[k], S) - pl.i0;
+    f.sx = fdiv(tx[k], S) - pl.j0;
     f.gym = pmod(ty[k], S);
     f.gxm = pmod(tx[k], S);
     f.toy = ty[k]; f.tox = tx[k];
@@ -927,7 +928,7 @@ bool tiled_plan(srmap_problem* p) {
         if (d < 0 || d > 1) { patch_ok = false; continue; }
         wc[((size_t)k * S + ph) * 2 + d] += k1[e];
       }
-      gb[(size_t)k * S + ph] = f.gbase;
+      gb[(size_t)k * S + ph] = 0;
     }
   }
   if (!patch_ok) return false;
