@@ -122,12 +122,19 @@ constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) 
 constexpr int posmod(int a, int b) { return a - floordiv(a, b) * b; }
 
 // sgn(d) * pw with sgn(0) = 0 (pw > 0).  f32: ldexp pushes every non-zero d
-// (subnormals included) beyond pw, med3 clamps to +-pw: 2 VALU ops, exact.
+// (subnormals included) beyond pw, med3 clamps to +-pw: 2 VALU ops, exact
+// (pw <= 2^50 assumed: BTV decay powers and 1).
 template <typename T>
 __device__ __forceinline__ T sgn_scaled(T d, T pw) { return d > T(0) ? pw : (d < T(0) ? -pw : T(0)); }
 template <>
 __device__ __forceinline__ float sgn_scaled<float>(float d, float pw) {
   return __builtin_amdgcn_fmed3f(__builtin_ldexpf(d, 200), -pw, pw);
+}
+// f64: same idea with ldexp + min + max (3 full-rate ops; the compare/select form costs 2 v_cmp_f64 +
+// 4 v_cndmask_b32, and compare->select pairs stall the issue port, tools/ubench/valu_asm.hip).
+template <>
+__device__ __forceinline__ double sgn_scaled<double>(double d, double pw) {
+  return __builtin_fmin(__builtin_fmax(__builtin_ldexp(d, 1200), -pw), pw);
 }
 template <typename T>
 __device__ __forceinline__ T sgnv(T d) { return sgn_scaled<T>(d, T(1)); }
@@ -480,6 +487,7 @@ __device__ __forceinline__ void reg_pass2(T (&acc)[S], const T* __restrict__ xs,
     if (A.dbg != nullptr && threadIdx.x == STAMP_TID)                                      \
       A.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = \
           __builtin_amdgcn_s_memtime();                                                    \
+    if ((A.terms >> 16) == (i) + 1) return; /* profiling aid: stop after stage i (uniform) */ \
   } while (0)
 
 template <typename T, int S, int B, int REGK, int R>
@@ -499,7 +507,9 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
 
   constexpr int STAMP_TID = 64 * (TileCfg<T, S>::NW - 1);  // last wave, lane 0
   SRMAP_STAMP(0);
-  if (A.terms & 0x800) return;  // ablation aid
+  if (A.dbg != nullptr && threadIdx.x == STAMP_TID)  // HW_ID (CU / SE / XCC of this block) for the schedule plot
+    A.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 15] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index = HR row of the tile (SGPR)
@@ -608,7 +618,6 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   __syncthreads();
   SRMAP_STAMP(3);
 
-  if (A.terms & 0x4000) return;  // ablation aid
   T acc[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) acc[j] = T(0);
@@ -705,7 +714,6 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   }
 
   SRMAP_STAMP(13);
-  if (A.terms & 0x8000) return;  // ablation aid
   // ---------------- cost partials ----------------
   {
     const double sd = wave_sum_d(cost_data);
@@ -977,6 +985,7 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
   A.margin = pl.margin;
   A.terms = (int)terms;
   if (const char* dbg = getenv("SRMAP_DEBUG_SKIP")) A.terms |= atoi(dbg) << 8;  // ablation aid (profiling only)
+  if (const char* dbg = getenv("SRMAP_DEBUG_STOP")) A.terms |= (atoi(dbg) + 1) << 16;  // stop after stamp n
   for (int i = 0; i < B * B; ++i) A.blur[i] = (T)p->blur2d[i];
   A.lambda = T(0);
   for (int i = 0; i < NP; ++i) A.powtab[i] = T(1);
@@ -991,7 +1000,8 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
   const bool timeline = getenv("SRMAP_DEBUG_TIMELINE") != nullptr && ++tl_calls == 30;
   const size_t nb_ = (size_t)grid.x * grid.y * grid.z;
   if (timeline) { (void)hipMalloc((void**)&A.dbg, nb_ * 16 * 8); (void)hipMemset(A.dbg, 0, nb_ * 16 * 8); }
-  hipLaunchKernelGGL((k_eval_fused<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A);
+  static const int extra_lds = getenv("SRMAP_DEBUG_EXTRA_LDS") ? atoi(getenv("SRMAP_DEBUG_EXTRA_LDS")) : 0;  // occupancy probe
+  hipLaunchKernelGGL((k_eval_fused<T, S, B, REGK, R>), grid, dim3(C::NT), extra_lds, st, A);
   if (timeline) {
     (void)hipStreamSynchronize(st);
     std::vector<unsigned long long> h(nb_ * 16);
@@ -1006,10 +1016,11 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
       if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
       for (int i = 0; i < 15; ++i) t1 = std::max(t1, h[b * 16 + i]);
     }
-    fprintf(stderr, "[timeline] blocks %zu, span %llu ticks (s_memtime, 100 MHz => x10 ns); mean delta per stamp:", nb_, t1 - t0);
+    fprintf(stderr, "[timeline] blocks %zu, span %llu ticks (s_memtime = shader clock); mean delta per stamp:", nb_, t1 - t0);
     for (int i = 1; i < 15; ++i) fprintf(stderr, " %d:%.0f", i, sum[i] / (nint ? nint : 1));
     fprintf(stderr, " (over %zu blocks)", nint);
     fprintf(stderr, "\n");
+    if (const char* f = getenv("SRMAP_DEBUG_TIMELINE_FILE")) { FILE* fp = fopen(f, "wb"); if (fp) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); } }
     (void)hipFree(A.dbg);
   }
   *nblocks = (int)(grid.x * grid.y * grid.z);
@@ -1052,7 +1063,14 @@ int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (want_reg)
     for (int r = 0; r < p->nreg; ++r)
       if (!(regk && r == pl.reg_index) && p->reg[r].lambda > 0.0) extra = true;
-  const bool fr = !extra && !getenv("SRMAP_NO_INKERNEL_REDUCE");
+  // ... and when the grid is about one generation of workgroups.  On larger grids
+  // the ticket's device-scope round trip keeps wave 0 -- and with it the
+  // workgroup's LDS -- resident for microseconds and delays the next workgroup
+  // of that CU; a separate 1-block reduction launch is cheaper (measured at
+  // cfg2: 107 -> 100 us f64, 75.5 -> 68.9 us f32).
+  const long ntiles_est = (long)((geo.w + 63) / 64) * ((geo.h * geo.s + 7) / 8) * geo.C;
+  bool fr = !extra && ntiles_est <= 2L * (p->ctx->num_cus > 0 ? p->ctx->num_cus : 256);
+  if (const char* e = getenv("SRMAP_INKERNEL_REDUCE")) fr = !extra && atoi(e) != 0;  // profiling override
   int rc = SRMAP_OK, nb = 0;
   if (geo.s == 2 && geo.b == 1) rc = dispatch_reg<T, 2, 1>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
   else if (geo.s == 2 && geo.b == 3) rc = dispatch_reg<T, 2, 3>(p, geo, obs_c0, fused_terms, x, g, wts, *pc, regk, regr, partials, &nb, fr, st);
