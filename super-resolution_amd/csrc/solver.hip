@@ -8,6 +8,7 @@
 // scalars f and g.d cross PCIe.  The control flow (step selection, stopping
 // rules) runs on the host, in double, in ALGLIB's order of operations so that
 // the trajectory follows the reference's up to reduction order.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -69,9 +70,14 @@ __global__ __launch_bounds__(256) void k_absmax(const T* __restrict__ a, size_t 
 }
 
 // Second stage: rows x nb partials -> out[rows] (sum or max), fixed order.
+// `out` may be host-mapped pinned memory (the CG loop reads it after one stream
+// sync, no copy kernels); extra_src, when given, is one more device scalar (the
+// cost of the evaluation) forwarded to out[rows].
 __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ part, int nb, int rows,
-                                               int is_max, double* __restrict__ out) {
+                                               int is_max, double* __restrict__ out,
+                                               const double* __restrict__ extra_src) {
   __shared__ double red[4];
+  if (extra_src != nullptr && threadIdx.x == 0) out[rows] = extra_src[0];
   for (int r = 0; r < rows; ++r) {
     double v = 0;
     for (int i = threadIdx.x; i < nb; i += 256)
@@ -130,6 +136,7 @@ struct DeviceCG {
     *yk = nullptr, *wa = nullptr;
   double* part = nullptr;  // [3][kRedBlocks]
   double* scal = nullptr;  // [4] device
+  double* hs = nullptr;    // host-mapped pinned scalars (ctx->h_scal): written by k_finish, read after a stream sync
   srmap_allreduce_fn ar = nullptr;
   void* user = nullptr;
   int evaluations = 0;
@@ -142,6 +149,9 @@ struct DeviceCG {
     for (T** q : v) SRMAP_HIP(p->ctx, hipMalloc((void**)q, n * sizeof(T)));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&part, sizeof(double) * 3 * kRedBlocks));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&scal, sizeof(double) * 4));
+    int rc = ensure_staging(p->ctx);
+    if (rc) return rc;
+    hs = p->ctx->h_scal;
     return SRMAP_OK;
   }
   void release() {
@@ -158,21 +168,18 @@ struct DeviceCG {
   int dots(const T* a0, const T* b0, const T* a1, const T* b1, const T* a2, const T* b2, int count,
            double* out) {
     hipLaunchKernelGGL(k_dots<T>, dim3(nb()), dim3(256), 0, st, a0, b0, a1, b1, a2, b2, n, part);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 3, 0, scal);
-    double h[3];
-    SRMAP_HIP(p->ctx, hipMemcpyAsync(h, scal, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 3, 0, hs, (const double*)nullptr);
     SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+    double h[3] = {hs[0], hs[1], hs[2]};
     if (ar) ar(h, count, user);
     for (int i = 0; i < count; ++i) out[i] = h[i];
     return SRMAP_OK;
   }
   int absmax(const T* a, double* out) {
     hipLaunchKernelGGL(k_absmax<T>, dim3(nb()), dim3(256), 0, st, a, n, part);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 1, 1, scal);
-    double h = 0;
-    SRMAP_HIP(p->ctx, hipMemcpyAsync(&h, scal, sizeof(double), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 1, 1, hs, (const double*)nullptr);
     SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
-    *out = h;
+    *out = hs[0];
     return SRMAP_OK;
   }
   // f, g <- objective at x; dg <- g.d (when d_vec != nullptr)
@@ -184,11 +191,14 @@ struct DeviceCG {
     if (d_vec) {
       hipLaunchKernelGGL(k_dots<T>, dim3(nb()), dim3(256), 0, st, (const T*)g, d_vec, (const T*)nullptr,
                          (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, n, part);
-      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 1, 0, scal);
-      SRMAP_HIP(p->ctx, hipMemcpyAsync(&h[1], scal, sizeof(double), hipMemcpyDeviceToHost, st));
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 1, 0, hs, (const double*)p->d_cost);
+      SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+      h[1] = hs[0]; h[0] = hs[1];
+    } else {
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, 0, 0, 0, hs, (const double*)p->d_cost);
+      SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+      h[0] = hs[0];
     }
-    SRMAP_HIP(p->ctx, hipMemcpyAsync(&h[0], p->d_cost, sizeof(double), hipMemcpyDeviceToHost, st));
-    SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
     if (ar) ar(h, 2, user);
     *f = h[0];
     if (dg) *dg = h[1];
@@ -492,6 +502,12 @@ static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const do
   }
   srmap_solve_report rep = {0, 0, 0, 0, 0.0};
   hipStream_t st = p->ctx->stream;
+  static const bool timing = getenv("SRMAP_DEBUG_SOLVE_TIMING") != nullptr;  // phase wall times (profiling aid)
+  auto now = [&]() { if (timing) (void)hipStreamSynchronize(st); return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count(); };
+  double t_alloc = 0, t_up = 0, t_loop = 0, t_down = 0;
+  auto t0 = now();
   DeviceCG<T> cg;
   cg.p = p; cg.st = st; cg.n = npts; cg.ar = ar; cg.user = user;
   int rc = cg.alloc();
@@ -506,14 +522,18 @@ static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const do
   if (rc == SRMAP_OK && p->nreg > 0 && hipMalloc((void**)&regvals, npts * sizeof(T)) != hipSuccess)
     rc = set_error(p->ctx, SRMAP_ENOMEM, "hipMalloc failed");
   const int saved_c0 = p->view_c0, saved_C = p->view_C;
+  t_alloc = ms(t0, now());
   for (int round = 0; round < rounds && rc == SRMAP_OK; ++round) {
     const int c0 = round * per_split;
     p->view_c0 = c0;
     p->view_C = per_split;
     Geometry vg = geo;
     vg.C = per_split;
+    auto t1 = now();
     rc = convert_upload(p, x0 + (size_t)c0 * N, cg.x, npts, st);
     if (rc) break;
+    auto t2 = now();
+    t_up += ms(t1, t2);
     // w <- 1  (irls_map_solver.cpp:66-74)
     for (int r = 0; r < p->nreg; ++r)
       hipLaunchKernelGGL(k_fill<T>, dim3(cg.blocks()), dim3(256), 0, st, (T*)p->reg[r].weights + (size_t)c0 * N, T(1), npts);
@@ -543,13 +563,20 @@ static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const do
     }
     if (rc) break;
     rep.irls_rounds += ran;
+    auto t3 = now();
+    t_loop += ms(t2, t3);
     rc = convert_download(p, cg.x, x_out + (size_t)c0 * N, npts, st);
+    t_down += ms(t3, now());
   }
   rep.evaluations = cg.evaluations;
   p->view_c0 = saved_c0;
   p->view_C = saved_C;
+  auto t4 = now();
   if (regvals) (void)hipFree(regvals);
   cg.release();
+  if (timing)
+    fprintf(stderr, "[solve] alloc %.2f ms, upload %.2f, irls/cg loop %.2f (%d evaluations), download %.2f, free %.2f\n", t_alloc,
+            t_up, t_loop, cg.evaluations, t_down, ms(t4, now()));
   if (report) *report = rep;
   return rc;
 }

@@ -56,6 +56,11 @@ struct srmap_ctx {
   hipStream_t stream = nullptr;
   std::string error;
   int num_cus = 0;
+  // pinned host staging: two chunks for pipelined host<->device copies of caller (pageable) buffers,
+  // and a small scalar block the reduction kernels write directly (no copy kernels, one sync)
+  void* h_stage[2] = {nullptr, nullptr};
+  hipEvent_t h_event[2] = {nullptr, nullptr};
+  double* h_scal = nullptr;  // [16], host-mapped
 };
 
 struct srmap_problem {
@@ -155,7 +160,8 @@ int solve_impl(srmap_problem* p, const srmap_irls_options* o, const double* x0,
                double* x_out, srmap_solve_report* rep, srmap_allreduce_fn ar,
                void* user);
 
-// conversions
+// conversions / staging
+int ensure_staging(srmap_ctx* ctx);
 int convert_upload(srmap_problem* p, const double* host, void* dev, size_t n,
                    hipStream_t st);
 int convert_download(srmap_problem* p, const void* dev, double* host, size_t n,
