@@ -482,12 +482,20 @@ __device__ __forceinline__ void reg_pass2(T (&acc)[S], const T* __restrict__ xs,
   }
 }
 
+// Profiling aids (phase stamps, stop-after-stage, ablation bits) exist only in
+// the -DSRMAP_PROFILING build (lib/libsrmap_prof.so, see tools/): in the product
+// kernel they cost registers (the f32 instance spills with them compiled in).
+#ifdef SRMAP_PROFILING
+constexpr bool kProf = true;
+#else
+constexpr bool kProf = false;
+#endif
 #define SRMAP_STAMP(i)                                                                     \
   do {                                                                                     \
-    if (A.dbg != nullptr && threadIdx.x == STAMP_TID)                                      \
+    if (kProf && A.dbg != nullptr && threadIdx.x == STAMP_TID)                             \
       A.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = \
           __builtin_amdgcn_s_memtime();                                                    \
-    if ((A.terms >> 16) == (i) + 1) return; /* profiling aid: stop after stage i (uniform) */ \
+    if (kProf && (A.terms >> 16) == (i) + 1) return; /* stop after stage i (uniform) */    \
   } while (0)
 
 template <typename T, int S, int B, int REGK, int R>
@@ -507,7 +515,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
 
   constexpr int STAMP_TID = 64 * (TileCfg<T, S>::NW - 1);  // last wave, lane 0
   SRMAP_STAMP(0);
-  if (A.dbg != nullptr && threadIdx.x == STAMP_TID)  // HW_ID (CU / SE / XCC of this block) for the schedule plot
+  if (kProf && A.dbg != nullptr && threadIdx.x == STAMP_TID)  // HW_ID (CU / SE / XCC of this block) for the schedule plot
     A.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 15] =
         ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
   const int tid = threadIdx.x;
@@ -534,7 +542,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   // wave w stages rows w, w + NW, ...; lane = cell (0..63), the few cells beyond
   // 64 by the first lanes.  All loads are issued before the first LDS write.
   constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // row iterations per wave
-  const bool skipA = (A.terms & 0x400) != 0;
+  const bool skipA = kProf && (A.terms & 0x400) != 0;
   const int extra = A.xcells - 64;                  // 0..kMaxHaloCells
   T va[ARI][S], vb[ARI][S];
 #pragma unroll
@@ -559,7 +567,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   const int gi0 = CI0 + A.i0, gj0 = CJ0 + A.j0;  // LR region origin
   const LaneTail tl = tail_lane(lane, A.lrh, A.lrw);
   ObsPrefetch<T> op = {T(0), T(0), T(0)};
-  if (want_data && wv < A.K && !(A.terms & 0x1000))
+  if (want_data && wv < A.K && !(kProf && (A.terms & 0x1000)))
     op = prefetch_obs<T>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0);
   // only tiles whose LR region contains LR row 0 or column 0 need blur-tap masks
   const bool edge_tl = (gi0 <= 0) || (gj0 <= 0);
@@ -627,7 +635,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
     for (int k0 = 0; k0 < A.K; k0 += C::FR) {
       // ---------------- Phase B: residuals of frame k0 + wave ----------------
       const int k = k0 + wv;  // wave-uniform
-      if (k < A.K && !(A.terms & 0x100)) {
+      if (k < A.K && !(kProf && (A.terms & 0x100))) {
         const int soff = A.frames[k].frow * C::XROW + A.frames[k].fcell;  // scalar loads
         const int fxm = A.frames[k].fxm;
         const int sy = A.frames[k].sy, sx = A.frames[k].sx;
@@ -643,7 +651,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
       __syncthreads();
       if (k0 == 0) SRMAP_STAMP(5);
       // ---------------- Phase C: gather into this thread's S pixels ----------------
-      if (A.g != nullptr && !(A.terms & 0x200)) {
+      if (A.g != nullptr && !(kProf && (A.terms & 0x200))) {
         const int kc = (A.K - k0) < C::FR ? (A.K - k0) : C::FR;
         // every frame's 2 x 2 LR patch of this thread sits at the same LDS
         // offsets (frame-aligned storage), the weights are LDS broadcasts: no
@@ -707,7 +715,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
 
   SRMAP_STAMP(12);
   // ---------------- write g: one S-element vector per thread, a wave = one row segment ----------------
-  if (A.g != nullptr && gr < A.H && gc0 < A.W && !(A.terms & 0x2000)) {
+  if (A.g != nullptr && gr < A.H && gc0 < A.W && !(kProf && (A.terms & 0x2000))) {
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pc];
@@ -984,8 +992,10 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
   A.i0 = pl.i0; A.j0 = pl.j0; A.lrh = pl.lrh; A.lrw = pl.lrw;
   A.margin = pl.margin;
   A.terms = (int)terms;
-  if (const char* dbg = getenv("SRMAP_DEBUG_SKIP")) A.terms |= atoi(dbg) << 8;  // ablation aid (profiling only)
-  if (const char* dbg = getenv("SRMAP_DEBUG_STOP")) A.terms |= (atoi(dbg) + 1) << 16;  // stop after stamp n
+  if (kProf) {  // libsrmap_prof.so only
+    if (const char* dbg = getenv("SRMAP_DEBUG_SKIP")) A.terms |= atoi(dbg) << 8;         // ablation bits
+    if (const char* dbg = getenv("SRMAP_DEBUG_STOP")) A.terms |= (atoi(dbg) + 1) << 16;  // stop after stamp n
+  }
   for (int i = 0; i < B * B; ++i) A.blur[i] = (T)p->blur2d[i];
   A.lambda = T(0);
   for (int i = 0; i < NP; ++i) A.powtab[i] = T(1);
@@ -997,7 +1007,7 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.h + C::CH - 1) / C::CH, geo.C);
   A.dbg = nullptr;
   static int tl_calls = 0;
-  const bool timeline = getenv("SRMAP_DEBUG_TIMELINE") != nullptr && ++tl_calls == 30;
+  const bool timeline = kProf && getenv("SRMAP_DEBUG_TIMELINE") != nullptr && ++tl_calls == 30;
   const size_t nb_ = (size_t)grid.x * grid.y * grid.z;
   if (timeline) { (void)hipMalloc((void**)&A.dbg, nb_ * 16 * 8); (void)hipMemset(A.dbg, 0, nb_ * 16 * 8); }
   static const int extra_lds = getenv("SRMAP_DEBUG_EXTRA_LDS") ? atoi(getenv("SRMAP_DEBUG_EXTRA_LDS")) : 0;  // occupancy probe

@@ -9,7 +9,8 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for d in f64 f32; do
   B="python $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --dtype $d"
-  timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$d -o kt -- $B > $out/kt_$d.log 2>&1
+  BK="python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline --dtype $d"
+  timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$d -o kt -- $BK > $out/kt_$d.log 2>&1
   timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch_$d -o pmc -- $B > /dev/null 2>&1
   timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write_$d -o pmc -- $B > /dev/null 2>&1
   timeout 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sqa_$d -o pmc -- $B > /dev/null 2>&1

@@ -1,6 +1,7 @@
 #!/bin/bash
 # VALU/SALU/LDS instruction counts of the fused kernel by phase, via the ablation switches (profiling aid).
 root=$(pwd); out=$root/gpurun_out/${1:-phase}; mkdir -p $out
+export SRMAP_LIB=$root/super-resolution_amd/lib/libsrmap_prof.so  # python -c 'import __graft_entry__ as g; g.build_lib(profiling=True)'
 cd /tmp && export TMPDIR=/tmp
 for d in f64 f32; do
  for v in "all 0" "data 0" "reg 0" "all 1" "all 2" "all 3" "data 3"; do

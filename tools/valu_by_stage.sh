@@ -1,6 +1,7 @@
 #!/bin/bash
 # Cumulative instruction counts of the fused kernel when it stops after stage n (SRMAP_DEBUG_STOP): differences = per-stage cost.
 root=$(pwd); out=$root/gpurun_out/${1:-stage}; mkdir -p $out; d=${2:-f64}
+export SRMAP_LIB=$root/super-resolution_amd/lib/libsrmap_prof.so  # python -c 'import __graft_entry__ as g; g.build_lib(profiling=True)'
 cd /tmp && export TMPDIR=/tmp
 for st in 0 1 3 4 5 6 7 8 9 10 11 12 13 99; do
   SRMAP_DEBUG_STOP=$st timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $out/s$st -o pmc -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --dtype $d > /dev/null 2>&1
