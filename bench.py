@@ -110,6 +110,10 @@ def main():
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
                     help="ablation only: evaluate a subset of the objective terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--joint-scalars", action="store_true",
+                    help="channel sharding only: also all-reduce the scalar cost every step, as ONE joint solve over "
+                         "all channels would (srmap_solve_ex hook). Default: the reference's split_channels semantics "
+                         "(irls_map_solver.cpp:200-210), independent per-channel solves, no collective in the timed region")
     args = ap.parse_args()
 
     import torch
@@ -181,7 +185,9 @@ def main():
             with torch.cuda.stream(stream):
                 if args.shard == "frames":
                     dist.all_reduce(g_dev)          # HR gradient all-reduce over RCCL/xGMI
-                dist.all_reduce(cost_buf)           # scalar cost of the joint objective
+                    dist.all_reduce(cost_buf)       # scalar cost of the joint objective
+                elif args.joint_scalars:
+                    dist.all_reduce(cost_buf)
 
     def barrier():
         stream.synchronize()
@@ -233,6 +239,10 @@ def main():
             "config": {"workload": "configs[1]: 16-frame grayscale, 4x upscale to %dx%d, Gaussian blur 3/1.0 + BTV(3,0.5) "
                                    "lambda 0.01, IRLS weights from x0" % (W, H),
                        "frames": K, "scale": s, "channels": C_total, "shard": args.shard if world > 1 else "none",
+                       "collective_per_step": ("none" if world == 1 else
+                                               "all-reduce(g, C*N) + all-reduce(cost)" if args.shard == "frames" else
+                                               "all-reduce(cost)" if args.joint_scalars else
+                                               "none (split_channels: independent per-channel solves)"),
                        "impl": args.impl, "device_ms_per_step": dev_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.dtype),
