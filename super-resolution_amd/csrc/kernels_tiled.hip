@@ -104,7 +104,10 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index = HR row of the tile (SGPR)
-  const int CI0 = blockIdx.y * C::CH, CJ0 = blockIdx.x * C::CW;
+  // profiling aid (bit 0x4000): every workgroup computes tile (4, 4) -- same instruction stream, all loads hit
+  // the caches -- but writes its own tile: isolates how much of the time is exposed memory latency/bandwidth
+  const bool same_tile = kProf && (A.terms & 0x4000) != 0;
+  const int CI0 = (same_tile ? 4 : blockIdx.y) * C::CH, CJ0 = (same_tile ? 4 : blockIdx.x) * C::CW;
   const int R0 = CI0 * S, C0 = CJ0 * S;
   const int ch = blockIdx.z;
   const size_t N = (size_t)A.W * A.H;
@@ -300,6 +303,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   // ---------------- write g: one S-element vector per thread, a wave = one row segment ----------------
   if (A.g != nullptr && gr < A.H && gc0 < A.W && !(kProf && (A.terms & 0x2000))) {
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
+    if (same_tile) dst += ((size_t)blockIdx.y - 4) * C::TH * A.W + ((size_t)blockIdx.x - 4) * C::TW;
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pc];
   }
