@@ -66,13 +66,13 @@ def pmc_traffic(dtype):
         return None
 
 
-def cpu_baseline(cfg, lr, x0, wts, budget_s=20.0):
+def cpu_baseline(cfg, lr, x0, wts, budget_s=12.0):
     """Oracle (CPU restatement of the reference, 1 thread like the reference) on
     a bounded crop of the same workload, scaled by pixel count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     s, K = cfg["scale"], cfg["frames"]
-    crop_lr = 128  # LR crop 128x128 -> HR 512x512: 1/16 of the cfg2 pixels
+    crop_lr = 256  # LR crop 256x256 -> HR 1024x1024: 1/4 of the cfg2 pixels (~0.65 s per evaluation)
     crop_lr = min(crop_lr, lr.shape[-1])
     ch = crop_lr * s
     model = orc.ImageModel(scale=s, shifts=cfg["shifts"], blur_ksize=cfg["blur"][0], blur_sigma=cfg["blur"][1])
@@ -86,7 +86,7 @@ def cpu_baseline(cfg, lr, x0, wts, budget_s=20.0):
         prob.objective(x)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 5:
+        if el > budget_s or n >= 40:  # about 10-15 s of CPU work
             break
     per_eval_crop = el / n
     frac = (ch * ch) / float(cfg["W"] * cfg["H"])
@@ -104,7 +104,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="arithmetic/storage type on device (the reference is f64)")
-    ap.add_argument("--shard", choices=["channels", "frames"], default="channels")
+    ap.add_argument("--shard", choices=["channels", "frames", "rows"], default="channels",
+                    help="N > 1: channels = one cfg2 channel per GPU, no collective (weak, default); frames = frame shards + "
+                         "RCCL all-reduce of the gradient (strong); rows = HR row bands + halo exchange of x (strong)")
     ap.add_argument("--impl", choices=["auto", "direct", "tiled"], default="auto")
     ap.add_argument("--hr", type=int, default=2048)
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
@@ -152,23 +154,38 @@ def main():
     shifts = [shifts_all[k] for k in frame_ids]
     Kloc = len(frame_ids)
 
+    # row bands: this rank's problem lives on its owned HR rows + halo rows
+    band = None
+    Hloc, e0, e1, r0, r1 = H, 0, H, 0, H
+    if world > 1 and args.shard == "rows":
+        halo = srmap_dist.band_halo(s, 3, s - 1, 3)
+        bands = [srmap_dist.row_band(H, s, world, r, halo) for r in range(world)]
+        (r0, r1), (e0, e1) = bands[rank]
+        Hloc = e1 - e0
+
     ctx = srmap.Context(local_rank)
-    prob = srmap.Problem(ctx, W, H, 1, Kloc, s, shifts, 3, 1.0, dtype)
+    prob = srmap.Problem(ctx, W, Hloc, 1, Kloc, s, shifts, 3, 1.0, dtype)
     prob.set_impl({"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED}[args.impl])
 
     # ---- synthetic data, seeded; channel = rank under channel sharding
     rng = np.random.default_rng(20240607 + (rank if args.shard == "channels" else 0))
     gt = synth_ground_truth(W, H, max(world, 1) if args.shard == "channels" else 1)
     gt = gt[rank:rank + 1] if args.shard == "channels" and world > 1 else gt[:1]
+    gt = gt[:, e0:e1, :]
     lr = np.stack([prob.apply(gt, i) for i in range(Kloc)])
     noise_rng = np.random.default_rng(777 + rank)
     lr = lr + (5.0 / 255.0) * noise_rng.standard_normal(lr.shape)
     prob.set_observations(lr)
     reg = prob.add_regularizer(srmap.REG_BTV, cfg["lambda"], 3, 0.5)
     x0 = bilinear_upsample(lr[0], s)
-    r0 = prob.reg_values(reg, x0)
-    wts = 1.0 / np.maximum(1e-5, r0)
+    rv0 = prob.reg_values(reg, x0)
+    wts = 1.0 / np.maximum(1e-5, rv0)
     prob.set_irls_weights(reg, wts)
+
+    if world > 1 and args.shard == "rows":
+        prob.set_cost_rows(r0 - e0, r1 - e0)
+        band = srmap_dist.BandObjective((r0, r1), (e0, e1), None, dist)
+        band.set_peer_halos([(b[0][0] - b[1][0], b[1][1] - b[0][1]) for b in bands])
 
     x_dev = torch.from_numpy(x0).to(dev, tdtype).contiguous()
     g_dev = torch.empty_like(x_dev)
@@ -180,12 +197,17 @@ def main():
         terms = srmap.TERM_DATA  # the regulariser term is evaluated once (rank 0)
 
     def step():
+        if band is not None:
+            with torch.cuda.stream(stream):
+                band.exchange_halos(x_dev)          # boundary rows of x from the neighbour ranks (xGMI p2p)
         prob.eval_device(x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
         if dist is not None:
             with torch.cuda.stream(stream):
                 if args.shard == "frames":
                     dist.all_reduce(g_dev)          # HR gradient all-reduce over RCCL/xGMI
                     dist.all_reduce(cost_buf)       # scalar cost of the joint objective
+                elif args.shard == "rows":
+                    dist.all_reduce(cost_buf)       # scalar cost (sum of the owned-row costs)
                 elif args.joint_scalars:
                     dist.all_reduce(cost_buf)
 
@@ -234,13 +256,14 @@ def main():
             "unit": "MAP gradient iterations/s" if C_total == 1 else "channel-iterations/s (one 16-frame 2048^2 channel per GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and args.shard == "frames") else "weak",
+            "scaling": "strong" if (world > 1 and args.shard in ("frames", "rows")) else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: 16-frame grayscale, 4x upscale to %dx%d, Gaussian blur 3/1.0 + BTV(3,0.5) "
                                    "lambda 0.01, IRLS weights from x0" % (W, H),
                        "frames": K, "scale": s, "channels": C_total, "shard": args.shard if world > 1 else "none",
                        "collective_per_step": ("none" if world == 1 else
                                                "all-reduce(g, C*N) + all-reduce(cost)" if args.shard == "frames" else
+                                               "p2p halo rows of x + all-reduce(cost)" if args.shard == "rows" else
                                                "all-reduce(cost)" if args.joint_scalars else
                                                "none (split_channels: independent per-channel solves)"),
                        "impl": args.impl, "device_ms_per_step": dev_ms / args.steps},

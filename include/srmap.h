@@ -91,6 +91,15 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* desc,
 void srmap_problem_destroy(srmap_problem* p);
 int srmap_problem_set_impl(srmap_problem* p, int impl /* srmap_impl */);
 
+/* Row-band sharding (no reference counterpart: the reference is single-process).
+ * A rank that owns HR rows [r0, r1) of a larger image creates its problem on the
+ * band extended by halo rows and restricts the COST to the rows it owns:
+ * regulariser pixels of HR rows [hr_row0, hr_row1) and data residuals of LR rows
+ * [hr_row0/scale, hr_row1/scale) (rows relative to this problem; multiples of the
+ * scale).  The gradient is always produced for every row; the caller keeps the
+ * owned ones.  Default: the whole image. */
+int srmap_problem_set_cost_rows(srmap_problem* p, int hr_row0, int hr_row1);
+
 /* LR size the model produces: (int)(len * (1.0/scale)),
  * DownsamplingModule::ApplyToImage downsampling_module.cpp:19-27. */
 int srmap_problem_lr_size(const srmap_problem* p, int* lr_width, int* lr_height);

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void k_forward_direct(
     T res = acc;
     if (y) res -= y[((size_t)k * obs_C + c + obs_c0) * n + lp];
     out[((size_t)kk * g.C + c) * n + lp] = res;
-    sq = (double)res * (double)res;
+    // cost rows (row-band sharding): LR row i counts when its first HR row is in [cr0, cr1)
+    sq = (i * g.s >= g.cr0 && i * g.s < g.cr1) ? (double)res * (double)res : 0.0;
   }
   if (partials) {
     const double s = block_sum_256(sq, red);
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void k_reg_gradient_direct(
     const T* __restrict__ x, const T* __restrict__ gc, T gc_scale,
     const T* __restrict__ values, T* __restrict__ gout, int accumulate,
     double* __restrict__ partials, int W, int H, int C, int kind, int range,
-    PowTable pw) {
+    PowTable pw, int cr0, int cr1) {
   __shared__ double red[4];
   const int hp = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void k_reg_gradient_direct(
     const size_t o = (size_t)c * N + idx;
     if (gout) gout[o] = (accumulate ? gout[o] : T(0)) + grad;
     // lambda * w * r^2  (objective_irls_regularization_term.cpp:45-50)
-    cost = (double)c0 * (double)r0 * (double)r0;
+    cost = (r >= cr0 && r < cr1) ? (double)c0 * (double)r0 * (double)r0 : 0.0;
   }
   if (partials) {
     const double s = block_sum_256(cost, red);
@@ -333,7 +334,7 @@ int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegS
   dim3 grid((geo.W * geo.H + 255) / 256, geo.C);
   hipLaunchKernelGGL(k_reg_gradient_direct<T>, grid, dim3(256), 0, st, x, gc, (T)gc_scale,
                      values, g, accumulate ? 1 : 0, partials, geo.W, geo.H, geo.C, rs.kind,
-                     rs.range, make_pow(rs));
+                     rs.range, make_pow(rs), geo.cr0, geo.cr1);
   if (nblocks) *nblocks = (int)(grid.x * grid.y);
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;

@@ -59,6 +59,7 @@ struct FusedArgs {
   int i0, j0;           // LR region origin relative to the tile's first cell (<= 0)
   int lrh, lrw;         // LR region extent
   int margin;           // tiles closer than this to the image edge take the border path
+  int cr0, cr1;         // HR rows whose cost terms are counted (row-band sharding; default 0, H)
   int terms;            // SRMAP_TERM_* (| ablation bits << 8, profiling only)
   T blur[B * B];        // k * k^T (blur_module.cpp:20-22)
   T lambda;
@@ -285,10 +286,10 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
     const int xrow = A.hu + wv, xcell = A.hlc + lane;
     if (border)
       reg_pass1<T, S, REGK, R, NP, true>(acc, cost_reg, xs, cr, wreg, xrow, xcell, wv + RU, lane + 1, gr, gc0, A.W,
-                                         A.H, A.lambda, A.powtab);
+                                         A.H, A.lambda, A.powtab, gr >= A.cr0 && gr < A.cr1);
     else
       reg_pass1<T, S, REGK, R, NP, false>(acc, cost_reg, xs, cr, wreg, xrow, xcell, wv + RU, lane + 1, gr, gc0, A.W,
-                                          A.H, A.lambda, A.powtab);
+                                          A.H, A.lambda, A.powtab, gr >= A.cr0 && gr < A.cr1);
     SRMAP_STAMP(9);
     if (A.g != nullptr)  // halo strips are needed by pass 2 only
       reg_halo<T, S, REGK, R, NP>(xs, cr, whalo, tid, A.hu, A.hlc, R0, C0, A.W, A.H, A.lambda, A.powtab);
@@ -559,6 +560,7 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
   A.xcells = C::CW + pl.hlc + pl.hrc;
   A.i0 = pl.i0; A.j0 = pl.j0; A.lrh = pl.lrh; A.lrw = pl.lrw;
   A.margin = pl.margin;
+  A.cr0 = geo.cr0; A.cr1 = geo.cr1;
   A.terms = (int)terms;
   if (kProf) {  // libsrmap_prof.so only
     if (const char* dbg = getenv("SRMAP_DEBUG_SKIP")) A.terms |= atoi(dbg) << 8;         // ablation bits

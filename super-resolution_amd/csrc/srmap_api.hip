@@ -363,6 +363,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   if (g.w <= 0 || g.h <= 0) { delete p; return set_error(ctx, SRMAP_EINVAL, "image smaller than the scale"); }
   g.b = blur ? d->blur_ksize : 1;
   g.hb = (g.b - 1) / 2;
+  g.cr0 = 0; g.cr1 = g.H;
   // Gaussian kernel: cv::getGaussianKernel (sigma > 0) and k * k^T, blur_module.cpp:20-22
   p->blur2d.assign((size_t)g.b * g.b, 1.0);
   p->blur1d.assign((size_t)g.b, 1.0);
@@ -454,6 +455,18 @@ int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
   if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
+  return SRMAP_OK;
+}
+
+int srmap_problem_set_cost_rows(srmap_problem* p, int hr_row0, int hr_row1) {
+  if (!p) return SRMAP_EINVAL;
+  const Geometry& g = p->geo;
+  if (hr_row0 < 0 || hr_row1 > g.H || hr_row0 >= hr_row1)
+    return set_error(p->ctx, SRMAP_EINVAL, "cost rows [%d, %d) outside the image", hr_row0, hr_row1);
+  if (hr_row0 % g.s != 0 || (hr_row1 % g.s != 0 && hr_row1 != g.H))
+    return set_error(p->ctx, SRMAP_EINVAL, "cost rows must be multiples of the scale %d", g.s);
+  p->geo.cr0 = hr_row0;
+  p->geo.cr1 = hr_row1;
   return SRMAP_OK;
 }
 

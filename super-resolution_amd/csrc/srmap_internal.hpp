@@ -32,6 +32,8 @@ struct Geometry {
   int w, h;        // LR size
   int s;           // scale
   int b, hb;       // blur kernel size (1 = none) and (b-1)/2
+  int cr0, cr1;    // HR rows [cr0, cr1) whose cost terms are counted (row-band sharding; default 0, H):
+                   // regulariser pixels of those rows, data residuals of LR rows [cr0/s, cr1/s)
 };
 
 struct RegSpec {

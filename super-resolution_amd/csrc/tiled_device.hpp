@@ -229,7 +229,7 @@ __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restric
     if (j + 2 < A.lrh) y1 = load_obs<T>(A, yk, gi0 + j + 2, gj);  // uniform branch
     const int gi = gi0 + j;
     const bool row_valid = (unsigned)gi < (unsigned)A.hl;      // uniform
-    const bool row_owned = (unsigned)(gi - CI0) < (unsigned)C::CH;
+    const bool row_owned = (unsigned)(gi - CI0) < (unsigned)C::CH && S * gi >= A.cr0 && S * gi < A.cr1;  // uniform
     unsigned amask = 0xffffffffu;
     if (EDGE) {
       amask = 0;
@@ -242,7 +242,8 @@ __device__ __forceinline__ void residual_pass(const ArgsT& A, const T* __restric
   if (A.lrw > 64) {  // uniform: tail columns 64..lrw-1 of every row
     const int gi = gi0 + tl.li, gjt = gj0 + tl.lj;
     const bool valid = tl.act && (unsigned)gi < (unsigned)A.hl && (unsigned)gjt < (unsigned)A.wl;
-    const bool owned = tl.act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gjt - CJ0) < (unsigned)C::CW;
+    const bool owned = tl.act && (unsigned)(gi - CI0) < (unsigned)C::CH && (unsigned)(gjt - CJ0) < (unsigned)C::CW &&
+                       S * gi >= A.cr0 && S * gi < A.cr1;
     unsigned amask = 0xffffffffu, em = 0xffffffffu;
     if (EDGE) {
       amask = 0; em = 0;
@@ -297,7 +298,7 @@ template <typename T, int S, int REGK, int R, int NP, bool BORDER>
 __device__ __forceinline__ void reg_pass1(T (&acc)[S], double& cost, const T* __restrict__ xs,
                                           T* __restrict__ cr, const T (&wv)[S], int xrow, int xcell, int crrow,
                                           int crcell, int gr, int gc0, int W, int H, T lambda,
-                                          const T (&pw)[NP]) {
+                                          const T (&pw)[NP], bool cost_row = true) {
   using C = TileCfg<T, S>;
   constexpr int WIN = (REGK == 2) ? R : 1;  // taps extend WIN pixels right/down
   constexpr int NC = S + WIN;
@@ -348,7 +349,7 @@ __device__ __forceinline__ void reg_pass1(T (&acc)[S], double& cost, const T* __
     T cr2 = T(2) * c * r;
     acc[pc] += cr2 * didi;
     const bool in_img = gr < H && gc0 + pc < W;
-    const double cd = in_img ? (double)c * (double)r * (double)r : 0.0;
+    const double cd = (in_img && cost_row) ? (double)c * (double)r * (double)r : 0.0;
     cost += cd;
     if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
     cr[crrow * C::CRROW + pc * C::CRPLANE + crcell] = cr2;

@@ -57,6 +57,7 @@ _SIGNATURES = [
     ("srmap_last_error", C.c_char_p, [C.c_void_p]),
     ("srmap_version", C.c_char_p, []),
     ("srmap_problem_create", C.c_int, [C.c_void_p, C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),
+    ("srmap_problem_set_cost_rows", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("srmap_problem_destroy", None, [C.c_void_p]),
     ("srmap_problem_set_impl", C.c_int, [C.c_void_p, C.c_int]),
     ("srmap_problem_lr_size", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -167,6 +168,10 @@ class Problem:
 
     def set_impl(self, impl):
         self.ctx.check(load().srmap_problem_set_impl(self._h, impl))
+
+    def set_cost_rows(self, hr_row0, hr_row1):
+        """Row-band sharding: count only the cost terms of HR rows [hr_row0, hr_row1)."""
+        self.ctx.check(load().srmap_problem_set_cost_rows(self._h, hr_row0, hr_row1))
 
     def set_observations(self, lr):
         a, pa = _d(lr)
