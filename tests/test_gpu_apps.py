@@ -1,0 +1,104 @@
+"""The command-line callers of the path: generate_data and
+super_resolution (host/apps) run end to end on a GPU box on a small synthetic
+cube in ENVI format, and agree with the library driven from Python."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_envi(path, cube):
+    cube = np.asarray(cube, dtype="<f4")
+    cube.tofile(path)
+    C, H, W = cube.shape
+    with open(path + ".config", "w") as f:
+        f.write("file %s\ninterleave bsq\ndata_type float\nbig_endian false\nheader_offset 0\n" % path)
+        f.write("num_data_rows %d\nnum_data_cols %d\nnum_data_bands %d\n" % (H, W, C))
+        f.write("start_row 0\nend_row %d\nstart_col 0\nend_col %d\nstart_band 0\nend_band %d\n" % (H, W, C))
+    return path + ".config"
+
+
+def _read_envi(path, shape):
+    return np.fromfile(path, dtype="<f4").reshape(shape).astype(np.float64)
+
+
+def _ground_truth(C, H, W):
+    v, u = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+    base = 0.5 + 0.25 * np.sin(2 * np.pi * 2 * u) * np.cos(2 * np.pi * 3 * v) + 0.2 * ((u - .5) ** 2 + (v - .5) ** 2 < .08)
+    return np.stack([np.clip(base * (0.7 + 0.3 * c / max(1, C - 1)), 0, 1) for c in range(C)])
+
+
+def test_generate_then_super_resolve(tmp_path):
+    import __graft_entry__ as ge
+    ge.build_lib()
+    gen, sr = ge.build_apps()
+    C, H, W, s, K = 2, 48, 64, 2, 4
+    gt = _ground_truth(C, H, W)
+    gt_cfg = _write_envi(str(tmp_path / "gt"), gt)
+    motion = tmp_path / "motion.txt"
+    motion.write_text("0 0\n1 1\n0 1\n1 0\n")
+    lr_dir = tmp_path / "lr"
+    lr_dir.mkdir()
+    out = subprocess.run([gen, "--input_image=" + gt_cfg, "--output_image_dir=" + str(lr_dir),
+                          "--motion_sequence_path=" + str(motion), "--blur_radius=3", "--blur_sigma=1.0",
+                          "--downsampling_scale=%d" % s, "--number_of_frames=%d" % K],
+                         capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0
+    frames = np.stack([_read_envi(str(lr_dir / ("low_res_%d" % i)), (C, H // s, W // s)) for i in range(K)])
+
+    # the frames on disk are the image model applied by the library (float32 on disk)
+    import srmap
+    ctx = srmap.Context(0)
+    shifts = [[0, 0], [1, 1], [0, 1], [1, 0]]
+    prob = srmap.Problem(ctx, W, H, C, K, s, shifts, 3, 1.0, srmap.F64)
+    gt32 = gt.astype(np.float32).astype(np.float64)   # what the tool read back from the ENVI file
+    for k in range(K):
+        assert np.allclose(frames[k], prob.apply(gt32, k), atol=2e-7)
+
+    result_path = str(tmp_path / "result")
+    out = subprocess.run([sr, "--data_path=" + str(lr_dir), "--ground_truth_image=" + gt_cfg,
+                          "--upsampling_scale=%d" % s, "--blur_radius=3", "--blur_sigma=1.0",
+                          "--motion_sequence_path=" + str(motion), "--regularizer=btv", "--btv_scale_range=2",
+                          "--regularization_parameter=0.001", "--optimization_iterations=5",
+                          "--solver_iterations=30", "--evaluators=psnr", "--result_path=" + result_path],
+                         capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0
+    lines = {l.split(":")[0].strip(): float(l.split(":")[1]) for l in out.stdout.splitlines() if l.startswith("PSNR")}
+    assert lines["PSNR score on result"] > lines["PSNR score on upsampled"] + 1.0
+    result = _read_envi(result_path, (C, H, W))
+    mse = np.mean((result - gt32) ** 2)
+    assert abs(-10 * np.log10(mse) - lines["PSNR score on result"]) < 1e-3
+
+    # same solve through the Python binding of the same C ABI: same image up to the float32 file format
+    prob.set_observations(frames)
+    prob.add_regularizer(srmap.REG_BTV, 0.001, 2, 0.5)
+    o = srmap.default_irls_options()
+    o.max_num_irls_iterations, o.max_num_solver_iterations = 5, 30
+    import bench
+    x0 = np.stack([bench.bilinear_upsample(frames[0, c:c + 1], s)[0] for c in range(C)])
+    x, _ = prob.solve(x0, o)
+    assert np.max(np.abs(x - result)) < 5e-3
+
+
+def test_pgm_round_trip_and_usage(tmp_path):
+    import __graft_entry__ as ge
+    ge.build_lib()
+    gen, sr = ge.build_apps()
+    img = (np.arange(20 * 30).reshape(20, 30) % 251).astype(np.uint8)
+    p = tmp_path / "a.pgm"
+    with open(p, "wb") as f:
+        f.write(b"P5\n# comment\n30 20\n255\n" + img.tobytes())
+    q = tmp_path / "b.pgm"
+    out = subprocess.run([gen, "--input_image=" + str(p), "--save_as=" + str(q)], capture_output=True, text=True)
+    assert out.returncode == 0
+    data = open(q, "rb").read()
+    assert data.endswith(img.tobytes())
+    bad = subprocess.run([sr, "--no_such_flag=1", "--data_path=x"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "unknown flag" in bad.stderr
