@@ -158,16 +158,20 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
     op = prefetch_obs<T>(A, A.y + ((size_t)wv * A.obs_C + ch + A.obs_c0) * nl, lane, tl, gi0, gj0);
   // only tiles whose LR region contains LR row 0 or column 0 need blur-tap masks
   const bool edge_tl = (gi0 <= 0) || (gj0 <= 0);
-  // gather tables: one element per thread into a register now, into LDS after
-  // the x tile (kTabFrames * 4 * S <= NT)
-  static_assert(kTabFrames * 4 * S <= C::NT, "gather table does not fit one element per thread");
+  // gather tables: NTAB elements per thread into registers now, into LDS after the x tile
+  constexpr int NTAB = (kTabFrames * 4 * S + C::NT - 1) / C::NT;
   const int kt = A.K < kTabFrames ? A.K : kTabFrames;
   const bool tab_on = want_data && A.g != nullptr;
-  T tabw = T(0);
-  if (tab_on) {
-    const int tk = tid / (4 * S), ti = tid - tk * 4 * S;
-    const bool okw = tid < kt * 4 * S;
-    tabw = ti < 2 * S ? A.wr[okw ? tk * 2 * S + ti : 0] : A.wc[okw ? tk * 2 * S + ti - 2 * S : 0];
+  T tabw[NTAB];
+#pragma unroll
+  for (int q = 0; q < NTAB; ++q) {
+    tabw[q] = T(0);
+    const int e = tid + q * C::NT;
+    if (tab_on && q * C::NT < kt * 4 * S) {  // uniform
+      const int tk = e / (4 * S), ti = e - tk * 4 * S;
+      const bool okw = e < kt * 4 * S;
+      tabw[q] = ti < 2 * S ? A.wr[okw ? tk * 2 * S + ti : 0] : A.wc[okw ? tk * 2 * S + ti - 2 * S : 0];
+    }
   }
   T wreg[S];  // IRLS weights of this thread's pixels
   using HG = HaloGeom<T, S, REGK, R>;
@@ -207,7 +211,9 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
     }
   }
   if (tab_on) {
-    if (tid < kt * 4 * S) gtw[tid] = tabw;
+#pragma unroll
+    for (int q = 0; q < NTAB; ++q)
+      if (tid + q * C::NT < kt * 4 * S) gtw[tid + q * C::NT] = tabw[q];
   }
   SRMAP_STAMP(2);
   __syncthreads();

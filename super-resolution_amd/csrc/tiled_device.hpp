@@ -51,7 +51,7 @@ namespace {
 
 constexpr int kMaxHaloRows = 12;  // max hu + hd of the x tile
 constexpr int kMaxHaloCells = 4;  // max hlc + hrc
-constexpr int kTabFrames = 32;         // frames whose gather weights are staged in LDS
+constexpr int kTabFrames = 64;         // frames whose gather weights are staged in LDS (cfg5 has 64)
 constexpr unsigned kSubCounters = 32;  // first-level arrival counters of the in-kernel cost reduction
 
 constexpr int cmax_(int a, int b) { return a > b ? a : b; }

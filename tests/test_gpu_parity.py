@@ -400,6 +400,9 @@ TILED_CASES = [
     (138, 68, 2, 2, 1, [[0, 0], [1, 0], [-1, 3]]),
     (201, 150, 1, 3, 3, [[i, j] for i in range(3) for j in range(3)]),
     (111, 99, 1, 3, 1, [[0, 0], [2, 1], [-2, -1], [1, -4]]),
+    # more frames than one residual round, up to the 64 of cfg5 (gather tables: two elements per thread)
+    (136, 48, 1, 4, 3, [[k % 4, (k // 4) % 4] for k in range(40)]),
+    (72, 40, 1, 4, 3, [[(k * 3) % 4, (k // 2) % 4] for k in range(64)]),
 ]
 TILED_REGS = [[], [(0, 0.05, 0, 0.0)], [(2, 0.01, 3, 0.5)], [(2, 0.02, 2, 0.7)], [(2, 0.03, 1, 0.5)],
               [(2, 0.01, 3, 0.5), (0, 0.02, 0, 0.0)], [(1, 0.02, 0, 0.0), (2, 0.01, 2, 0.5)]]
