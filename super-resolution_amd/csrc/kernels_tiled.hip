@@ -4,33 +4,35 @@
 // blur size B in {1,3}, and at most one regulariser handled in-kernel (2-D TV or
 // BTV with range <= 3); anything else is evaluated by kernels_direct.hip.
 //
-// Design (DESIGN.md "Fused evaluation kernel"):
-//   * Row-major ownership: a workgroup of TH waves (TH = 16 HR rows, 15 for
+// Design:
+//   * Row-major ownership: a workgroup of TH waves (TH = 8 HR rows, 9 for
 //     S = 3) owns a tile of TH x (64*S) HR pixels; wave w owns HR row w, lane l
 //     owns the S pixels of LR cell column l in that row.  x / IRLS weights are
 //     read and g is written as one S-element vector per thread (a wave touches
 //     one contiguous 64*S-element row segment): every compulsory byte crosses
-//     HBM once, x halo re-reads hit L2.  Per-thread state is small (S
-//     accumulators), so many waves per SIMD stay resident and hide the ~1 us
-//     HBM / ~100 cycle LDS latencies that dominate this kernel.
+//     HBM once, x halo re-reads hit L2.  Row phase, the LR rows a pixel row
+//     receives from and all row predicates are wave-uniform (SGPR).
 //   * The x tile (+halo) is staged in LDS in POLYPHASE layout
 //     xs[row][column phase (c mod S)][cell]: the decimated forward stencil
 //     (stride-S access) and the per-pixel regulariser windows are unit-stride
 //     across lanes -> no LDS bank conflicts, every tap offset an immediate.
-//   * Per round of FR frames: the waves sweep the LR region the tile needs and
-//     compute the residuals r_k = A_k x - y_k (warp -> blur -> decimate fused,
-//     objective_data_term.cpp:27-50) into LDS; then every thread gathers
-//     sum_k M_k^T B^T D^T r_k for its S pixels (image_model.cpp:93-101).  The
-//     frame's shift phase (shift mod S, combined with the row phase) selects
-//     one of S*S fully unrolled code paths by a wave-uniform switch: tap
-//     positions and register targets are compile-time, a valid tap is one FMA.
+//   * Per round of NW frames (one per wave): the wave sweeps the LR region the
+//     tile's gather needs, one LR row per iteration of a rolled loop, and
+//     computes r_k = A_k x - y_k (warp -> blur -> decimate fused,
+//     objective_data_term.cpp:27-50) into LDS, stored frame-aligned; then every
+//     thread gathers sum_k M_k^T B^T D^T r_k for its S pixels
+//     (image_model.cpp:93-101) from the same LDS offsets for every frame, with
+//     wave-uniform weights (1-D blur taps or 0) tabulated by the host: no
+//     branches.  The forward stencil's column phase (ox mod S) selects one of S
+//     code paths by a wave-uniform switch.
 //   * The regulariser (tv_regularizer.cpp:135-227 / btv_regularizer.cpp:93-170,
 //     bug-compatible) runs on the same x tile: pass 1 computes r, the self term
 //     and 2*lambda*w*r for the tile plus an up/left halo strip into LDS, pass 2
 //     adds the neighbour terms.
-//   * Cost: fp64 wave-shuffle + workgroup reduction -> partials; the last
-//     workgroup to arrive (agent-scope ticket) sums them in index order, so the
-//     total is deterministic without a second launch.
+//   * Cost: fp64 wave-shuffle + workgroup reduction -> partials, summed in index
+//     order (deterministic): by the last workgroup to arrive (agent-scope
+//     ticket) on grids of about one generation of workgroups, by a separate
+//     1-block launch on larger grids.
 // No MFMA: this is a stencil/gather path.
 #include "tiled_device.hpp"
 
