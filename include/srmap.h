@@ -163,6 +163,19 @@ int srmap_upload(srmap_problem* p, const double* host, void* dev, size_t count);
 int srmap_download(srmap_problem* p, const void* dev, double* host, size_t count);
 int srmap_synchronize(srmap_ctx* ctx);
 
+/* ---------------------------------------------- spectral (channel) maps */
+/* out[r][p] = sum_c M[r][c] * (in[c][p] - offset_in[c]) + offset_out[r] on planar
+ * images in[rows_in][n], out[rows_out][n] (host, double): the per-pixel
+ * projection of SpectralPCA::GetPCAImage / ReconstructImage
+ * (spectral_pca.cpp:94-161: cv::PCA::project / backProject pixel by pixel),
+ * done as one dense contraction on the GPU (rocBLAS DGEMM: this is the one place
+ * on the path where the matrix cores apply).  M is rows_out x rows_in, row
+ * major; the offsets may be NULL (zero). */
+int srmap_channel_map(srmap_ctx* ctx, int rows_out, int rows_in, size_t n,
+                      const double* M, const double* offset_in,
+                      const double* offset_out, const double* in_host,
+                      double* out_host);
+
 /* ------------------------------------------------------------- solver */
 /* IRLSMapSolverOptions (irls_map_solver.h:14-36) + MapSolverOptions
  * (map_solver.h:28-79); srmap_irls_options_default() fills the reference

@@ -3,7 +3,7 @@
 // main), on the drop-in classes: load or generate the LR frames, bilinear
 // initial estimate, IRLS-MAP solve on the GPU, optional PSNR against the ground
 // truth, save.  Same flag names and defaults.  Not carried over (out of scope,
-// DESIGN.md section 7): wavelet-domain solve, colour-space interpolation, PCA,
+// DESIGN.md section 7): wavelet-domain solve, colour-space interpolation,
 // L-BFGS / numerical differentiation, SSIM, display.
 #include <chrono>
 #include <cstdio>
@@ -15,6 +15,7 @@
 
 #include "apps/app_flags.h"
 #include "evaluation/peak_signal_to_noise_ratio.h"
+#include "hyperspectral/spectral_pca.h"
 #include "image/image_io.h"
 #include "image_model/image_model.h"
 #include "optimization/irls_map_solver.h"
@@ -30,6 +31,7 @@ int main(int argc, char** argv) {
       "  [--motion_sequence_path=<file>] [--optimization_iterations=20] [--split_channels]\n"
       "  [--regularizer=tv|3dtv|btv] [--btv_scale_range=3] [--btv_spatial_decay=0.5]\n"
       "  [--regularization_parameter=0.01] [--solver=cg] [--solver_iterations=50]\n"
+      "  [--solve_in_pca_space] [--num_pca_components=0] [--pca_retained_variance=0]\n"
       "  [--evaluators=psnr] [--result_path=<path>] [--verbose]");
   const std::string data_path = flags.Str("data_path");
   const bool generate_lr_images = flags.Bool("generate_lr_images", false);
@@ -52,6 +54,9 @@ int main(int argc, char** argv) {
   const double btv_spatial_decay = flags.Double("btv_spatial_decay", 0.5);
   const double regularization_parameter = flags.Double("regularization_parameter", 0.01);
   const std::string solver_name = flags.Str("solver", "cg");
+  const bool solve_in_pca_space = flags.Bool("solve_in_pca_space", false);
+  const int num_pca_components = flags.Int("num_pca_components", 0);
+  const double pca_retained_variance = flags.Double("pca_retained_variance", 0.0);
   const std::string evaluators = flags.Str("evaluators");
   const std::string result_path = flags.Str("result_path");
   const bool verbose = flags.Bool("verbose", false);
@@ -87,9 +92,21 @@ int main(int argc, char** argv) {
   const bool has_ground_truth = !ground_truth_image.empty() || generate_lr_images;
   const bool evaluate_results = has_ground_truth && !evaluators.empty();
 
+  // bilinear upsampling of frame 0 in the original spectral space: the evaluation baseline
+  ImageData upsampled_image = low_res_images[0];
+  upsampled_image.ResizeImage(upsampling_scale, INTERPOLATE_LINEAR);
+
+  // spectral PCA (super_resolution.cpp:344-366): solve on the leading components, reconstruct afterwards
+  std::unique_ptr<SpectralPCA> spectral_pca;
+  if (solve_in_pca_space) {
+    if (pca_retained_variance > 0.0) spectral_pca.reset(new SpectralPCA(low_res_images, pca_retained_variance));
+    else spectral_pca.reset(new SpectralPCA(low_res_images, num_pca_components));
+    for (auto& frame : low_res_images) frame = spectral_pca->GetPCAImage(frame);
+    std::printf("Super-resolving in PCA space with %d PCA components.\n", low_res_images[0].GetNumChannels());
+  }
+
   ImageData initial_estimate = low_res_images[0];
   initial_estimate.ResizeImage(upsampling_scale, INTERPOLATE_LINEAR);
-  const ImageData upsampled_image = initial_estimate;
 
   IRLSMapSolver solver(solver_options, image_model, low_res_images, verbose);
   if (regularization_parameter > 0.0) {
@@ -112,9 +129,10 @@ int main(int argc, char** argv) {
 
   std::printf("Super-resolving from %zu images...\n", low_res_images.size());
   const auto start_time = std::chrono::steady_clock::now();
-  const ImageData result = solver.Solve(initial_estimate);
+  ImageData result = solver.Solve(initial_estimate);
   const std::chrono::duration<double> elapsed = std::chrono::steady_clock::now() - start_time;
   std::printf("Done! Finished in %g seconds.\n", elapsed.count());
+  if (spectral_pca) result = spectral_pca->ReconstructImage(result);
 
   if (evaluate_results) {
     size_t pos = 0;

@@ -78,6 +78,7 @@ _SIGNATURES = [
     ("srmap_device_free", C.c_int, [C.c_void_p, C.c_void_p]),
     ("srmap_upload", C.c_int, [C.c_void_p, c_double_p, C.c_void_p, C.c_size_t]),
     ("srmap_download", C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_size_t]),
+    ("srmap_channel_map", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("srmap_synchronize", C.c_int, [C.c_void_p]),
     ("srmap_irls_options_default", None, [C.POINTER(IrlsOptions)]),
     ("srmap_solve", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
@@ -122,6 +123,19 @@ class Context:
 
     def synchronize(self):
         self.check(load().srmap_synchronize(self._h))
+
+    def channel_map(self, M, x, offset_in=None, offset_out=None):
+        """out[r] = sum_c M[r, c] * (x[c] - offset_in[c]) + offset_out[r] on a planar image x[C, ...] (GPU DGEMM)."""
+        Mm, pM = _d(M)
+        a, pa = _d(x)
+        ro, ri = Mm.shape
+        assert a.shape[0] == ri
+        n = a.size // ri
+        out = np.empty((ro,) + a.shape[1:])
+        oi = _d(offset_in) if offset_in is not None else (None, None)
+        oo = _d(offset_out) if offset_out is not None else (None, None)
+        self.check(load().srmap_channel_map(self._h, ro, ri, n, pM, oi[1], oo[1], pa, out.ctypes.data_as(c_double_p)))
+        return out
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -7,12 +7,14 @@
 //   test/test_map_solver.cpp:79-199    SmallDataTest (1 / 10 channels / split)
 //   test/test_map_solver.cpp:369-469   RegularizationTest (PSNR ordering)
 //   test/test_evaluation.cpp:12-47     PSNR literal
+//   test/test_spectral_pca.cpp:19-137  SpectralPCA literal + reconstruction bounds
 #include <cmath>
 #include <cstdio>
 #include <random>
 #include <vector>
 
 #include "evaluation/peak_signal_to_noise_ratio.h"
+#include "hyperspectral/spectral_pca.h"
 #include "image/image_data.h"
 #include "image_model/image_model.h"
 #include "motion/motion_shift.h"
@@ -181,6 +183,52 @@ static void TestPsnr() {
   EXPECT(std::fabs(psnr.Evaluate(im) - 17.09269960975831) < 1e-12);
 }
 
+// TEST(SpectralPCA, Decomposition), test_spectral_pca.cpp:19-137
+static double MaxAbsDiff(const ImageData& a, const ImageData& b) {
+  double m = 0;
+  for (int c = 0; c < a.GetNumChannels(); ++c)
+    for (int i = 0; i < a.GetNumPixels(); ++i) m = std::max(m, std::fabs(a.GetChannelData(c)[i] - b.GetChannelData(c)[i]));
+  return m;
+}
+static void TestSpectralPca() {
+  const double ch1[10] = {1.85, 2.05, -0.95, -1.55, -2.55, 2.85, 1.95, 2.75, -2.75, -3.65};
+  const double ch2[10] = {2.2175, 2.5425, -1.2075, -1.9575, -3.3825, 3.6425, 2.5925, 3.3175, -3.4825, -4.2825};
+  ImageData small_image;
+  small_image.AddChannel(ch1, cv::Size(1, 10));
+  small_image.AddChannel(ch2, cv::Size(1, 10));
+  const SpectralPCA pca_small({small_image});
+  const std::vector<double> known1 = {2.88737, 3.266, -1.53633, -2.49680, -4.23402, 4.62459, 3.24237, 4.30858, -4.43722, -5.62453};
+  const std::vector<double> known2 = {0.0538, 0.00622, 0.01545, 0.01729, 0.12995, -0.05886, -0.10306, 0.06669, 0.03664, -0.16411};
+  const ImageData small_pca = pca_small.GetPCAImage(small_image);
+  EXPECT(small_pca.GetNumChannels() == 2);
+  EXPECT(Near(small_pca.GetChannelData(0), known1, 1e-5));
+  EXPECT(Near(small_pca.GetChannelData(1), known2, 1e-5));
+  EXPECT(MaxAbsDiff(pca_small.ReconstructImage(small_pca), small_image) <= 1e-5);
+
+  // bigger image with strongly correlated channels (:62-80; cv::randn replaced by std::normal_distribution)
+  ImageData cube;
+  const int num_channels = 300;
+  const cv::Size size(50, 25);
+  std::mt19937_64 rng(12345);
+  std::normal_distribution<double> gauss(0.5, 0.1);
+  std::vector<double> base(size.area());
+  for (int i = 0; i < num_channels; ++i) {
+    const double scalar = static_cast<double>(i) / num_channels;
+    for (auto& v : base) v = gauss(rng) * scalar;
+    cube.AddChannel(base.data(), size);
+  }
+  const SpectralPCA pca_full({cube});
+  EXPECT(MaxAbsDiff(pca_full.ReconstructImage(pca_full.GetPCAImage(cube)), cube) <= 1e-5);
+  const SpectralPCA pca_count({cube}, 250);
+  const ImageData pca_count_image = pca_count.GetPCAImage(cube);
+  EXPECT(pca_count_image.GetNumChannels() == 250);
+  EXPECT(MaxAbsDiff(pca_count.ReconstructImage(pca_count_image), cube) <= 0.05);
+  const SpectralPCA pca_var({cube}, 0.999);
+  const ImageData pca_var_image = pca_var.GetPCAImage(cube);
+  EXPECT(pca_var_image.GetNumChannels() < cube.GetNumChannels());
+  EXPECT(MaxAbsDiff(pca_var.ReconstructImage(pca_var_image), cube) <= 0.05);
+}
+
 int main() {
   TestDownsamplingModule();
   TestBlurModule();
@@ -190,6 +238,7 @@ int main() {
   TestSmallData(10, true);
   TestRegularizationOrdering();
   TestPsnr();
+  TestSpectralPca();
   std::printf(g_fail ? "FACADE TESTS FAILED (%d)\n" : "FACADE TESTS PASSED\n", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -455,3 +455,15 @@ def test_fused_kernel_matches_oracle_and_direct(sr, ctx, case, regs, dtype):
     assert relerr(gd_t + gr_t, g_t) <= 4 * tol
     fc, _ = p.eval(x, sr.TERM_ALL, want_grad=False)
     assert abs(fc - f_t) <= 1e-12 * max(1.0, abs(f_t))
+
+
+def test_channel_map_matches_numpy(sr, ctx):
+    """srmap_channel_map (the per-pixel PCA projection as one GPU DGEMM) against numpy."""
+    rng = np.random.default_rng(77)
+    for ri, ro, shape in ((5, 3, (7, 9)), (64, 64, (33, 17)), (3, 8, (1000,)), (300, 40, (25, 50))):
+        M = rng.standard_normal((ro, ri))
+        x = rng.standard_normal((ri,) + shape)
+        oi, oo = rng.standard_normal(ri), rng.standard_normal(ro)
+        ref = np.tensordot(M, x - oi.reshape((-1,) + (1,) * len(shape)), axes=1) + oo.reshape((-1,) + (1,) * len(shape))
+        assert relerr(ctx.channel_map(M, x, oi, oo), ref) <= 1e-12
+        assert relerr(ctx.channel_map(M, x), np.tensordot(M, x, axes=1)) <= 1e-12
