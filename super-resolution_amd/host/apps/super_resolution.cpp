@@ -3,8 +3,8 @@
 // main), on the drop-in classes: load or generate the LR frames, bilinear
 // initial estimate, IRLS-MAP solve on the GPU, optional PSNR against the ground
 // truth, save.  Same flag names and defaults.  Not carried over (out of scope,
-// DESIGN.md section 7): wavelet-domain solve, colour-space interpolation,
-// L-BFGS / numerical differentiation, SSIM, display.
+// DESIGN.md section 7): wavelet-domain solve, L-BFGS / numerical differentiation,
+// SSIM, display.
 #include <chrono>
 #include <cstdio>
 #include <iostream>
@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
       "  [--motion_sequence_path=<file>] [--optimization_iterations=20] [--split_channels]\n"
       "  [--regularizer=tv|3dtv|btv] [--btv_scale_range=3] [--btv_spatial_decay=0.5]\n"
       "  [--regularization_parameter=0.01] [--solver=cg] [--solver_iterations=50]\n"
-      "  [--solve_in_pca_space] [--num_pca_components=0] [--pca_retained_variance=0]\n"
+      "  [--interpolate_color] [--solve_in_pca_space] [--num_pca_components=0] [--pca_retained_variance=0]\n"
       "  [--evaluators=psnr] [--result_path=<path>] [--verbose]");
   const std::string data_path = flags.Str("data_path");
   const bool generate_lr_images = flags.Bool("generate_lr_images", false);
@@ -54,6 +54,7 @@ int main(int argc, char** argv) {
   const double btv_spatial_decay = flags.Double("btv_spatial_decay", 0.5);
   const double regularization_parameter = flags.Double("regularization_parameter", 0.01);
   const std::string solver_name = flags.Str("solver", "cg");
+  const bool interpolate_color = flags.Bool("interpolate_color", false);
   const bool solve_in_pca_space = flags.Bool("solve_in_pca_space", false);
   const int num_pca_components = flags.Int("num_pca_components", 0);
   const double pca_retained_variance = flags.Double("pca_retained_variance", 0.0);
@@ -96,9 +97,15 @@ int main(int argc, char** argv) {
   ImageData upsampled_image = low_res_images[0];
   upsampled_image.ResizeImage(upsampling_scale, INTERPOLATE_LINEAR);
 
+  // luminance-only colour path (super_resolution.cpp:330-342, 392-395): solve Y, interpolate Cr / Cb
+  if (interpolate_color) {
+    std::printf("Super-resolving only the luminance channel.\n");
+    for (auto& frame : low_res_images) frame.ChangeColorSpace(SPECTRAL_MODE_COLOR_YCRCB, true);
+  }
+
   // spectral PCA (super_resolution.cpp:344-366): solve on the leading components, reconstruct afterwards
   std::unique_ptr<SpectralPCA> spectral_pca;
-  if (solve_in_pca_space) {
+  if (solve_in_pca_space && !interpolate_color) {
     if (pca_retained_variance > 0.0) spectral_pca.reset(new SpectralPCA(low_res_images, pca_retained_variance));
     else spectral_pca.reset(new SpectralPCA(low_res_images, num_pca_components));
     for (auto& frame : low_res_images) frame = spectral_pca->GetPCAImage(frame);
@@ -132,6 +139,10 @@ int main(int argc, char** argv) {
   ImageData result = solver.Solve(initial_estimate);
   const std::chrono::duration<double> elapsed = std::chrono::steady_clock::now() - start_time;
   std::printf("Done! Finished in %g seconds.\n", elapsed.count());
+  if (interpolate_color) {
+    result.InterpolateColorFrom(initial_estimate);
+    result.ChangeColorSpace(SPECTRAL_MODE_COLOR_BGR);
+  }
   if (spectral_pca) result = spectral_pca->ReconstructImage(result);
 
   if (evaluate_results) {

@@ -5,7 +5,8 @@
 // and write (a) ENVI float32 BSQ cubes (*.config / *.txt, see
 // hyperspectral/hyperspectral_data_loader.h) and (b) binary PGM / PPM (P5 / P6,
 // 8-bit), normalised to [0, 1] like the reference normalises 8-bit images
-// (image_data.cpp:244-265).  Channels of a PPM are kept in file order (R, G, B).
+// (image_data.cpp:244-265).  A PPM's R, G, B samples become channels 2, 1, 0: ImageData colour images are
+// BGR like OpenCV's (SPECTRAL_MODE_COLOR_BGR), which ChangeColorSpace relies on.
 #pragma once
 #include <dirent.h>
 #include <sys/stat.h>
@@ -63,7 +64,8 @@ inline ImageData LoadPnm(const std::string& path) {
   ImageData image;
   std::vector<double> plane(static_cast<size_t>(w) * h);
   for (int c = 0; c < nc; ++c) {
-    for (size_t i = 0; i < plane.size(); ++i) plane[i] = raw[i * nc + c] / static_cast<double>(maxv);
+    const int fc = nc == 3 ? 2 - c : c;  // channel c = B, G, R <- file sample R, G, B
+    for (size_t i = 0; i < plane.size(); ++i) plane[i] = raw[i * nc + fc] / static_cast<double>(maxv);
     image.AddChannel(plane.data(), cv::Size(w, h));
   }
   return image;
@@ -81,7 +83,7 @@ inline void SavePnm(const ImageData& image, const std::string& path) {
     const double* src = image.GetChannelData(c);
     for (size_t i = 0; i < static_cast<size_t>(w) * h; ++i) {
       const double v = std::min(1.0, std::max(0.0, src[i]));  // saturate like an 8-bit save
-      raw[i * nc + c] = static_cast<unsigned char>(std::lround(v * 255.0));
+      raw[i * nc + (nc == 3 ? 2 - c : c)] = static_cast<unsigned char>(std::lround(v * 255.0));
     }
   }
   out.write(reinterpret_cast<const char*>(raw.data()), static_cast<std::streamsize>(raw.size()));

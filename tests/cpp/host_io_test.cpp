@@ -1,7 +1,8 @@
 // host_io_test.cpp -- the reference's hyperspectral I/O test cases
 // (test/test_hyperspectral_data_loader.cpp:33-110) restated against the drop-in
 // loader (super-resolution_amd/host/hyperspectral), on the reference's own data
-// files (tests/golden/envi).  No GPU needed.  argv[1] = golden directory,
+// files (tests/golden/envi), and the colour-space cases of test/test_image_data.cpp:403-606
+// (ChangeColorSpace, InterpolateColorFrom) on the reference's 4 x 4 x 3 literal.  No GPU needed.  argv[1] = golden directory,
 // argv[2] = scratch directory.
 #include <cmath>
 #include <cstdio>
@@ -134,6 +135,93 @@ static void TestBandShards(const std::string& config) {
   for (int c = 0; c < 2; ++c) EXPECT(ChannelIs(b.GetImage(), c, 8 + c, 2, 0));
 }
 
+// ---- colour path (test_image_data.cpp:15-34 literal, :403-606 cases) ----
+constexpr double kPixelErrorTolerance = 1.0 / 255.0;
+static const double kB[16] = {0.1, 0.2, 0.3, 0.4, 0.15, 0.25, 0.35, 0.45, 0.55, 0.75, 0.85, 0.95, 0.6, 0.65, 0.7, 0.75};
+static const double kG[16] = {0.2, 0.3, 0.4, 0.45, 0.1, 0.2, 0.3, 0.4, 0.75, 0.65, 1.0, 1.0, 0.3, 0.35, 0.4, 0.45};
+static const double kR[16] = {0.0, 0.05, 0.1, 0.1, 0.0, 0.0, 0.05, 0.1, 0.25, 0.1, 0.2, 0.2, 0.0, 0.05, 0.1, 0.15};
+
+static ImageData ColorImage() {
+  ImageData im;
+  im.AddChannel(kB, cv::Size(4, 4));
+  im.AddChannel(kG, cv::Size(4, 4));
+  im.AddChannel(kR, cv::Size(4, 4));
+  return im;
+}
+static bool ChannelNear(const ImageData& a, int ca, const ImageData& b, int cb, double tol) {
+  if (a.GetImageSize() != b.GetImageSize()) return false;
+  for (int i = 0; i < a.GetNumPixels(); ++i)
+    if (std::fabs(a.GetChannelData(ca)[i] - b.GetChannelData(cb)[i]) > tol) return false;
+  return true;
+}
+
+static void TestChangeColorSpace() {
+  ImageData image = ColorImage();
+  EXPECT(image.GetNumChannels() == 3 && image.GetSpectralMode() == SPECTRAL_MODE_COLOR_BGR);
+  image.ChangeColorSpace(SPECTRAL_MODE_COLOR_YCRCB);
+  EXPECT(image.GetNumChannels() == 3 && image.GetSpectralMode() == SPECTRAL_MODE_COLOR_YCRCB);
+  // cvtColor's float BGR -> YCrCb on known colours: pixel 0 = (B .1, G .2, R 0)
+  const double y0 = 0.299 * 0.0 + 0.587 * 0.2 + 0.114 * 0.1;
+  EXPECT(std::fabs(image.GetChannelData(0)[0] - y0) < 1e-6);
+  EXPECT(std::fabs(image.GetChannelData(1)[0] - ((0.0 - y0) * 0.713 + 0.5)) < 1e-6);
+  EXPECT(std::fabs(image.GetChannelData(2)[0] - ((0.1 - y0) * 0.564 + 0.5)) < 1e-6);
+  {  // white and pure red
+    const double w[1] = {1.0}, z[1] = {0.0};
+    ImageData white; white.AddChannel(w, cv::Size(1, 1)); white.AddChannel(w, cv::Size(1, 1)); white.AddChannel(w, cv::Size(1, 1));
+    white.ChangeColorSpace(SPECTRAL_MODE_COLOR_YCRCB);
+    EXPECT(std::fabs(white.GetChannelData(0)[0] - 1.0) < 1e-6 && std::fabs(white.GetChannelData(1)[0] - 0.5) < 1e-6 &&
+           std::fabs(white.GetChannelData(2)[0] - 0.5) < 1e-6);
+    ImageData red; red.AddChannel(z, cv::Size(1, 1)); red.AddChannel(z, cv::Size(1, 1)); red.AddChannel(w, cv::Size(1, 1));
+    red.ChangeColorSpace(SPECTRAL_MODE_COLOR_YCRCB);
+    EXPECT(std::fabs(red.GetChannelData(0)[0] - 0.299) < 1e-6 && std::fabs(red.GetChannelData(1)[0] - 0.999813) < 1e-5 &&
+           std::fabs(red.GetChannelData(2)[0] - 0.331364) < 1e-5);
+  }
+  // image operations still work on the converted image; converting back restores BGR (:449-487)
+  ImageData resized = image;
+  resized.ResizeImage(2, INTERPOLATE_NEAREST);
+  EXPECT(resized.GetImageSize() == cv::Size(8, 8));
+  image.ChangeColorSpace(SPECTRAL_MODE_COLOR_BGR);
+  const ImageData original = ColorImage();
+  for (int c = 0; c < 3; ++c) EXPECT(ChannelNear(image, c, original, c, kPixelErrorTolerance));
+  resized.ChangeColorSpace(SPECTRAL_MODE_COLOR_BGR);
+  ImageData original_resized = ColorImage();
+  original_resized.ResizeImage(2, INTERPOLATE_NEAREST);
+  for (int c = 0; c < 3; ++c) EXPECT(ChannelNear(resized, c, original_resized, c, kPixelErrorTolerance));
+
+  // luminance-only mode (:489-530): one visible channel, chroma hidden and interpolated back
+  ImageData reference_ycrcb = ColorImage();
+  reference_ycrcb.ChangeColorSpace(SPECTRAL_MODE_COLOR_YCRCB);
+  ImageData image_2 = ColorImage();
+  image_2.ChangeColorSpace(SPECTRAL_MODE_COLOR_YCRCB, true);
+  EXPECT(image_2.GetNumChannels() == 1);
+  EXPECT(ChannelNear(image_2, 0, reference_ycrcb, 0, kPixelErrorTolerance));
+  EXPECT(image_2.ToPlanar().size() == 16);  // only the luminance crosses the C ABI
+  image_2.ResizeImage(2, INTERPOLATE_NEAREST);
+  EXPECT(image_2.GetImageSize() == cv::Size(8, 8) && image_2.GetNumChannels() == 1);
+  image_2.ChangeColorSpace(SPECTRAL_MODE_COLOR_BGR);
+  EXPECT(image_2.GetNumChannels() == 3);
+  for (int c = 0; c < 3; ++c) EXPECT(ChannelNear(image_2, c, original_resized, c, 0.15));  // the reference's tolerance
+}
+
+static void TestInterpolateColorFrom() {
+  ImageData reference_color = ColorImage();
+  reference_color.ChangeColorSpace(SPECTRAL_MODE_COLOR_YCRCB);
+  ImageData luminance(reference_color.GetChannelData(0), cv::Size(4, 4));
+  EXPECT(luminance.GetNumChannels() == 1);
+  ImageData luminance_2 = luminance;
+  luminance.InterpolateColorFrom(reference_color);
+  EXPECT(luminance.GetNumChannels() == 3 && luminance.GetSpectralMode() == SPECTRAL_MODE_COLOR_YCRCB);
+  for (int c = 0; c < 3; ++c) EXPECT(ChannelNear(luminance, c, reference_color, c, 1e-12));
+  // resized luminance takes bilinearly resized chroma (:573-605)
+  luminance_2.ResizeImage(2, INTERPOLATE_LINEAR);
+  ImageData reference_resized = reference_color;
+  reference_resized.ResizeImage(2, INTERPOLATE_LINEAR);
+  EXPECT(luminance_2.GetImageSize() != reference_color.GetImageSize());
+  luminance_2.InterpolateColorFrom(reference_color);
+  EXPECT(luminance_2.GetNumChannels() == 3);
+  for (int c = 0; c < 3; ++c) EXPECT(ChannelNear(luminance_2, c, reference_resized, c, 1e-12));
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) { std::printf("usage: host_io_test <golden dir> <scratch dir>\n"); return 2; }
   const std::string golden = argv[1], scratch = argv[2];
@@ -143,6 +231,8 @@ int main(int argc, char** argv) {
   TestLoad(config);
   TestSaveRoundTrip(config, scratch);
   TestBandShards(config);
+  TestChangeColorSpace();
+  TestInterpolateColorFrom();
   std::printf(g_fail ? "HOST IO TESTS FAILED (%d)\n" : "HOST IO TESTS PASSED\n", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -137,3 +137,36 @@ def test_super_resolve_in_pca_space(tmp_path):
     # dropping two of six components loses little on this cube, but something
     err4 = np.sqrt(np.mean((results["pca4"] - results["full"]) ** 2))
     assert 0 < err4 < 0.1
+
+
+def test_interpolate_color_path(tmp_path):
+    """--interpolate_color: the frames go to YCrCb, only the luminance is super-resolved, Cr / Cb are bilinearly
+    interpolated and the result returns to BGR (super_resolution.cpp:330-342, 392-395).  PPM in, PPM out."""
+    import __graft_entry__ as ge
+    ge.build_lib()
+    gen, sr = ge.build_apps()
+    H, W, s, K = 48, 64, 2, 4
+    gt = _ground_truth(3, H, W)
+    gt[1] = np.clip(gt[1] * 0.8 + 0.1, 0, 1)
+    gt[2] = np.clip(1.0 - gt[2], 0, 1)
+    rgb = np.round(np.transpose(gt, (1, 2, 0)) * 255).astype(np.uint8)
+    p = tmp_path / "gt.ppm"
+    with open(p, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (W, H) + rgb.tobytes())
+    motion = tmp_path / "motion.txt"
+    motion.write_text("0 0\n1 1\n0 1\n1 0\n")
+    common = [sr, "--data_path=" + str(p), "--generate_lr_images", "--number_of_frames=%d" % K, "--upsampling_scale=%d" % s,
+              "--blur_radius=3", "--blur_sigma=1.0", "--motion_sequence_path=" + str(motion), "--regularizer=tv",
+              "--regularization_parameter=0.001", "--optimization_iterations=4", "--solver_iterations=30", "--evaluators=psnr"]
+    scores = {}
+    for name, extra in (("all", []), ("luma", ["--interpolate_color"])):
+        q = tmp_path / (name + ".ppm")
+        out = subprocess.run(common + extra + ["--result_path=" + str(q)], capture_output=True, text=True, timeout=600)
+        print(out.stdout, out.stderr)
+        assert out.returncode == 0
+        scores[name] = {l.split(":")[0].strip(): float(l.split(":")[1]) for l in out.stdout.splitlines() if l.startswith("PSNR")}
+        data = open(q, "rb").read()
+        assert data.startswith(b"P6") and len(data) >= H * W * 3
+    assert "only the luminance channel" in out.stdout
+    # solving all three channels is the upper bound; luminance-only must still beat plain bilinear upsampling
+    assert scores["all"]["PSNR score on result"] > scores["luma"]["PSNR score on result"] > scores["luma"]["PSNR score on upsampled"]
