@@ -268,7 +268,10 @@ __global__ __launch_bounds__(256) void k_reg_gradient_direct(
     const T x0 = plane[idx];
     const T wt0 = gcp ? gcp[idx] : T(1);
     const T c0 = gc_scale * wt0;
-    const T r0 = vals[idx];
+    // values == nullptr (TV kinds only): the residual values are recomputed where they are needed -- the
+    // k_reg_values pass and its C*N array round trip disappear (TV is 2-3 differences per value)
+    const bool onfly = values == nullptr;
+    const T r0 = onfly ? reg_value_at(x, W, H, C, c, r, col, kind, range, pw) : vals[idx];
     T grad = T(0);
     if (kind == SRMAP_REG_BTV) {
       T didi = T(0);
@@ -302,17 +305,17 @@ __global__ __launch_bounds__(256) void k_reg_gradient_direct(
       if (col - 1 >= 0) {
         const size_t q = idx - 1;
         const T cq = gc_scale * (gcp ? gcp[q] : T(1));
-        grad += T(2) * cq * vals[q] * sgn(x0 - plane[q]);
+        grad += T(2) * cq * (onfly ? reg_value_at(x, W, H, C, c, r, col - 1, kind, range, pw) : vals[q]) * sgn(x0 - plane[q]);
       }
       if (r - 1 >= 0) {
         const size_t q = idx - W;
         const T cq = gc_scale * (gcp ? gcp[q] : T(1));
-        grad += T(2) * cq * vals[q] * sgn(x0 - plane[q]);
+        grad += T(2) * cq * (onfly ? reg_value_at(x, W, H, C, c, r - 1, col, kind, range, pw) : vals[q]) * sgn(x0 - plane[q]);
       }
       if (kind == SRMAP_REG_TV3D && c > 0) {
         const T xb = plane[idx - N];
         const T cq = gc_scale * (gcp ? gcp[idx - N] : T(1));
-        grad += T(2) * cq * vals[idx - N] * sgn(x0 - xb);
+        grad += T(2) * cq * (onfly ? reg_value_at(x, W, H, C, c - 1, r, col, kind, range, pw) : vals[idx - N]) * sgn(x0 - xb);
       }
     }
     const size_t o = (size_t)c * N + idx;
@@ -326,11 +329,85 @@ __global__ __launch_bounds__(256) void k_reg_gradient_direct(
   }
 }
 
+// TV / 3-D TV in ONE pass (tv_regularizer.cpp:110-227): value, gradient and cost per pixel with the values of
+// the left / upper / previous-channel neighbours recomputed on the spot (2-3 differences each) -- no values
+// array, no integer division (2-D thread index), every load a coalesced row access served by L1/L2.
+// Same expressions, in the same order, as reg_value_at + the TV branch of k_reg_gradient_direct.
+template <typename T, bool D3>
+__global__ __launch_bounds__(256) void k_tv_onepass(const T* __restrict__ x, const T* __restrict__ gc, T gc_scale,
+                                                    T* __restrict__ gout, int accumulate,
+                                                    double* __restrict__ partials, int W, int H, int C, int cr0,
+                                                    int cr1) {
+  __shared__ double red[4];
+  const int col = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.z;
+  const size_t N = (size_t)W * H;
+  double cost = 0.0;
+  if (col < W && r < H) {
+    const T* plane = x + (size_t)c * N;
+    const T* gcp = gc ? gc + (size_t)c * N : nullptr;
+    const size_t idx = (size_t)r * W + col;
+    auto value_at = [&](const T* pl, int cc, int rr, int co) -> T {  // reg_value_at, TV kinds
+      const size_t q = (size_t)rr * W + co;
+      const T v0 = pl[q];
+      const T yv = (rr + 1 < H) ? absval(pl[q + W] - v0) : T(0);
+      const T xv = (co + 1 < W) ? absval(pl[q + 1] - v0) : T(0);
+      T tv = yv + xv;
+      if (D3 && cc + 1 < C) tv += absval(pl[q + N] - v0);
+      return tv;
+    };
+    const T x0 = plane[idx];
+    const T c0 = gc_scale * (gcp ? gcp[idx] : T(1));
+    const T r0 = value_at(plane, c, r, col);
+    T grad = T(0);
+    T didi = T(0);
+    if (col + 1 < W) didi -= sgn(plane[idx + 1] - x0);
+    if (r + 1 < H) didi -= sgn(plane[idx + W] - x0);
+    grad += T(2) * c0 * r0 * didi;  // 3-D TV has no z self term (tv_regularizer.cpp:154-170)
+    if (col - 1 >= 0) {
+      const size_t q = idx - 1;
+      const T cq = gc_scale * (gcp ? gcp[q] : T(1));
+      grad += T(2) * cq * value_at(plane, c, r, col - 1) * sgn(x0 - plane[q]);
+    }
+    if (r - 1 >= 0) {
+      const size_t q = idx - W;
+      const T cq = gc_scale * (gcp ? gcp[q] : T(1));
+      grad += T(2) * cq * value_at(plane, c, r - 1, col) * sgn(x0 - plane[q]);
+    }
+    if (D3 && c > 0) {
+      const T* prev = plane - N;
+      const T cq = gc_scale * (gcp ? gcp[idx - N] : T(1));
+      grad += T(2) * cq * value_at(prev, c - 1, r, col) * sgn(x0 - prev[idx]);
+    }
+    const size_t o = (size_t)c * N + idx;
+    if (gout) gout[o] = (accumulate ? gout[o] : T(0)) + grad;
+    cost = (r >= cr0 && r < cr1) ? (double)c0 * (double)r0 * (double)r0 : 0.0;
+  }
+  if (partials) {  // (64, 4) block: wave = threadIdx.y
+    const double ws = wave_sum(cost);
+    if (threadIdx.x == 0) red[threadIdx.y] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+      partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
 template <typename T>
 int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegSpec& rs,
                                const T* x, const T* gc, double gc_scale, const T* values,
                                T* g, bool accumulate, double* partials, int* nblocks,
                                hipStream_t st) {
+  if (values == nullptr && rs.kind != SRMAP_REG_BTV) {  // TV kinds, one pass
+    dim3 grid2((geo.W + 63) / 64, (geo.H + 3) / 4, geo.C);
+    if (rs.kind == SRMAP_REG_TV3D)
+      hipLaunchKernelGGL((k_tv_onepass<T, true>), grid2, dim3(64, 4), 0, st, x, gc, (T)gc_scale, g, accumulate ? 1 : 0,
+                         partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1);
+    else
+      hipLaunchKernelGGL((k_tv_onepass<T, false>), grid2, dim3(64, 4), 0, st, x, gc, (T)gc_scale, g, accumulate ? 1 : 0,
+                         partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1);
+    if (nblocks) *nblocks = (int)(grid2.x * grid2.y * grid2.z);
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    return SRMAP_OK;
+  }
   dim3 grid((geo.W * geo.H + 255) / 256, geo.C);
   hipLaunchKernelGGL(k_reg_gradient_direct<T>, grid, dim3(256), 0, st, x, gc, (T)gc_scale,
                      values, g, accumulate ? 1 : 0, partials, geo.W, geo.H, geo.C, rs.kind,
@@ -360,20 +437,36 @@ int launch_irls_weights(srmap_problem* p, const T* values, T* weights, size_t n,
   return SRMAP_OK;
 }
 
-// Deterministic final reduction of per-block partials: one 256-thread block,
-// fixed order.  out[0] = sum.
+// Deterministic final reduction of per-block partials, fixed order.  out[0] = sum.
+// Up to kReduceChunk partials: one 256-thread block.  More (multi-channel images: one partial per tile and
+// channel -- cfg5 has half a million): first one block per chunk of kReduceChunk partials into a scratch tail
+// behind the partials, then one block over the chunk sums.  A single block over 73 K partials took 36 us.
+constexpr int kReduceChunk = 4096;
+
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partials,
                                                         int n, double* __restrict__ out) {
   __shared__ double red[4];
+  const int i0 = blockIdx.x * kReduceChunk;
+  const int i1 = (gridDim.x == 1) ? n : (i0 + kReduceChunk < n ? i0 + kReduceChunk : n);
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) v += partials[i];
   const double s = block_sum_256(v, red);
-  if (threadIdx.x == 0) out[0] = s;
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
+int reduce_scratch_slots(size_t n) { return (int)((n + kReduceChunk - 1) / kReduceChunk); }
+
+// `partials` must have room for n + reduce_scratch_slots(n) doubles.
 int launch_reduce_partials(srmap_problem* p, const double* partials, int n, double* out,
                            hipStream_t st) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partials, n, out);
+  if (n <= kReduceChunk) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partials, n, out);
+  } else {
+    const int nb = reduce_scratch_slots((size_t)n);
+    double* scratch = const_cast<double*>(partials) + n;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nb), dim3(256), 0, st, partials, n, scratch);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, (const double*)scratch, nb, out);
+  }
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
 }

@@ -676,12 +676,16 @@ int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
       if (regk && r == pl.reg_index) continue;
       const RegSpec& rs = p->reg[r];
       if (rs.lambda <= 0.0) continue;
-      if (!p->d_regvals) SRMAP_HIP(p->ctx, hipMalloc(&p->d_regvals, p->hr_count() * sizeof(T)));
-      rc = launch_reg_values<T>(p, geo, rs, x, (T*)p->d_regvals, st);
-      if (rc) return rc;
+      // TV / 3-D TV: one pass, values recomputed in the gradient kernel; BTV: values first
+      const bool onfly = rs.kind != SRMAP_REG_BTV;
+      if (!onfly) {
+        if (!p->d_regvals) SRMAP_HIP(p->ctx, hipMalloc(&p->d_regvals, p->hr_count() * sizeof(T)));
+        rc = launch_reg_values<T>(p, geo, rs, x, (T*)p->d_regvals, st);
+        if (rc) return rc;
+      }
       const T* w2 = rs.weights ? (const T*)rs.weights + (size_t)obs_c0 * N : nullptr;
       int nb2 = 0;
-      rc = launch_reg_gradient_direct<T>(p, geo, rs, x, w2, rs.lambda, (const T*)p->d_regvals, g, true,
+      rc = launch_reg_gradient_direct<T>(p, geo, rs, x, w2, rs.lambda, onfly ? nullptr : (const T*)p->d_regvals, g, true,
                                          partials + total, &nb2, st);
       if (rc) return rc;
       total += nb2;

@@ -3,6 +3,7 @@
 // on the host), buffer management, and the dispatch of one cost+gradient
 // evaluation onto the HIP kernels.  No CPU compute path exists here: every
 // numeric entry point launches gfx950 kernels or fails.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -215,8 +216,10 @@ static int ensure_partials(srmap_problem* p, size_t n) {
 static size_t partials_needed(const srmap_problem* p) {
   const Geometry& g = p->geo;
   const size_t fwd = (size_t)((g.w * g.h + 255) / 256) * g.C * g.K;
-  const size_t reg = (size_t)((g.W * g.H + 255) / 256) * g.C * kMaxRegularizers;
-  return fwd + reg + 16;
+  const size_t reg_blocks = std::max((size_t)((g.W * g.H + 255) / 256), (size_t)((g.W + 63) / 64) * ((g.H + 3) / 4));
+  const size_t reg = reg_blocks * g.C * kMaxRegularizers;
+  const size_t n = fwd + reg + 16;
+  return n + (size_t)reduce_scratch_slots(n) + 16;  // + the second-stage scratch of launch_reduce_partials
 }
 
 // One ObjectiveFunction::ComputeAllTerms on device buffers.
@@ -262,14 +265,17 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
         if (!g) {
           // cost only: the gradient kernel still produces the lambda*w*r^2 partials
         }
-        rc = ensure(p, &p->d_regvals, p->hr_count() * sizeof(T));
-        if (rc) return rc;
-        rc = launch_reg_values<T>(p, geo, rs, x, (T*)p->d_regvals, st);
-        if (rc) return rc;
+        const bool onfly = rs.kind != SRMAP_REG_BTV;  // TV kinds: values recomputed in the gradient kernel
+        if (!onfly) {
+          rc = ensure(p, &p->d_regvals, p->hr_count() * sizeof(T));
+          if (rc) return rc;
+          rc = launch_reg_values<T>(p, geo, rs, x, (T*)p->d_regvals, st);
+          if (rc) return rc;
+        }
         int nb = 0;
         const T* wts = rs.weights ? (const T*)rs.weights + (size_t)c0 * N : nullptr;
         rc = launch_reg_gradient_direct<T>(p, geo, rs, x, wts, rs.lambda,
-                                           (const T*)p->d_regvals, g, true,
+                                           onfly ? nullptr : (const T*)p->d_regvals, g, true,
                                            p->d_partials + nparts, &nb, st);
         if (rc) return rc;
         nparts += nb;
