@@ -331,56 +331,97 @@ __global__ __launch_bounds__(256) void k_reg_gradient_direct(
 
 // TV / 3-D TV in ONE pass (tv_regularizer.cpp:110-227): value, gradient and cost per pixel with the values of
 // the left / upper / previous-channel neighbours recomputed on the spot (2-3 differences each) -- no values
-// array, no integer division (2-D thread index), every load a coalesced row access served by L1/L2.
-// Same expressions, in the same order, as reg_value_at + the TV branch of k_reg_gradient_direct.
+// array, no integer division.  A thread owns 4 consecutive pixels of a row (block = 256 columns x 4 rows) and
+// loads the row segments it needs once: rows r-1, r, r+1 of its plane, and for 3-D TV rows of the next and the
+// previous channel.  Same expressions, in the same order, as reg_value_at + the TV branch of
+// k_reg_gradient_direct.
 template <typename T, bool D3>
 __global__ __launch_bounds__(256) void k_tv_onepass(const T* __restrict__ x, const T* __restrict__ gc, T gc_scale,
                                                     T* __restrict__ gout, int accumulate,
                                                     double* __restrict__ partials, int W, int H, int C, int cr0,
                                                     int cr1) {
   __shared__ double red[4];
-  const int col = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.z;
+  constexpr int P = 4;
+  const int c0 = (blockIdx.x * 64 + threadIdx.x) * P, r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.z;
   const size_t N = (size_t)W * H;
   double cost = 0.0;
-  if (col < W && r < H) {
+  if (c0 < W && r < H) {
     const T* plane = x + (size_t)c * N;
     const T* gcp = gc ? gc + (size_t)c * N : nullptr;
-    const size_t idx = (size_t)r * W + col;
-    auto value_at = [&](const T* pl, int cc, int rr, int co) -> T {  // reg_value_at, TV kinds
-      const size_t q = (size_t)rr * W + co;
-      const T v0 = pl[q];
-      const T yv = (rr + 1 < H) ? absval(pl[q + W] - v0) : T(0);
-      const T xv = (co + 1 < W) ? absval(pl[q + 1] - v0) : T(0);
-      T tv = yv + xv;
-      if (D3 && cc + 1 < C) tv += absval(pl[q + N] - v0);
-      return tv;
+    // n values of row rr starting at column cs; positions outside the image read as 0 (never used unmasked)
+    auto row = [&](const T* pl, int rr, int cs, int n, T* dst, T fill) {
+      const bool rin = (unsigned)rr < (unsigned)H;
+      const T* src = pl + (rin ? (size_t)rr * W : (size_t)0);
+#pragma unroll
+      for (int k = 0; k < P + 2; ++k)
+        if (k < n) { const int cc = cs + k; dst[k] = (rin && (unsigned)cc < (unsigned)W) ? src[cc] : fill; }
     };
-    const T x0 = plane[idx];
-    const T c0 = gc_scale * (gcp ? gcp[idx] : T(1));
-    const T r0 = value_at(plane, c, r, col);
-    T grad = T(0);
-    T didi = T(0);
-    if (col + 1 < W) didi -= sgn(plane[idx + 1] - x0);
-    if (r + 1 < H) didi -= sgn(plane[idx + W] - x0);
-    grad += T(2) * c0 * r0 * didi;  // 3-D TV has no z self term (tv_regularizer.cpp:154-170)
-    if (col - 1 >= 0) {
-      const size_t q = idx - 1;
-      const T cq = gc_scale * (gcp ? gcp[q] : T(1));
-      grad += T(2) * cq * value_at(plane, c, r, col - 1) * sgn(x0 - plane[q]);
+    T xc[P + 2], xd[P + 2], xu[P + 2], xn[P + 2], xnu[P + 2], xp[P + 2], xpd[P + 2], wc[P + 2], wu[P + 2], wp[P + 2];
+    row(plane, r, c0 - 1, P + 2, xc, T(0));      // columns c0-1 .. c0+4
+    row(plane, r + 1, c0 - 1, P + 1, xd, T(0));  // c0-1 .. c0+3
+    row(plane, r - 1, c0, P + 1, xu, T(0));      // c0 .. c0+4
+    const bool has_next = D3 && c + 1 < C, has_prev = D3 && c > 0;
+    if (has_next) { row(plane + N, r, c0 - 1, P + 1, xn, T(0)); row(plane + N, r - 1, c0, P, xnu, T(0)); }
+    if (has_prev) { row(plane - N, r, c0, P + 1, xp, T(0)); row(plane - N, r + 1, c0, P, xpd, T(0)); }
+    if (gcp) {
+      row(gcp, r, c0 - 1, P + 1, wc, T(1));
+      row(gcp, r - 1, c0, P, wu, T(1));
+      if (has_prev) row(gcp - N, r, c0, P, wp, T(1));
     }
-    if (r - 1 >= 0) {
-      const size_t q = idx - W;
-      const T cq = gc_scale * (gcp ? gcp[q] : T(1));
-      grad += T(2) * cq * value_at(plane, c, r - 1, col) * sgn(x0 - plane[q]);
+    const bool down = r + 1 < H;
+    T* gdst = gout ? gout + (size_t)c * N + (size_t)r * W + c0 : nullptr;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int col = c0 + i;
+      if (col < W) {
+        const bool right = col + 1 < W;
+        const T x0 = xc[i + 1];
+        const T w0 = gcp ? wc[i + 1] : T(1);
+        const T cc0 = gc_scale * w0;
+        T r0;
+        {
+          const T yv = down ? absval(xd[i + 1] - x0) : T(0);
+          const T xv = right ? absval(xc[i + 2] - x0) : T(0);
+          r0 = yv + xv;
+          if (has_next) r0 += absval(xn[i + 1] - x0);
+        }
+        T grad = T(0);
+        T didi = T(0);
+        if (right) didi -= sgn(xc[i + 2] - x0);
+        if (down) didi -= sgn(xd[i + 1] - x0);
+        grad += T(2) * cc0 * r0 * didi;  // 3-D TV has no z self term (tv_regularizer.cpp:154-170)
+        if (col - 1 >= 0) {
+          const T v0 = xc[i];
+          const T yv = down ? absval(xd[i] - v0) : T(0);
+          const T xv = absval(x0 - v0);  // col - 1 + 1 < W always
+          T rq = yv + xv;
+          if (has_next) rq += absval(xn[i] - v0);
+          const T cq = gc_scale * (gcp ? wc[i] : T(1));
+          grad += T(2) * cq * rq * sgn(x0 - v0);
+        }
+        if (r - 1 >= 0) {
+          const T v0 = xu[i];
+          const T yv = absval(x0 - v0);  // r - 1 + 1 < H always
+          const T xv = right ? absval(xu[i + 1] - v0) : T(0);
+          T rq = yv + xv;
+          if (has_next) rq += absval(xnu[i] - v0);
+          const T cq = gc_scale * (gcp ? wu[i] : T(1));
+          grad += T(2) * cq * rq * sgn(x0 - v0);
+        }
+        if (has_prev) {
+          const T v0 = xp[i];
+          const T yv = down ? absval(xpd[i] - v0) : T(0);
+          const T xv = right ? absval(xp[i + 1] - v0) : T(0);
+          T rq = yv + xv;
+          rq += absval(x0 - v0);  // (c - 1) + 1 < C always
+          const T cq = gc_scale * (gcp ? wp[i] : T(1));
+          grad += T(2) * cq * rq * sgn(x0 - v0);
+        }
+        if (gdst) gdst[i] = (accumulate ? gdst[i] : T(0)) + grad;
+        // lambda * w * r^2  (objective_irls_regularization_term.cpp:45-50)
+        cost += (r >= cr0 && r < cr1) ? (double)cc0 * (double)r0 * (double)r0 : 0.0;
+      }
     }
-    if (D3 && c > 0) {
-      const T* prev = plane - N;
-      const T cq = gc_scale * (gcp ? gcp[idx - N] : T(1));
-      grad += T(2) * cq * value_at(prev, c - 1, r, col) * sgn(x0 - prev[idx]);
-    }
-    const size_t o = (size_t)c * N + idx;
-    if (gout) gout[o] = (accumulate ? gout[o] : T(0)) + grad;
-    cost = (r >= cr0 && r < cr1) ? (double)c0 * (double)r0 * (double)r0 : 0.0;
   }
   if (partials) {  // (64, 4) block: wave = threadIdx.y
     const double ws = wave_sum(cost);
@@ -397,7 +438,7 @@ int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegS
                                T* g, bool accumulate, double* partials, int* nblocks,
                                hipStream_t st) {
   if (values == nullptr && rs.kind != SRMAP_REG_BTV) {  // TV kinds, one pass
-    dim3 grid2((geo.W + 63) / 64, (geo.H + 3) / 4, geo.C);
+    dim3 grid2((geo.W + 255) / 256, (geo.H + 3) / 4, geo.C);
     if (rs.kind == SRMAP_REG_TV3D)
       hipLaunchKernelGGL((k_tv_onepass<T, true>), grid2, dim3(64, 4), 0, st, x, gc, (T)gc_scale, g, accumulate ? 1 : 0,
                          partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1);
