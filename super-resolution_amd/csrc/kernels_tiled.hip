@@ -62,6 +62,7 @@ struct FusedArgs {
   int lrh, lrw;         // LR region extent
   int margin;           // tiles closer than this to the image edge take the border path
   int cr0, cr1;         // HR rows whose cost terms are counted (row-band sharding; default 0, H)
+  int banded;           // tile rows on blockIdx.x, dealt to the 8 XCDs in contiguous bands (see the kernel)
   int terms;            // SRMAP_TERM_* (| ablation bits << 8, profiling only)
   T blur[B * B];        // k * k^T (blur_module.cpp:20-22)
   T lambda;
@@ -110,7 +111,19 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   // profiling aid (bit 0x4000): every workgroup computes tile (4, 4) -- same instruction stream, all loads hit
   // the caches -- but writes its own tile: isolates how much of the time is exposed memory latency/bandwidth
   const bool same_tile = kProf && (A.terms & 0x4000) != 0;
-  const int CI0 = (same_tile ? 4 : blockIdx.y) * C::CH, CJ0 = (same_tile ? 4 : blockIdx.x) * C::CW;
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin in launch order, and each XCD has
+  // its own L2.  With the tile ROW on blockIdx.x and launch index n -> row band (n mod 8), the workgroups
+  // an XCD runs at the same time are vertical neighbours: the 12 halo rows of a 20-row x tile, the LR rows
+  // of the observations and the halo IRLS weights they share are served by that XCD's L2 (cfg2: -4 %).
+  // The map is a bijection for any row count: band b holds rows [b*q + min(b, r), ...), q = rows / 8, r = rows % 8.
+  int tby = blockIdx.y;
+  int tbx = blockIdx.x;
+  if (A.banded) {
+    const int n = blockIdx.x, q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
+    tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
+    tbx = blockIdx.y;
+  }
+  const int CI0 = (same_tile ? 4 : tby) * C::CH, CJ0 = (same_tile ? 4 : tbx) * C::CW;
   const int R0 = CI0 * S, C0 = CJ0 * S;
   const int ch = blockIdx.z;
   const size_t N = (size_t)A.W * A.H;
@@ -312,7 +325,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   // ---------------- write g: one S-element vector per thread, a wave = one row segment ----------------
   if (A.g != nullptr && gr < A.H && gc0 < A.W && !(kProf && (A.terms & 0x2000))) {
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
-    if (same_tile) dst += ((size_t)blockIdx.y - 4) * C::TH * A.W + ((size_t)blockIdx.x - 4) * C::TW;
+    if (same_tile) dst += ((size_t)tby - 4) * C::TH * A.W + ((size_t)tbx - 4) * C::TW;
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pc];
   }
@@ -583,6 +596,8 @@ static int launch_fused(srmap_problem* p, const Geometry& geo, int obs_c0, unsig
     if (REGK == 2) for (int i = 0; i < NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
   }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.h + C::CH - 1) / C::CH, geo.C);
+  A.banded = getenv("SRMAP_TILE_ORDER_NATURAL") ? 0 : 1;  // A/B aid
+  if (A.banded) { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
   A.dbg = nullptr;
   static int tl_calls = 0;
   const bool timeline = kProf && getenv("SRMAP_DEBUG_TIMELINE") != nullptr && ++tl_calls == 30;
