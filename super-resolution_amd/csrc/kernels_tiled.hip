@@ -327,7 +327,7 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
     if (same_tile) dst += ((size_t)tby - 4) * C::TH * A.W + ((size_t)tbx - 4) * C::TW;
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) dst[pc] = acc[pc];
+    for (int pc = 0; pc < S; ++pc) __builtin_nontemporal_store(acc[pc], &dst[pc]);  // written once, not re-read here
   }
 
   SRMAP_STAMP(13);
