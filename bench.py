@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
                     help="ablation only: evaluate a subset of the objective terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--test-single-device", action="store_true",
+                    help="testing aid for 1-GPU boxes: all ranks share GPU 0 and talk over gloo (exercises the N > 1 code "
+                         "paths; the numbers mean nothing)")
     ap.add_argument("--joint-scalars", action="store_true",
                     help="channel sharding only: also all-reduce the scalar cost every step, as ONE joint solve over "
                          "all channels would (srmap_solve_ex hook). Default: the reference's split_channels semantics "
@@ -123,14 +126,17 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.test_single_device else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.test_single_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
     torch.cuda.set_device(local_rank)
@@ -253,7 +259,7 @@ def main():
         out = {
             "metric": "MAP gradient iterations/sec at fixed HR size",
             "value": value,
-            "unit": "MAP gradient iterations/s" if C_total == 1 else "channel-iterations/s (one 16-frame 2048^2 channel per GPU)",
+            "unit": "MAP gradient iterations/s" if C_total == 1 else "channel-iterations/s (one 16-frame %dx%d channel per GPU)" % (W, H),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if (world > 1 and args.shard in ("frames", "rows")) else "weak",
