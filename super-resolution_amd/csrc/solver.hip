@@ -9,6 +9,7 @@
 // rules) runs on the host, in double, in ALGLIB's order of operations so that
 // the trajectory follows the reference's up to reduction order.
 #include <chrono>
+#include <utility>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -131,9 +132,9 @@ struct DeviceCG {
   hipStream_t st;
   size_t n;
   // x, g: current point and gradient; xk/dk: accepted point and direction;
-  // d: normalised direction; wa: line-search base; yk = -g_k (then g_{k+1}-g_k)
+  // d: normalised direction; yk = -g_k (then g_{k+1}-g_k).  The line-search base is xk itself.
   T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr,
-    *yk = nullptr, *wa = nullptr;
+    *yk = nullptr;
   double* part = nullptr;  // [3][kRedBlocks]
   double* scal = nullptr;  // [4] device
   double* hs = nullptr;    // host-mapped pinned scalars (ctx->h_scal): written by k_finish, read after a stream sync
@@ -145,7 +146,7 @@ struct DeviceCG {
   int nb() const { size_t b = (n + 255) / 256; return (int)(b < (size_t)kRedBlocks ? b : kRedBlocks); }
 
   int alloc() {
-    T** v[] = {&x, &g, &xk, &dk, &dn, &d, &yk, &wa};
+    T** v[] = {&x, &g, &xk, &dk, &dn, &d, &yk};
     for (T** q : v) SRMAP_HIP(p->ctx, hipMalloc((void**)q, n * sizeof(T)));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&part, sizeof(double) * 3 * kRedBlocks));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&scal, sizeof(double) * 4));
@@ -155,7 +156,7 @@ struct DeviceCG {
     return SRMAP_OK;
   }
   void release() {
-    T* v[] = {x, g, xk, dk, dn, d, yk, wa};
+    T* v[] = {x, g, xk, dk, dn, d, yk};
     for (T* q : v) if (q) (void)hipFree(q);
     if (part) (void)hipFree(part);
     if (scal) (void)hipFree(scal);
@@ -301,13 +302,14 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
   int infoc = 1;
   *info = 0;
   *nfev = 0;
-  if (*stp <= 0) return SRMAP_OK;
-  if (dginit >= 0) return SRMAP_OK;  // not a descent direction
+  // On entry the base point is cg.xk; cg.x is scratch for the trial points.  The paths that try nothing
+  // still leave x = base, as mcsrch does.
+  if (*stp <= 0) return cg.copy(cg.x, cg.xk);
+  if (dginit >= 0) return cg.copy(cg.x, cg.xk);  // not a descent direction
   bool brackt = false, stage1 = true;
   const double finit = *f, dgtest = ftol * dginit;
   double width = stpmax - stpmin, width1 = width / p5;
-  int rc = cg.copy(cg.wa, cg.x);
-  if (rc) return rc;
+  int rc = SRMAP_OK;
   Bracket b = {0, finit, dginit, 0, finit, dginit};
   double stmin = 0, stmax = 0;
   for (;;) {
@@ -318,7 +320,7 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
     if ((brackt && (*stp <= stmin || *stp >= stmax)) || *nfev >= maxfev - 1 || infoc == 0 ||
         (brackt && stmax - stmin <= xtol * stmax))
       *stp = b.stx;
-    hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.wa,
+    hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
                        (const T*)cg.d, (T)*stp, cg.n);
     double dg = 0;
     rc = cg.evaluate(f, cg.d, &dg);
@@ -395,8 +397,7 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
   for (;;) {
     // yk = -g ; d = normalised dk ; x = xk
     hipLaunchKernelGGL(k_scale_copy<T>, dim3(nbk), dim3(256), 0, st, cg.yk, (const T*)cg.g, T(-1), n);
-    rc = cg.copy(cg.x, cg.xk);
-    if (rc) return rc;
+    // (x = xk is not materialised: the line search writes every trial point x = xk + stp * d itself)
     double stp = 1.0, dginit = 0;
     {
       // linminnormalized: d *= 1/max|d| ; d *= 1/sqrt(d.d).  Under a multi-rank
@@ -467,10 +468,8 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     if (fold - f <= epsf * dmax(std::fabs(fold), dmax(std::fabs(f), 1.0))) { res.type = 1; break; }
     if (lastscaledstep <= epsx) { res.type = 2; break; }
     if (rstimer <= 0) { res.type = 7; break; }
-    rc = cg.copy(cg.xk, cg.x);
-    if (rc) return rc;
-    rc = cg.copy(cg.dk, cg.dn);
-    if (rc) return rc;
+    std::swap(cg.xk, cg.x);    // xk <- accepted point; the old xk becomes trial scratch
+    std::swap(cg.dk, cg.dn);   // dk <- new direction
     fold = f;
   }
   res.f = f;
