@@ -1,5 +1,6 @@
 """Randomised parity sweep: fused (AUTO) path vs the CPU oracle on random geometries, shifts and regulariser
-mixes (f64: 1e-12 relative on the gradient and the cost).  python tools/fuzz_parity.py [cases] [seed]"""
+mixes (f64: 1e-11 relative on the gradient and the cost; f32: 1e-4 / 2e-5).
+   python tools/fuzz_parity.py [cases] [seed] [f64|f32]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +13,8 @@ import srmap
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    f32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
+    tol_g, tol_f = (1e-4, 2e-5) if f32 else (1e-11, 1e-11)
     rng = np.random.default_rng(seed)
     ctx = srmap.Context(0)
     worst = 0.0
@@ -33,7 +36,7 @@ def main():
         model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=b, blur_sigma=sigma)
         lr = rng.random((K, C, h, w))
         ref = orc.Problem(model, lr)
-        p = srmap.Problem(ctx, W, H, C, K, s, shifts, b, sigma, srmap.F64)
+        p = srmap.Problem(ctx, W, H, C, K, s, shifts, b, sigma, srmap.F32 if f32 else srmap.F64)
         p.set_observations(lr)
         for kind, lam, rg, dc in regs:
             i = p.add_regularizer(kind, lam, rg, dc)
@@ -50,7 +53,7 @@ def main():
             p.set_impl(srmap.IMPL_TILED); p.eval(x); tiled += 1
         except srmap.SrmapError:
             pass
-        if eg > 1e-11 or ef > 1e-11:
+        if eg > tol_g or ef > tol_f:
             print("MISMATCH case", it, dict(s=s, W=W, H=H, C=C, K=K, shifts=shifts, b=b, regs=regs), eg, ef)
             sys.exit(1)
     print("fuzz ok: %d cases (%d on the fused path), worst relative error %.2e" % (cases, tiled, worst))
