@@ -305,7 +305,10 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
   if (want_reg) {
     const T* wplane = A.w ? A.w + (size_t)ch * N : nullptr;
     const int xrow = A.hu + wv, xcell = A.hlc + lane;
-    if (border)
+    // pass 1 looks right / down only: tap masks are needed by tiles at the right or bottom image edge alone
+    constexpr int WIN1 = (REGK == 2) ? R : 1;
+    const bool reg_border = (R0 + C::TH + WIN1 > A.H) || (C0 + C::TW + WIN1 > A.W);
+    if (reg_border)
       reg_pass1<T, S, REGK, R, NP, true>(acc, cost_reg, xs, cr, wreg, xrow, xcell, wv + RU, lane + 1, gr, gc0, A.W,
                                          A.H, A.lambda, A.powtab, gr >= A.cr0 && gr < A.cr1);
     else
