@@ -280,14 +280,19 @@ __global__ __launch_bounds__((TileCfg<T, S>::NT), (sizeof(T) == 4 ? 6 : 4)) void
             const int k = k0 + kk;
             const int toy = A.frames[k].toy, tox = A.frames[k].tox;
             if ((unsigned)(gr + toy) >= (unsigned)A.H) continue;  // p' row outside the image (uniform)
-            unsigned cmask = 0;
-#pragma unroll
-            for (int pc = 0; pc < S; ++pc) cmask |= ((unsigned)(gc0 + pc + tox) < (unsigned)A.W ? 1u : 0u) << pc;
             const T* gw = gwr + k * 4 * S;
             T wcv[2 * S];
 #pragma unroll
             for (int i = 0; i < 2 * S; ++i) wcv[i] = gw[2 * S - 2 * pr + i];
-            gather_frame<T, S, true>(acc, rs_row + kk * (C::GRH * C::GRW), gw[0], gw[1], wcv, cmask);
+            // column masks only when this frame's shift moves some pixel of the tile out of the image (uniform)
+            if (C0 + tox >= 0 && C0 + C::TW - 1 + tox < A.W) {
+              gather_frame<T, S, false>(acc, rs_row + kk * (C::GRH * C::GRW), gw[0], gw[1], wcv, 0xffffffffu);
+            } else {
+              unsigned cmask = 0;
+#pragma unroll
+              for (int pc = 0; pc < S; ++pc) cmask |= ((unsigned)(gc0 + pc + tox) < (unsigned)A.W ? 1u : 0u) << pc;
+              gather_frame<T, S, true>(acc, rs_row + kk * (C::GRH * C::GRW), gw[0], gw[1], wcv, cmask);
+            }
           }
         }
       }
