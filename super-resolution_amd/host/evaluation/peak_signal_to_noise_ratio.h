@@ -13,7 +13,7 @@ class PeakSignalToNoiseRatioEvaluator {
   double Evaluate(const ImageData& image) const {
     const int num_pixels = image.GetNumPixels(), num_channels = image.GetNumChannels();
     if (num_channels != ground_truth_.GetNumChannels() || image.GetImageSize() != ground_truth_.GetImageSize())
-      srmap_host::Check(SRMAP_EINVAL, "Images must have the same size and number of channels to be compared.");
+      srmap_host::Fail("Images must have the same size and number of channels to be compared.");
     double ssd = 0.0;
     for (int c = 0; c < num_channels; ++c) {
       const double* a = ground_truth_.GetChannelData(c);

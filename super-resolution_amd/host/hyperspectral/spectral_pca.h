@@ -37,7 +37,7 @@ class SpectralPCA {
   }
   SpectralPCA(const std::vector<ImageData>& hyperspectral_images, const double retained_variance) {
     Train(hyperspectral_images);
-    if (!(retained_variance > 0 && retained_variance <= 1)) srmap_host::Check(SRMAP_EINVAL, "retained variance must be in (0, 1]");
+    if (!(retained_variance > 0 && retained_variance <= 1)) srmap_host::Fail("retained variance must be in (0, 1]");
     const double total = std::accumulate(eigenvalues_.begin(), eigenvalues_.end(), 0.0);
     int L = 0;
     double cumulative = 0.0;
@@ -50,12 +50,12 @@ class SpectralPCA {
 
   ImageData GetPCAImage(const ImageData& image_data) const {
     if (image_data.GetNumChannels() != num_spectral_bands_)
-      srmap_host::Check(SRMAP_EINVAL, "The input image does not have the correct number of channels.");
+      srmap_host::Fail("The input image does not have the correct number of channels.");
     return Map(image_data, basis_, num_pca_bands_, num_spectral_bands_, mean_.data(), nullptr);
   }
   ImageData ReconstructImage(const ImageData& pca_image_data) const {
     if (pca_image_data.GetNumChannels() != num_pca_bands_)
-      srmap_host::Check(SRMAP_EINVAL, "The input image does not have the correct number of channels.");
+      srmap_host::Fail("The input image does not have the correct number of channels.");
     std::vector<double> bt(static_cast<size_t>(num_spectral_bands_) * num_pca_bands_);
     for (int k = 0; k < num_pca_bands_; ++k)
       for (int c = 0; c < num_spectral_bands_; ++c) bt[static_cast<size_t>(c) * num_pca_bands_ + k] = basis_[static_cast<size_t>(k) * num_spectral_bands_ + c];
@@ -84,20 +84,20 @@ class SpectralPCA {
 
   // spectral_pca.cpp:30-88 (sampling) + cv::PCA (mean, covariance / n, eigen, descending)
   void Train(const std::vector<ImageData>& images) {
-    if (images.empty()) srmap_host::Check(SRMAP_EINVAL, "At least one image is required to compute the PCA basis.");
+    if (images.empty()) srmap_host::Fail("At least one image is required to compute the PCA basis.");
     const int C = images[0].GetNumChannels();
-    if (C <= 0) srmap_host::Check(SRMAP_EINVAL, "Cannot compute PCA on empty images.");
+    if (C <= 0) srmap_host::Fail("Cannot compute PCA on empty images.");
     const int num_images = static_cast<int>(images.size());
     const int num_pixels = images[0].GetNumPixels();
     int per_image = (C * 10) / num_images;
     if (per_image > num_pixels) per_image = num_pixels;
-    if (per_image <= 0) srmap_host::Check(SRMAP_EINVAL, "Too many images for the PCA sampling rule.");
+    if (per_image <= 0) srmap_host::Fail("Too many images for the PCA sampling rule.");
     const int skip = num_pixels / per_image;
     const int ns = num_images * per_image;
     std::vector<double> data(static_cast<size_t>(ns) * C);
     for (int im = 0; im < num_images; ++im) {
       if (images[im].GetNumChannels() != C)
-        srmap_host::Check(SRMAP_EINVAL, "Inconsistent number of channels between the given images. Cannot perform PCA.");
+        srmap_host::Fail("Inconsistent number of channels between the given images. Cannot perform PCA.");
       for (int c = 0; c < C; ++c) {
         const double* src = images[im].GetChannelData(c);
         for (int smp = 0; smp < per_image; ++smp) data[(static_cast<size_t>(im) * per_image + smp) * C + c] = src[smp * skip];

@@ -34,13 +34,13 @@ class ImageData {
   // pixel_values: planar [C][H][W], copied.
   ImageData(const double* pixel_values, const cv::Size& size, const int num_channels = 1)
       : image_size_(size) {
-    if (!pixel_values || size.area() <= 0 || num_channels <= 0) srmap_host::Check(SRMAP_EINVAL, "ImageData");
+    if (!pixel_values || size.area() <= 0 || num_channels <= 0) srmap_host::Fail("ImageData");
     const size_t n = static_cast<size_t>(size.area());
     for (int c = 0; c < num_channels; ++c) channels_.emplace_back(pixel_values + c * n, pixel_values + (c + 1) * n);
     spectral_mode_ = DefaultSpectralMode(num_channels);
   }
   void AddChannel(const double* pixel_values, const cv::Size& size) {
-    if (!channels_.empty() && size != image_size_) srmap_host::Check(SRMAP_EINVAL, "AddChannel: size mismatch");
+    if (!channels_.empty() && size != image_size_) srmap_host::Fail("AddChannel: size mismatch");
     image_size_ = size;
     channels_.emplace_back(pixel_values, pixel_values + size.area());
     spectral_mode_ = DefaultSpectralMode(static_cast<int>(channels_.size()));  // image_data.cpp:298-308
@@ -65,15 +65,15 @@ class ImageData {
   // taps to the image (replicated border).  OpenCV is absent here: parity unpinned, used only for the
   // initial estimate and the "upsampled" baseline of the CLI.
   void ResizeImage(const double scale_factor, const ResizeInterpolationMethod method = INTERPOLATE_LINEAR) {
-    if (channels_.empty() || !(scale_factor > 0)) srmap_host::Check(SRMAP_EINVAL, "ResizeImage");
+    if (channels_.empty() || !(scale_factor > 0)) srmap_host::Fail("ResizeImage");
     ResizeImage(cv::Size(static_cast<int>(image_size_.width * scale_factor), static_cast<int>(image_size_.height * scale_factor)),
                 method);
   }
   void ResizeImage(const cv::Size& new_size, const ResizeInterpolationMethod method = INTERPOLATE_LINEAR) {
-    if (channels_.empty()) srmap_host::Check(SRMAP_EINVAL, "Cannot resize an empty image.");
+    if (channels_.empty()) srmap_host::Fail("Cannot resize an empty image.");
     const int ow = image_size_.width, oh = image_size_.height;
     const int nw = new_size.width, nh = new_size.height;
-    if (nw <= 0 || nh <= 0) srmap_host::Check(SRMAP_EINVAL, "ResizeImage: images must have a positive size");
+    if (nw <= 0 || nh <= 0) srmap_host::Fail("ResizeImage: images must have a positive size");
     // hidden chroma planes (luminance-only mode) keep their size until the colour is interpolated back
     if (GetNumChannels() < static_cast<int>(channels_.size()) && chroma_size_.area() == 0) chroma_size_ = image_size_;
     const double inv_fx = static_cast<double>(ow) / nw, inv_fy = static_cast<double>(oh) / nh;
@@ -141,10 +141,10 @@ class ImageData {
   void ChangeColorSpace(const ImageSpectralMode new_color_mode, const bool luminance_only = false) {
     const auto is_color = [](ImageSpectralMode m) { return m == SPECTRAL_MODE_COLOR_BGR || m == SPECTRAL_MODE_COLOR_YCRCB; };
     if (!is_color(spectral_mode_))
-      srmap_host::Check(SRMAP_EINVAL, "Cannot convert non-color (monochrome or hyperspectral) images to a different color space.");
-    if (!is_color(new_color_mode)) srmap_host::Check(SRMAP_EINVAL, "Invalid color space. new_color_mode must be SPECTRAL_MODE_COLOR_*.");
+      srmap_host::Fail("Cannot convert non-color (monochrome or hyperspectral) images to a different color space.");
+    if (!is_color(new_color_mode)) srmap_host::Fail("Invalid color space. new_color_mode must be SPECTRAL_MODE_COLOR_*.");
     if (new_color_mode == spectral_mode_) return;  // already there (the reference warns and returns)
-    if (channels_.size() != 3) srmap_host::Check(SRMAP_EINVAL, "colour images have three channels");
+    if (channels_.size() != 3) srmap_host::Fail("colour images have three channels");
     if (new_color_mode == SPECTRAL_MODE_COLOR_YCRCB) {
       luminance_channel_only_ = luminance_only;
       const size_t n = channels_[0].size();
@@ -173,8 +173,8 @@ class ImageData {
   // InterpolateColorFrom (image_data.cpp:450-463): this single-channel (luminance) image takes the two
   // chroma channels of `color_image`, bilinearly resized to this image's size when the sizes differ.
   void InterpolateColorFrom(const ImageData& color_image) {
-    if (GetNumChannels() != 1) srmap_host::Check(SRMAP_EINVAL, "Color can only be interpolated for single-channel images.");
-    if (color_image.channels_.size() != 3) srmap_host::Check(SRMAP_EINVAL, "The given image must have color information for interpolation.");
+    if (GetNumChannels() != 1) srmap_host::Fail("Color can only be interpolated for single-channel images.");
+    if (color_image.channels_.size() != 3) srmap_host::Fail("The given image must have color information for interpolation.");
     channels_.resize(3);
     InterpolateColor(color_image.channels_, color_image.ChromaSize(), &channels_, image_size_);
     spectral_mode_ = color_image.spectral_mode_;

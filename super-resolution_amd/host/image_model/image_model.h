@@ -23,7 +23,7 @@ namespace super_resolution {
 namespace srmap_host {
 // Runs srmap_apply / srmap_apply_transpose for one chain on an ImageData.
 inline void RunChain(const ChainParams& c, ImageData* image, int index, bool transpose) {
-  if (!image) Check(SRMAP_EINVAL, "CHECK_NOTNULL(image_data)");
+  if (!image) Fail("CHECK_NOTNULL(image_data)");
   const cv::Size in = image->GetImageSize();
   const int C = image->GetNumChannels();
   const std::vector<double> src = image->ToPlanar();
@@ -76,7 +76,7 @@ class BlurModule : public DegradationOperator {
   // blur_radius is the (odd) kernel size, sigma > 0 (blur_module.cpp:13-23).
   BlurModule(const int blur_radius, const double sigma) : blur_radius_(blur_radius), sigma_(sigma) {
     if (blur_radius < 1 || !(sigma > 0.0) || blur_radius % 2 != 1)
-      srmap_host::Check(SRMAP_EINVAL, "BlurModule: radius must be odd and >= 1, sigma > 0");
+      srmap_host::Fail("BlurModule: radius must be odd and >= 1, sigma > 0");
   }
   void ApplyToImage(ImageData* image_data, const int index) const override {
     srmap_host::RunChain(Chain(), image_data, 0, false);
@@ -95,7 +95,7 @@ class BlurModule : public DegradationOperator {
 class DownsamplingModule : public DegradationOperator {
  public:
   explicit DownsamplingModule(const int scale) : scale_(scale) {
-    if (scale < 1) srmap_host::Check(SRMAP_EINVAL, "DownsamplingModule: scale must be >= 1");
+    if (scale < 1) srmap_host::Fail("DownsamplingModule: scale must be >= 1");
   }
   void ApplyToImage(ImageData* image_data, const int index) const override {
     srmap_host::RunChain(Chain(), image_data, 0, false);
@@ -122,7 +122,7 @@ struct ImageModelParameters {
 class ImageModel {
  public:
   explicit ImageModel(const int downsampling_scale) : downsampling_scale_(downsampling_scale) {
-    if (downsampling_scale < 1) srmap_host::Check(SRMAP_EINVAL, "Downsampling scale must be at least 1");
+    if (downsampling_scale < 1) srmap_host::Fail("Downsampling scale must be at least 1");
   }
   // image_model.cpp:17-61
   static ImageModel CreateImageModel(const ImageModelParameters& parameters) {
@@ -136,7 +136,7 @@ class ImageModel {
       model.AddDegradationOperator(std::make_shared<BlurModule>(parameters.blur_radius, parameters.blur_sigma));
     model.AddDegradationOperator(std::make_shared<DownsamplingModule>(parameters.scale));
     if (parameters.noise_sigma > 0.0)
-      srmap_host::Check(SRMAP_EUNSUPPORTED, "AdditiveNoiseModule (cv::randn) is data generation, outside the gradient path");
+      srmap_host::Fail("AdditiveNoiseModule (cv::randn) is data generation, outside the gradient path");
     return model;
   }
   void AddDegradationOperator(std::shared_ptr<DegradationOperator> op) { operators_.push_back(op); }
@@ -149,13 +149,15 @@ class ImageModel {
   // [Motion][Blur]Downsampling runs as ONE fused device pass.
   void ApplyToImage(ImageData* image_data, const int index) const {
     srmap_host::ChainParams chain;
-    if (Canonical(&chain)) { srmap_host::RunChain(chain, image_data, index, false); return; }
+    // Blur and downsampling ignore the index (blur_module.cpp:25-28, downsampling_module.cpp:19-27): without a
+    // MotionModule the fused problem has ONE frame, whatever index the caller passes
+    if (Canonical(&chain)) { srmap_host::RunChain(chain, image_data, chain.shifts_xy.empty() ? 0 : index, false); return; }
     for (const auto& op : operators_) op->ApplyToImage(image_data, index);
   }
   // image_model.cpp:93-101: transposes in reverse order.
   void ApplyTransposeToImage(ImageData* image_data, const int index) const {
     srmap_host::ChainParams chain;
-    if (Canonical(&chain)) { srmap_host::RunChain(chain, image_data, index, true); return; }
+    if (Canonical(&chain)) { srmap_host::RunChain(chain, image_data, chain.shifts_xy.empty() ? 0 : index, true); return; }
     for (int i = static_cast<int>(operators_.size()) - 1; i >= 0; --i) operators_[i]->ApplyTransposeToImage(image_data, index);
   }
   int GetDownsamplingScale() const { return downsampling_scale_; }

@@ -22,14 +22,14 @@ class MotionShiftSequence {
   void SetMotionSequence(const std::vector<MotionShift>& shifts) { shifts_ = shifts; }
   void LoadSequenceFromFile(const std::string& path) {
     std::ifstream fin(path);
-    if (!fin.is_open()) srmap_host::Check(SRMAP_EINVAL, ("Could not open file " + path).c_str());
+    if (!fin.is_open()) srmap_host::Fail(("Could not open file " + path).c_str());
     shifts_.clear();
     double dx, dy;
     while (fin >> dx >> dy) shifts_.push_back(MotionShift(dx, dy));
   }
   int GetNumMotionShifts() const { return static_cast<int>(shifts_.size()); }
   const MotionShift& GetMotionShift(const int index) const {
-    if (index < 0 || index >= GetNumMotionShifts()) srmap_host::Check(SRMAP_EINVAL, "motion shift index out of range");
+    if (index < 0 || index >= GetNumMotionShifts()) srmap_host::Fail("motion shift index out of range");
     return shifts_[index];
   }
   const MotionShift& operator[](const int index) const { return GetMotionShift(index); }

@@ -80,10 +80,10 @@ class MapSolver : public Solver {
   MapSolver(const ImageModel& image_model, const std::vector<ImageData>& low_res_images,
             const bool print_solver_output = true)
       : Solver(image_model, print_solver_output) {
-    if (low_res_images.empty()) srmap_host::Check(SRMAP_EINVAL, "Cannot super-resolve with 0 low-res images.");
+    if (low_res_images.empty()) srmap_host::Fail("Cannot super-resolve with 0 low-res images.");
     num_channels_ = low_res_images[0].GetNumChannels();
     for (const ImageData& im : low_res_images)
-      if (im.GetNumChannels() != num_channels_) srmap_host::Check(SRMAP_EINVAL, "Image channel counts do not match up.");
+      if (im.GetNumChannels() != num_channels_) srmap_host::Fail("Image channel counts do not match up.");
     const int s = image_model_.GetDownsamplingScale();
     const cv::Size lr = low_res_images[0].GetImageSize();
     image_size_ = cv::Size(lr.width * s, lr.height * s);
@@ -91,15 +91,15 @@ class MapSolver : public Solver {
     // them NN-upsampled, map_solver.cpp:80-85; algebraically identical).
     srmap_host::ChainParams chain;
     if (!image_model_.Canonical(&chain))
-      srmap_host::Check(SRMAP_EUNSUPPORTED, "MapSolver needs the [Motion][Blur]Downsampling operator chain");
+      srmap_host::Fail("MapSolver needs the [Motion][Blur]Downsampling operator chain");
     chain.frames = static_cast<int>(low_res_images.size());
     if (!chain.shifts_xy.empty() && chain.shifts_xy.size() / 2 < low_res_images.size())
-      srmap_host::Check(SRMAP_EINVAL, "fewer motion shifts than observations");
+      srmap_host::Fail("fewer motion shifts than observations");
     if (!chain.shifts_xy.empty()) chain.shifts_xy.resize(2 * low_res_images.size());
     problem_ = srmap_host::MakeProblem(chain, image_size_.width, image_size_.height, num_channels_);
     std::vector<double> stack;
     for (const ImageData& im : low_res_images) {
-      if (im.GetImageSize() != lr) srmap_host::Check(SRMAP_EINVAL, "observation sizes differ");
+      if (im.GetImageSize() != lr) srmap_host::Fail("observation sizes differ");
       const std::vector<double> planar = im.ToPlanar();
       stack.insert(stack.end(), planar.begin(), planar.end());
     }
@@ -120,7 +120,7 @@ class MapSolver : public Solver {
   int GetNumImages() const { return num_images_; }
   int GetNumDataPoints() const {
     const long n = static_cast<long>(GetNumPixels()) * GetNumChannels();
-    if (n > std::numeric_limits<int>::max()) srmap_host::Check(SRMAP_EINVAL, "Number of data points exceeds maximum size.");
+    if (n > std::numeric_limits<int>::max()) srmap_host::Fail("Number of data points exceeds maximum size.");
     return static_cast<int>(n);
   }
   double GetRegularizationParameterSum() const {
@@ -157,7 +157,7 @@ class IRLSMapSolver : public MapSolver {
   ImageData Solve(const ImageData& initial_estimate) override {
     if (initial_estimate.GetNumPixels() != GetNumPixels() || initial_estimate.GetNumChannels() != GetNumChannels() ||
         initial_estimate.GetImageSize() != GetImageSize())
-      srmap_host::Check(SRMAP_EINVAL, "initial estimate does not match the HR geometry");
+      srmap_host::Fail("initial estimate does not match the HR geometry");
     srmap_irls_options o;
     srmap_irls_options_default(&o);
     o.max_num_solver_iterations = solver_options_.max_num_solver_iterations;
@@ -168,7 +168,7 @@ class IRLSMapSolver : public MapSolver {
     o.max_num_irls_iterations = solver_options_.max_num_irls_iterations;
     o.irls_cost_difference_threshold = solver_options_.irls_cost_difference_threshold;
     if (solver_options_.least_squares_solver != CG_SOLVER || solver_options_.use_numerical_differentiation)
-      srmap_host::Check(SRMAP_EUNSUPPORTED, "only CG with analytical differentiation is provided");
+      srmap_host::Fail("only CG with analytical differentiation is provided");
     const std::vector<double> x0 = initial_estimate.ToPlanar();
     std::vector<double> x(x0.size());
     srmap_host::Check(srmap_solve(problem_.get(), &o, x0.data(), x.data(), &report_), "srmap_solve");

@@ -24,7 +24,7 @@ class Regularizer {
 
  protected:
   std::vector<double> Values(const double* x, int num_channels) const {
-    if (!x) srmap_host::Check(SRMAP_EINVAL, "CHECK_NOTNULL(image_data)");
+    if (!x) srmap_host::Fail("CHECK_NOTNULL(image_data)");
     srmap_host::ProblemPtr p = Make(num_channels);
     std::vector<double> v(static_cast<size_t>(image_size_.area()) * num_channels);
     srmap_host::Check(srmap_reg_values(p.get(), 0, x, v.data()), "srmap_reg_values");
@@ -32,9 +32,9 @@ class Regularizer {
   }
   std::pair<std::vector<double>, std::vector<double>> ValuesAndGradient(
       const double* x, const std::vector<double>& gc, int num_channels) const {
-    if (!x) srmap_host::Check(SRMAP_EINVAL, "CHECK_NOTNULL(image_data)");
+    if (!x) srmap_host::Fail("CHECK_NOTNULL(image_data)");
     const size_t n = static_cast<size_t>(image_size_.area()) * num_channels;
-    if (gc.size() < n) srmap_host::Check(SRMAP_EINVAL, "gradient_constants too short");
+    if (gc.size() < n) srmap_host::Fail("gradient_constants too short");
     srmap_host::ProblemPtr p = Make(num_channels);
     std::vector<double> v(n), g(n);
     srmap_host::Check(srmap_reg_values_and_gradient(p.get(), 0, x, gc.data(), v.data(), g.data()),
@@ -78,8 +78,8 @@ class BilateralTotalVariationRegularizer : public Regularizer {
  public:
   BilateralTotalVariationRegularizer(const cv::Size& image_size, const int scale_range, const double spatial_decay)
       : Regularizer(image_size), scale_range_(scale_range), spatial_decay_(spatial_decay) {
-    if (scale_range < 1) srmap_host::Check(SRMAP_EINVAL, "Range must be at least 1 (1 pixel in each direction).");
-    if (!(0 < spatial_decay && spatial_decay <= 1)) srmap_host::Check(SRMAP_EINVAL, "Spatial decay must be between 0 and 1, (0, 1].");
+    if (scale_range < 1) srmap_host::Fail("Range must be at least 1 (1 pixel in each direction).");
+    if (!(0 < spatial_decay && spatial_decay <= 1)) srmap_host::Fail("Spatial decay must be between 0 and 1, (0, 1].");
   }
   std::vector<double> ApplyToImage(const double* image_data, const int num_channels) const override {
     return Values(image_data, num_channels);

@@ -26,7 +26,14 @@ inline srmap_ctx* Context() {
   return ctx;
 }
 
-// CHECK-style: abort with the library's message.
+// CHECK-style failure of a HOST-side precondition (bad size, null image, channel mismatch): print the given
+// message and abort.  Does not touch the GPU context, so argument errors read the same on a box without a device.
+[[noreturn]] inline void Fail(const char* what) {
+  std::fprintf(stderr, "Check failed: %s\n", what);
+  std::abort();
+}
+
+// CHECK-style on the status of a LIBRARY call: abort with the library's message.
 inline void Check(int status, const char* what) {
   if (status == SRMAP_OK) return;
   std::fprintf(stderr, "Check failed: %s: %s (srmap status %d)\n", what, srmap_last_error(Context()), status);

@@ -170,3 +170,27 @@ def test_interpolate_color_path(tmp_path):
     assert "only the luminance channel" in out.stdout
     # solving all three channels is the upper bound; luminance-only must still beat plain bilinear upsampling
     assert scores["all"]["PSNR score on result"] > scores["luma"]["PSNR score on result"] > scores["luma"]["PSNR score on upsampled"]
+
+
+def test_generate_without_motion_file(tmp_path):
+    """generate_data with the reference CLI defaults (several frames, NO motion file): blur and downsampling ignore
+    the frame index (blur_module.cpp:25-28, downsampling_module.cpp:19-27), so every frame is the same image."""
+    import __graft_entry__ as ge
+    ge.build_lib()
+    gen, _ = ge.build_apps()
+    C, H, W, s, K = 1, 24, 32, 2, 4
+    gt = _ground_truth(C, H, W)
+    gt_cfg = _write_envi(str(tmp_path / "gt"), gt)
+    lr_dir = tmp_path / "lr"
+    lr_dir.mkdir()
+    out = subprocess.run([gen, "--input_image=" + gt_cfg, "--output_image_dir=" + str(lr_dir),
+                          "--blur_radius=3", "--blur_sigma=1.0", "--downsampling_scale=%d" % s,
+                          "--number_of_frames=%d" % K], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0
+    frames = np.stack([_read_envi(str(lr_dir / ("low_res_%d" % i)), (C, H // s, W // s)) for i in range(K)])
+    import srmap
+    prob = srmap.Problem(srmap.Context(0), W, H, C, 1, s, None, 3, 1.0, srmap.F64)
+    ref = prob.apply(gt.astype(np.float32).astype(np.float64), 0)
+    for k in range(K):
+        assert np.allclose(frames[k], ref, atol=2e-7)
