@@ -1,0 +1,872 @@
+// kernels_ztile.hip -- the hot path: one MAP gradient iteration
+// (ObjectiveFunction::ComputeAllTerms, objective_function.cpp:5-20) as ONE
+// LDS-tiled launch + a thin exact border launch, for the common geometry:
+// integer motion shifts, HR = LR * S, S in {2,3,4}, blur size B in {1,3}, first
+// regulariser 2-D TV or BTV with range <= 3.  Everything else is evaluated by
+// kernels_direct.hip.
+//
+// Formulation.  With integer shifts the warp M_k and the
+// blur B are shift-invariant, so AWAY FROM THE IMAGE BORDER they commute and the
+// data term (objective_data_term.cpp:15-116, image_model.cpp:86-101) collapses
+// onto the HR grid:
+//     r_k(i,j) = (B x)(p) - y_k(i,j),   p = (S i + oy_k, S j + ox_k)   ("z position")
+//     z(p)     = sum over the frames k whose LR grid hits p of r_k
+//     g_data   = 2 S^2 * B^T z,         cost_data = S^2 * sum r_k^2
+// i.e. every residual is evaluated ONCE, by the thread that owns HR pixel p
+// ("owner computes"), from a full-resolution blur of x at its own pixels; the
+// K per-frame transposes become one blur of z.  Per HR pixel this is 9 + 9 FMAs
+// and K/S^2 observation loads instead of K gathers.  The reference clips every
+// stage to the H x W domain separately (SURVEY.md section 8a'), which the
+// commuted form does not reproduce within D = max|shift| + 2*floor(B/2) pixels of
+// the border: the tiled kernel therefore counts cost and data gradient only for
+// the CORE (pixels at distance >= D), and k_ring evaluates the border frame --
+// gradient of the ring pixels and cost of every residual whose z position is
+// outside the core -- with the reference's literal per-frame formulas.
+//
+// Tile kernel k_eval_z: a workgroup of 8 waves owns 8 HR rows x 64*S columns;
+// wave = HR row, lane = LR cell, a thread owns the S consecutive pixels of its
+// cell.  x tile (+halo) in LDS in polyphase layout xs[row][col mod S][cell]
+// (unit stride across lanes for every window read, offsets are immediates).
+//   phase 1  B x at S+2 pixels (own + one neighbour each side), residuals of
+//            the matching frames (host-built table per (row phase, col phase)),
+//            horizontal half of B^T in registers -> zh to LDS; regulariser
+//            pass 1 (values, self term, 2*lambda*w*r -> LDS); halo rows of zh /
+//            2*lambda*w*r by whole waves, the left halo columns by one wave;
+//   phase 2  vertical half of B^T from zh; regulariser pass 2; g store.
+// No MFMA: stencil path.  Cost partials are reduced in fixed order
+// (deterministic).
+#include "tiled_device.hpp"
+
+namespace srmap {
+
+namespace {
+
+constexpr int zmax(int a, int b) { return a > b ? a : b; }
+constexpr int zceil(int a, int b) { return (a + b - 1) / b; }
+
+template <typename T, int S, int B, int REGK, int R>
+struct ZCfg {
+  static constexpr int NW = 8;                 // waves = HR rows per tile
+  static constexpr int NT = 64 * NW;
+  static constexpr int TH = NW;
+  static constexpr int CW = 64;                // LR cells per tile row = lanes
+  static constexpr int TW = CW * S;
+  static constexpr int HB = (B - 1) / 2;
+  static constexpr int WIN = REGK == 2 ? R : (REGK == 1 ? 1 : 0);      // pass 1 reaches WIN pixels right / down
+  static constexpr int RU = REGK == 2 ? R - 1 : (REGK == 1 ? 1 : 0);   // pass 2 reaches RU pixels up / left
+  static constexpr int HU = zmax(RU, 2 * HB);  // x halo rows above / below the tile
+  static constexpr int HD = zmax(WIN, 2 * HB);
+  static constexpr int XCL = zceil(zmax(RU, 2 * HB), S);   // x halo cells left / right
+  static constexpr int XCR = zceil(zmax(WIN, 2 * HB), S);
+  static constexpr int XC = CW + XCL + XCR;
+  static constexpr int XR = TH + HU + HD;
+  static constexpr int XROW = S * XC;
+  static constexpr int XS_ELEMS = XR * XROW;
+  static constexpr int NV = S + 2 * HB;        // pixels a thread evaluates B x / z at: own S + HB each side
+  static constexpr int ZR = (B > 1) ? TH + 2 * HB : 0;     // zh rows -HB .. TH-1+HB (own columns only)
+  static constexpr int ZROW = S * CW;
+  static constexpr int ZS_ELEMS = ZR * ZROW;
+  static constexpr int CCL = RU > 0 ? zceil(RU, S) : 0;    // 2*lambda*w*r: halo cells on the left
+  static constexpr int CC = CW + CCL;
+  static constexpr int CROW = S * CC;
+  static constexpr int CRR = REGK ? TH + RU : 0;
+  static constexpr int CS_ELEMS = CRR * CROW;
+  static constexpr int NP = REGK == 2 ? 2 * R + 1 : 1;
+};
+
+struct ZEntry { int k, io, jo, pad; };  // frame, LR row / column offset of the residual a pixel of this phase owns
+
+template <typename T, int B, int NP>
+struct ZArgs {
+  const T* x;
+  const T* y;
+  const T* w;        // IRLS weights or nullptr
+  T* g;              // nullptr = cost only
+  double* partials;
+  const int2* hdr;   // [S*S] (count, first entry) per (row phase, column phase)
+  const ZEntry* ent;
+  int W, H, wl, hl;
+  int obs_C, obs_c0;
+  int D;             // core margin
+  int cr0, cr1;      // HR rows whose cost terms are counted (row-band sharding; default 0, H)
+  int banded;        // tile rows on blockIdx.x, dealt to the 8 XCDs in contiguous bands
+  int terms;         // SRMAP_TERM_*
+  T blur[B * B];     // k * k^T (blur_module.cpp:20-22)
+  T k1[B];           // the separable factor (B^T z is evaluated as two 1-D passes)
+  T lambda;
+  T powtab[NP];      // BTV alpha^(i+j)
+};
+
+// ---- index helpers: `col` is a pixel column relative to the first pixel of the thread's cell ----
+template <typename C>
+__device__ __forceinline__ constexpr int xi(int row, int col) {
+  return row * C::XROW + posmod(col, C::TW / C::CW) * C::XC + C::XCL + floordiv(col, C::TW / C::CW);
+}
+template <typename C>
+__device__ __forceinline__ constexpr int ci(int row, int col) {
+  return row * C::CROW + posmod(col, C::TW / C::CW) * C::CC + C::CCL + floordiv(col, C::TW / C::CW);
+}
+
+// Observation of LR pixel (i, j) of frame plane yk, address clamped into the image.
+template <typename T>
+__device__ __forceinline__ T obs_at(const T* __restrict__ yk, int i, int j, int hl, int wl) {
+  const int ic = i < 0 ? 0 : (i >= hl ? hl - 1 : i);
+  const int jc = j < 0 ? 0 : (j >= wl ? wl - 1 : j);
+  return yk[(size_t)ic * wl + jc];
+}
+
+// ---- data term, phase 1, for the S pixels of one cell in tile row `rowrel` (wave-uniform) ----
+// B x at NV pixels, residuals of the frames whose LR grid hits each pixel, z; returns z (B == 1) or writes the
+// horizontal half of B^T z to LDS (B == 3).  COUNT: the row is owned by this tile (cost is counted, with mk).
+template <typename T, int S, int B, typename C, typename ArgsT>
+__device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ zs, int rowrel,
+                                      int R0, int cellg, int lane, const T* __restrict__ ybase, bool use_pre,
+                                      const T (&ypre)[C::NV], bool count, const T (&mk)[S], T (&zout)[S],
+                                      double& cost) {
+  constexpr int HB = C::HB, NV = C::NV;
+  const int gr = R0 + rowrel;
+  // row phase and LR cell row of this HR row (floor division; gr may be negative in the top halo)
+  const int rc = (gr >= 0) ? gr / S : -((-gr + S - 1) / S);
+  const int pr = gr - rc * S;
+  const int xrow = rowrel + C::HU;
+  T bx[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) bx[v] = T(0);
+#pragma unroll
+  for (int a = 0; a < B; ++a) {
+    T xr[NV + B - 1];
+#pragma unroll
+    for (int j = 0; j < NV + B - 1; ++j) xr[j] = xs[xi<C>(xrow + a - HB, j - 2 * HB) + lane];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int e = 0; e < B; ++e) bx[v] += A.blur[a * B + e] * xr[v + e];
+    }
+  }
+  T z[NV];
+  const size_t nl = (size_t)A.wl * A.hl;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+    const bool own = pcv >= 0 && pcv < S;
+    const int2 h = A.hdr[pr * S + pc];  // scalar load: (count, first entry)
+    T za = T(0);
+    for (int t = 0; t < h.x; ++t) {
+      const ZEntry e = A.ent[h.y + t];
+      const int i = rc + e.io, j = cellg + dc + e.jo;
+      T yv;
+      if (t == 0 && use_pre) yv = ypre[v];
+      else yv = obs_at<T>(ybase + (size_t)e.k * A.obs_C * nl, i, j, A.hl, A.wl);
+      const T rr = bx[v] - yv;
+      za += rr;
+      if (own && count && S * i >= A.cr0 && S * i < A.cr1) {  // uniform
+        const double rd = (double)(rr * mk[own ? pcv : 0]);
+        cost += rd * (double)rr;
+      }
+    }
+    z[v] = za;
+  }
+  if (B == 1) {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) zout[pc] = z[pc];
+  } else {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      T zh = T(0);
+#pragma unroll
+      for (int e = 0; e < B; ++e) zh += A.k1[e] * z[pc + e];
+      zs[(rowrel + HB) * C::ZROW + pc * C::CW + lane] = zh;
+    }
+  }
+}
+
+// t = 0 observations of the NV pixels of the thread's cell in tile row `rowrel`, issued at kernel start.
+template <typename T, int S, int B, typename C, typename ArgsT>
+__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cellg,
+                                               const T* __restrict__ ybase, T (&ypre)[C::NV]) {
+  constexpr int HB = C::HB, NV = C::NV;
+  const int gr = R0 + rowrel;
+  const int rc = (gr >= 0) ? gr / S : -((-gr + S - 1) / S);
+  const int pr = gr - rc * S;
+  const size_t nl = (size_t)A.wl * A.hl;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+    const int2 h = A.hdr[pr * S + pc];
+    ypre[v] = T(0);
+    if (h.x > 0) {  // uniform
+      const ZEntry e = A.ent[h.y];
+      ypre[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * nl, rc + e.io, cellg + dc + e.jo, A.hl, A.wl);
+    }
+  }
+}
+
+// ---- regulariser pass 1 for the S pixels of one cell (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
+// FULL: values, self term into acc, cost, 2*lambda*w*r into cs (own rows).  !FULL: 2*lambda*w*r only (halo rows).
+// Stores 0 for pixels outside the image and, BTV only, for the absolute pixel (0,0) (btv_regularizer.cpp:143-146).
+template <typename T, int S, int REGK, int R, typename C, bool BORDER, bool FULL>
+__device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __restrict__ xs, T* __restrict__ cs,
+                                        const T (&wv)[S], int rowrel, int lane, int gr, int gc0, int W, int H,
+                                        T lambda, const T (&pw)[C::NP], bool cost_row) {
+  constexpr int WIN = C::WIN;
+  constexpr int NC = S + WIN;
+  const int xrow = rowrel + C::HU;
+  T x0v[S], rv[S], dv[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); }
+  // the window is walked row by row (i outer, j inner per pixel: the reference's summation order)
+#pragma unroll
+  for (int i = 0; i <= WIN; ++i) {
+    T row[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) row[j] = xs[xi<C>(xrow + i, j) + lane];
+    if (i == 0) {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) x0v[pc] = row[pc];
+    }
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      if (REGK == 2) {
+#pragma unroll
+        for (int j = 0; j <= R; ++j) {
+          if (i == 0 && j == 0) continue;  // |x0 - x0| = 0 and sgn(0) = 0
+          T d = x0v[pc] - row[pc + j];
+          if (BORDER) d = ((gr + i < H) && (gc0 + pc + j < W)) ? d : T(0);  // skipped tap == zero difference
+          rv[pc] += pw[i + j] * absv(d);
+          if (FULL && i < R && j < R) dv[pc] += sgn_scaled<T>(d, pw[i + j]);  // exclusive window in the gradient
+        }
+      } else if (i == 1) {
+        T dyv = row[pc] - x0v[pc];
+        if (BORDER) dyv = (gr + 1 < H) ? dyv : T(0);
+        rv[pc] = absv(dyv) + rv[pc];
+        if (FULL) dv[pc] = dv[pc] - sgnv(dyv);
+      } else {
+        T dxv = row[pc + 1] - x0v[pc];
+        if (BORDER) dxv = (gc0 + pc + 1 < W) ? dxv : T(0);
+        rv[pc] = absv(dxv);
+        if (FULL) dv[pc] = -sgnv(dxv);
+      }
+    }
+  }
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) {
+    const T r = rv[pc];
+    const T c = lambda * wv[pc];
+    T cr2 = T(2) * c * r;
+    const bool in_img = (unsigned)gr < (unsigned)H && (unsigned)(gc0 + pc) < (unsigned)W;
+    if (FULL) {
+      acc[pc] += cr2 * dv[pc];
+      const double cd = (in_img && cost_row) ? (double)c * (double)r * (double)r : 0.0;
+      cost += cd;
+    }
+    if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
+    cs[ci<C>(rowrel + C::RU, pc) + lane] = cr2;
+  }
+}
+
+// 2*lambda*w*r of ONE pixel at tile-relative (rowrel (per lane), col (compile time, < 0)): the left halo columns.
+// xs / cs arrive already offset by the lane's row (rowrel * XROW / rowrel * CROW): every index below is an immediate.
+template <typename T, int S, int REGK, int R, typename C, int COL>
+__device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __restrict__ cs, const T* __restrict__ wplane,
+                                             int rowrel, int R0, int C0, int W, int H, T lambda,
+                                             const T (&pw)[C::NP]) {
+  constexpr int WIN = C::WIN;
+  const int gr = R0 + rowrel, gc = C0 + COL;
+  constexpr int xrow = C::HU;
+  T cr2 = T(0);
+  if (gr >= 0 && gr < H && gc >= 0 && gc < W && !(REGK == 2 && gr == 0 && gc == 0)) {
+    const T wt = wplane ? wplane[(size_t)gr * W + gc] : T(1);
+    const T x0 = xs[xi<C>(xrow, COL)];
+    T r = T(0);
+    if (REGK == 2) {
+#pragma unroll
+      for (int i = 0; i <= WIN; ++i) {
+#pragma unroll
+        for (int j = 0; j <= WIN; ++j) {
+          if (i == 0 && j == 0) continue;
+          const T v = xs[xi<C>(xrow + i, COL + j)];
+          const T d = (gr + i < H && gc + j < W) ? x0 - v : T(0);
+          r += pw[i + j] * absv(d);
+        }
+      }
+    } else {
+      const T yv = (gr + 1 < H) ? absv(xs[xi<C>(xrow + 1, COL)] - x0) : T(0);
+      const T xv = (gc + 1 < W) ? absv(xs[xi<C>(xrow, COL + 1)] - x0) : T(0);
+      r = yv + xv;
+    }
+    cr2 = T(2) * (lambda * wt) * r;
+  }
+  cs[ci<C>(C::RU, COL)] = cr2;
+}
+
+// ---- regulariser pass 2: contributions of the up / left neighbours (tv_regularizer.cpp:172-203,
+// btv_regularizer.cpp:137-162) ----
+template <typename T, int S, int REGK, int R, typename C>
+__device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs, const T* __restrict__ cs, int rowrel,
+                                           int lane, const T (&pw)[C::NP]) {
+  constexpr int RU = C::RU;
+  if (RU == 0) return;
+  constexpr int NC = S + RU;
+  const int xrow = rowrel + C::HU, crow = rowrel + RU;
+  T x0v[S], sum[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) sum[pc] = T(0);
+#pragma unroll
+  for (int i = 0; i <= RU; ++i) {  // neighbour row r - i
+    T xw[NC], cw[NC];              // columns -RU .. S-1
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      xw[j] = xs[xi<C>(xrow - i, j - RU) + lane];
+      cw[j] = cs[ci<C>(crow - i, j - RU) + lane];
+    }
+    if (i == 0) {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) x0v[pc] = xw[pc + RU];
+    }
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      if (REGK == 2) {
+        if (i < R) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            if (i == 0 && j == 0) continue;
+            // -sgn(x[q] - x[p]) * alpha^(i+j) * 2 c[q] r[q],  q = p - (i, j)
+            sum[pc] += cw[pc + RU - j] * sgn_scaled<T>(x0v[pc] - xw[pc + RU - j], pw[i + j]);
+          }
+        }
+      } else {
+        if (i == 0) sum[pc] += cw[pc + RU - 1] * sgnv(x0v[pc] - xw[pc + RU - 1]);
+        else sum[pc] += cw[pc + RU] * sgnv(x0v[pc] - xw[pc + RU]);
+      }
+    }
+  }
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) acc[pc] += sum[pc];
+}
+
+template <typename T, int S, int B, int REGK, int R>
+__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_z(
+    ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
+  using C = ZCfg<T, S, B, REGK, R>;
+  constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
+  __shared__ T xs[C::XS_ELEMS];
+  __shared__ T zs[C::ZS_ELEMS > 0 ? C::ZS_ELEMS : 1];
+  __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
+  __shared__ double red[2][C::NW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = HR row of the tile (SGPR)
+  // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin in launch order and every XCD has its
+  // own L2; with the tile ROW on blockIdx.x and launch index n -> row band (n mod 8) the workgroups an XCD runs at
+  // the same time are vertical neighbours and share their x halo rows in that L2.  Bijective for any row count.
+  int tby = blockIdx.y, tbx = blockIdx.x;
+  if (A.banded) {
+    const int n = blockIdx.x, q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
+    tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
+    tbx = blockIdx.y;
+  }
+  const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;
+  const int ch = blockIdx.z;
+  const size_t N = (size_t)A.W * A.H;
+  const size_t nl = (size_t)A.wl * A.hl;
+  const T* xplane = A.x + (size_t)ch * N;
+  const int gr = R0 + wv;          // global HR row of this thread
+  const int gc0 = C0 + S * lane;   // first global HR column of this thread
+  const int cellg = CJ0 + lane;
+  const bool want_data = (A.terms & SRMAP_TERM_DATA) != 0;
+  const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0;
+  const T* ybase = A.y + (size_t)(ch + A.obs_c0) * nl;
+
+  // ---------------- global loads whose addresses are known now: x tile, observations, IRLS weights ----------------
+  constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // x rows per wave
+  constexpr int EXTRA = C::XC - C::CW;              // halo cells, staged by the first lanes
+  T va[ARI][S], vb[ARI][S];
+#pragma unroll
+  for (int it = 0; it < ARI; ++it) {
+    const int row = wv + it * C::NW;
+    const int grr = R0 - C::HU + row;
+    const bool row_in = row < C::XR && (unsigned)grr < (unsigned)A.H;  // uniform
+    const int gca = CJ0 - C::XCL + lane, gcb = gca + C::CW;
+    const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
+    const bool inb = row_in && lane < EXTRA && (unsigned)gcb < (unsigned)A.wl;
+    const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
+    const T* sb = xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) { va[it][pc] = ina ? va[it][pc] : T(0); vb[it][pc] = inb ? vb[it][pc] : T(0); }
+  }
+  T ypre[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) ypre[v] = T(0);
+  if (want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, cellg, ybase, ypre);
+  const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
+  T wreg[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
+  if (wplane != nullptr && gr < A.H && gc0 < A.W) {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)gr * A.W + gc0 + pc];
+  }
+  // halo row of 2*lambda*w*r this wave evaluates (waves 2 .. 2+RU-1: tile rows -1 .. -RU) and its weights
+  const bool reg_halo_on = want_reg && A.g != nullptr && RU > 0;
+  const int hrow = -(wv - 1);  // wave 2 -> -1, wave 3 -> -2
+  const bool has_reg_halo = reg_halo_on && wv >= 2 && wv < 2 + RU;
+  T whalo[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) whalo[pc] = T(1);
+  if (has_reg_halo && wplane != nullptr && R0 + hrow >= 0 && gc0 < A.W) {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) whalo[pc] = wplane[(size_t)(R0 + hrow) * A.W + gc0 + pc];
+  }
+
+  // ---------------- x tile -> LDS, polyphase ----------------
+#pragma unroll
+  for (int it = 0; it < ARI; ++it) {
+    const int row = wv + it * C::NW;
+    if (row < C::XR) {  // uniform
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + lane] = va[it][pc];
+      if (lane < EXTRA) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + lane] = vb[it][pc];
+      }
+    }
+  }
+  __syncthreads();
+
+  // core mask of this thread's pixels: the tile kernel counts data cost / gradient only at distance >= D from
+  // the image border (k_ring evaluates the rest exactly)
+  T mk[S];
+  {
+    const bool row_core = (unsigned)(gr - A.D) < (unsigned)(A.H - 2 * A.D);
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc)
+      mk[pc] = (row_core && (unsigned)(gc0 + pc - A.D) < (unsigned)(A.W - 2 * A.D)) ? T(1) : T(0);
+  }
+
+  T acc[S], zown[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) { acc[j] = T(0); zown[j] = T(0); }
+  double cost_data = 0.0, cost_reg = 0.0;
+
+  // ---------------- phase 1: data term ----------------
+  if (want_data) {
+    z_row<T, S, B, C>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
+    if (B > 1 && A.g != nullptr && wv < 2) {  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
+      T dummy[S];
+      double dc = 0.0;
+      z_row<T, S, B, C>(A, xs, zs, wv == 0 ? -HB : C::TH - 1 + HB, R0, cellg, lane, ybase, false, ypre, false, mk,
+                        dummy, dc);
+    }
+  }
+  // ---------------- phase 1: regulariser ----------------
+  if (want_reg) {
+    const bool reg_border = (R0 + C::TH + C::WIN > A.H) || (C0 + C::TW + C::WIN > A.W);
+    const bool cost_row = gr >= A.cr0 && gr < A.cr1;
+    if (reg_border)
+      reg_row<T, S, REGK, R, C, true, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, cost_row);
+    else
+      reg_row<T, S, REGK, R, C, false, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, cost_row);
+    if (has_reg_halo) {
+      T dacc[S];
+      double dc = 0.0;
+      // the rows above a tile are never at the bottom edge; the right-edge masks follow the tile's
+      if (C0 + C::TW + C::WIN > A.W)
+        reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, false);
+      else
+        reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, false);
+    }
+    if (reg_halo_on && wv == C::NW - 1 && lane < C::TH + RU) {  // left halo columns -1 .. -RU, one row per lane
+      const int rowrel = lane - RU;
+      const int lo = rowrel * C::XROW, lc = rowrel * C::CROW;  // per-lane row offsets
+      if (RU >= 1) reg_halo_col<T, S, REGK, R, C, -1>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+      if (RU >= 2) reg_halo_col<T, S, REGK, R, C, -2>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2 ----------------
+  if (want_data && A.g != nullptr) {
+    const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      T zz;
+      if (B == 1) {
+        zz = zown[pc];
+      } else {
+        zz = T(0);
+#pragma unroll
+        for (int a = 0; a < B; ++a) zz += A.k1[a] * zs[(wv + a) * C::ZROW + pc * C::CW + lane];  // rows wv-HB+a
+      }
+      acc[pc] += (sc * mk[pc]) * zz;
+    }
+  }
+  if (want_reg && A.g != nullptr) reg_pass2z<T, S, REGK, R, C>(acc, xs, cs, wv, lane, A.powtab);
+
+  if (A.g != nullptr && gr < A.H && gc0 < A.W) {
+    T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) __builtin_nontemporal_store(acc[pc], &dst[pc]);  // written once, not re-read here
+  }
+
+  // ---------------- cost partial of this workgroup ----------------
+  {
+    const double sd = wave_sum_d(cost_data);
+    const double sr = wave_sum_d(cost_reg);
+    if (lane == 0) { red[0][wv] = sd; red[1][wv] = sr; }
+    __syncthreads();
+    if (tid == 0) {
+      double d = 0.0, r = 0.0;
+#pragma unroll
+      for (int i = 0; i < C::NW; ++i) { d += red[0][i]; r += red[1][i]; }
+      const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      A.partials[b] = (double)(S * S) * d + r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ring: the border frame, with the reference's literal per-frame formulas (SURVEY.md section 8a').
+// One thread per pixel q of the EXTENDED ring: [-E, H+E) x [-E, W+E) minus the core [D, H-D) x [D, W-D), where
+// E = max |shift| (z positions of LR pixels can lie outside the image).
+//   (1) q inside the image: g[q] += 2 S^2 sum_k M_k^T B^T D^T r_k at q  (image_model.cpp:93-101, gather form);
+//   (2) cost: every LR pixel (k, i, j) whose z position (S i + oy_k, S j + ox_k) equals q  (each residual has
+//       exactly one z position, so tile kernel + ring count every residual once).
+struct RingFrame { int ox, oy; };  // forward source offset: warped(r, c) = x(r + oy, c + ox)
+
+template <typename T>
+struct RingArgs {
+  const T* x;
+  const T* y;
+  T* g;
+  double* partials;
+  const RingFrame* frames;
+  const T* blur;    // [b*b]
+  const T* blur_t;  // [b*b]
+  int W, H, wl, hl, K, S, b, hb;
+  int obs_C, obs_c0;
+  int D, E;
+  int cr0, cr1;
+  int band_rows;    // D + E
+  int mid_rows;     // H - 2 D
+  long long n_ring; // pixels of the extended ring
+};
+
+// r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
+template <typename T>
+__device__ __forceinline__ T ring_residual(const RingArgs<T>& A, const T* __restrict__ xplane,
+                                           const T* __restrict__ yk, int ox, int oy, int i, int j) {
+  T acc = T(0);
+  for (int a = 0; a < A.b; ++a) {
+    const int rr = A.S * i + a - A.hb;
+    if (rr < 0 || rr >= A.H) continue;  // filter2D BORDER_CONSTANT on the warped image
+    const int sr = rr + oy;
+    if (sr < 0 || sr >= A.H) continue;  // warpAffine BORDER_CONSTANT
+    for (int e = 0; e < A.b; ++e) {
+      const int cc = A.S * j + e - A.hb;
+      if (cc < 0 || cc >= A.W) continue;
+      const int sc = cc + ox;
+      if (sc < 0 || sc >= A.W) continue;
+      acc += A.blur[a * A.b + e] * xplane[(size_t)sr * A.W + sc];
+    }
+  }
+  return acc - yk[(size_t)i * A.wl + j];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_ring(RingArgs<T> A) {
+  __shared__ double red[4];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int ch = blockIdx.y;
+  const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
+  double cost = 0.0;
+  if (t < A.n_ring) {
+    // decode: top band, bottom band (band_rows x We each), then the left / right strips of the middle rows
+    const int We = A.W + 2 * A.E;
+    const long long band = (long long)A.band_rows * We;
+    int qr, qc;
+    if (t < band) { qr = -A.E + (int)(t / We); qc = -A.E + (int)(t % We); }
+    else if (t < 2 * band) { const long long u = t - band; qr = A.H - A.D + (int)(u / We); qc = -A.E + (int)(u % We); }
+    else {
+      const long long u = t - 2 * band;
+      const int per = 2 * A.band_rows;
+      qr = A.D + (int)(u / per);
+      const int m = (int)(u % per);
+      qc = m < A.band_rows ? -A.E + m : A.W - A.D + (m - A.band_rows);
+    }
+    const T* xplane = A.x + (size_t)ch * N;
+    const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
+    T gsum = T(0);
+    for (int k = 0; k < A.K; ++k) {
+      const int ox = A.frames[k].ox, oy = A.frames[k].oy;
+      const T* yk = A.y + ((size_t)k * A.obs_C + ch + A.obs_c0) * nl;
+      // (2) the residual whose z position is q
+      {
+        const int ri = qr - oy, rj = qc - ox;
+        if (ri >= 0 && rj >= 0 && ri % A.S == 0 && rj % A.S == 0) {
+          const int i = ri / A.S, j = rj / A.S;
+          if (i < A.hl && j < A.wl && A.S * i >= A.cr0 && A.S * i < A.cr1) {
+            const double r = (double)ring_residual<T>(A, xplane, yk, ox, oy, i, j);
+            cost += r * r;
+          }
+        }
+      }
+      // (1) transpose at q: t_k(q) = [v_k(q - o_k)], v_k = B^T (zero-inserted r_k), every stage clipped
+      if (inside && A.g != nullptr) {
+        const int vr = qr - oy, vc = qc - ox;
+        if (vr >= 0 && vr < A.H && vc >= 0 && vc < A.W) {
+          T v = T(0);
+          for (int a = 0; a < A.b; ++a) {
+            const int Rr = vr + a - A.hb;
+            if (Rr < 0 || Rr >= A.H || (Rr % A.S) != 0) continue;
+            const int i = Rr / A.S;
+            if (i >= A.hl) continue;
+            for (int e = 0; e < A.b; ++e) {
+              const int Cc = vc + e - A.hb;
+              if (Cc < 0 || Cc >= A.W || (Cc % A.S) != 0) continue;
+              const int j = Cc / A.S;
+              if (j >= A.wl) continue;
+              v += A.blur_t[a * A.b + e] * ring_residual<T>(A, xplane, yk, ox, oy, i, j);
+            }
+          }
+          gsum += v;
+        }
+      }
+    }
+    if (inside && A.g != nullptr) {
+      T* gp = A.g + (size_t)ch * N + (size_t)qr * A.W + qc;
+      *gp += (T)(2 * A.S * A.S) * gsum;
+    }
+  }
+  // block partial (s^2 * sum of squares)
+  {
+    double v = cost;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      A.partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (double)(A.S * A.S) * ((red[0] + red[1]) + (red[2] + red[3]));
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// host side: plan (per problem, owned by the problem) and launch
+struct ZPlan {
+  int S = 0, B = 1;
+  int regk = 0, regr = 0, reg_index = -1;
+  int D = 0, E = 0;
+  int2* d_hdr = nullptr;
+  ZEntry* d_ent = nullptr;
+  RingFrame* d_frames = nullptr;
+};
+
+void ztile_release(srmap_problem* p) {
+  ZPlan* z = static_cast<ZPlan*>(p->zplan);
+  if (!z) return;
+  if (z->d_hdr) (void)hipFree(z->d_hdr);
+  if (z->d_ent) (void)hipFree(z->d_ent);
+  if (z->d_frames) (void)hipFree(z->d_frames);
+  delete z;
+  p->zplan = nullptr;
+}
+
+// Decide whether k_eval_z covers the problem; build the frame table.
+bool ztile_plan(srmap_problem* p) {
+  ztile_release(p);
+  const Geometry& g = p->geo;
+  const int S = g.s, B = g.b, K = g.K;
+  if (!p->maps_regular) return false;
+  if (S < 2 || S > 4) return false;
+  if (B != 1 && B != 3) return false;
+  std::vector<int> ox(K, 0), oy(K, 0);
+  int amax = 0;
+  if (p->has_motion) {
+    for (int k = 0; k < K; ++k) {
+      const WarpTaps<double>& f = p->fwd_warps[k];
+      const WarpTaps<double>& b = p->bwd_warps[k];
+      if (f.ntaps != 1 || b.ntaps != 1) return false;          // integer shifts only
+      if (b.ox != -f.ox || b.oy != -f.oy) return false;
+      ox[k] = f.ox; oy[k] = f.oy;
+      amax = std::max(amax, std::max(std::abs(f.ox), std::abs(f.oy)));
+    }
+  }
+  if (amax > 4096) return false;
+  ZPlan* z = new ZPlan();
+  z->S = S; z->B = B;
+  z->E = amax;
+  z->D = amax + 2 * g.hb;
+  // the core must exist and the ring must stay a small part of the work
+  if (g.W <= 2 * z->D + 2 * S || g.H <= 2 * z->D + 2 * S) { delete z; return false; }
+  // the one regulariser handled in-kernel (first TV / BTV with lambda > 0)
+  for (int r = 0; r < p->nreg && z->regk == 0; ++r) {
+    const RegSpec& rs = p->reg[r];
+    if (rs.lambda <= 0) continue;
+    if (rs.kind == SRMAP_REG_TV) { z->regk = 1; z->reg_index = r; }
+    else if (rs.kind == SRMAP_REG_BTV && rs.range >= 1 && rs.range <= 3) { z->regk = 2; z->regr = rs.range; z->reg_index = r; }
+    break;  // only the first active regulariser may be fused (order of accumulation)
+  }
+  // frame table: pixel (row phase pr, column phase pc) owns the residual of frame k iff (pr - oy) and (pc - ox)
+  // are multiples of S; the LR pixel is (rc + io, cell + jo)
+  std::vector<int2> hdr((size_t)S * S);
+  std::vector<ZEntry> ent;
+  for (int pr = 0; pr < S; ++pr)
+    for (int pc = 0; pc < S; ++pc) {
+      int2 h; h.x = 0; h.y = (int)ent.size();
+      for (int k = 0; k < K; ++k) {
+        if (pmod(pr - oy[k], S) != 0 || pmod(pc - ox[k], S) != 0) continue;
+        ZEntry e; e.k = k; e.io = fdiv(pr - oy[k], S); e.jo = fdiv(pc - ox[k], S); e.pad = 0;
+        ent.push_back(e);
+        h.x++;
+      }
+      hdr[(size_t)pr * S + pc] = h;
+    }
+  if (ent.empty()) { ZEntry e = {0, 0, 0, 0}; ent.push_back(e); }
+  std::vector<RingFrame> fr(K);
+  for (int k = 0; k < K; ++k) { fr[k].ox = ox[k]; fr[k].oy = oy[k]; }
+  bool ok = hipMalloc((void**)&z->d_hdr, sizeof(int2) * hdr.size()) == hipSuccess &&
+            hipMemcpy(z->d_hdr, hdr.data(), sizeof(int2) * hdr.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void**)&z->d_ent, sizeof(ZEntry) * ent.size()) == hipSuccess &&
+            hipMemcpy(z->d_ent, ent.data(), sizeof(ZEntry) * ent.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void**)&z->d_frames, sizeof(RingFrame) * fr.size()) == hipSuccess &&
+            hipMemcpy(z->d_frames, fr.data(), sizeof(RingFrame) * fr.size(), hipMemcpyHostToDevice) == hipSuccess;
+  p->zplan = z;
+  if (!ok) { ztile_release(p); return false; }
+  return true;
+}
+
+size_t ztile_partials_needed(const srmap_problem* p) {
+  const Geometry& g = p->geo;
+  const size_t tiles = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * g.C;
+  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
+  size_t ring = 0;
+  if (z) {
+    const long long We = g.W + 2 * z->E, band = z->D + z->E;
+    const long long n = 2 * band * We + 2 * band * (long long)std::max(0, g.H - 2 * z->D);
+    ring = (size_t)((n + 255) / 256) * g.C;
+  }
+  return tiles + ring;
+}
+
+template <typename T, int S, int B, int REGK, int R>
+static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
+                    const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st) {
+  using C = ZCfg<T, S, B, REGK, R>;
+  ZArgs<T, B, C::NP> A;
+  A.x = x; A.y = (const T*)p->d_obs; A.w = wts; A.g = g; A.partials = partials;
+  A.hdr = z.d_hdr; A.ent = z.d_ent;
+  A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
+  A.obs_C = p->geo.C; A.obs_c0 = obs_c0;
+  A.D = z.D;
+  A.cr0 = geo.cr0; A.cr1 = geo.cr1;
+  A.terms = (int)terms;
+  for (int i = 0; i < B * B; ++i) A.blur[i] = (T)p->blur2d[i];
+  for (int i = 0; i < B; ++i) A.k1[i] = (T)p->blur1d[i];
+  A.lambda = T(0);
+  for (int i = 0; i < C::NP; ++i) A.powtab[i] = T(1);
+  if (REGK != 0) {
+    const RegSpec& rs = p->reg[z.reg_index];
+    A.lambda = (T)rs.lambda;
+    if (REGK == 2) for (int i = 0; i < C::NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
+  }
+  dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
+  A.banded = 1;
+  { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
+  hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A);
+  *nblocks = (int)(grid.x * grid.y * grid.z);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+template <typename T, int S, int B>
+static int dispatch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
+                      const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, hipStream_t st) {
+  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
+  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
+  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
+  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
+  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
+}
+
+template <typename T>
+int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
+                      double* partials, int* nblocks, hipStream_t st) {
+  const ZPlan* zp = static_cast<const ZPlan*>(p->zplan);
+  if (!zp) return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile plan");
+  const ZPlan& z = *zp;
+  const size_t N = (size_t)geo.W * geo.H;
+  const bool want_reg = (terms & SRMAP_TERM_REG) != 0;
+  int regk = 0, regr = 0;
+  const T* wts = nullptr;
+  if (want_reg && z.regk != 0) {
+    regk = z.regk; regr = z.regr;
+    const RegSpec& rs = p->reg[z.reg_index];
+    wts = rs.weights ? (const T*)rs.weights + (size_t)obs_c0 * N : nullptr;
+  }
+  unsigned zterms = terms & SRMAP_TERM_DATA;
+  if (regk) zterms |= SRMAP_TERM_REG;
+  int rc = SRMAP_OK, nb = 0;
+  const int S = geo.s, B = geo.b;
+  if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
+  else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
+  else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
+  else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
+  else if (S == 4 && B == 1) rc = dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
+  else if (S == 4 && B == 3) rc = dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
+  else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
+  if (rc) return rc;
+  int total = nb;
+  // the border frame of the data term
+  if ((terms & SRMAP_TERM_DATA) && (z.D > 0 || z.E > 0)) {
+    RingArgs<T> Rg;
+    Rg.x = x; Rg.y = (const T*)p->d_obs; Rg.g = g; Rg.partials = partials + total;
+    Rg.frames = z.d_frames; Rg.blur = (const T*)p->d_blur; Rg.blur_t = (const T*)p->d_blur_t;
+    Rg.W = geo.W; Rg.H = geo.H; Rg.wl = geo.w; Rg.hl = geo.h; Rg.K = geo.K; Rg.S = geo.s; Rg.b = geo.b; Rg.hb = geo.hb;
+    Rg.obs_C = p->geo.C; Rg.obs_c0 = obs_c0;
+    Rg.D = z.D; Rg.E = z.E; Rg.cr0 = geo.cr0; Rg.cr1 = geo.cr1;
+    Rg.band_rows = z.D + z.E;
+    Rg.mid_rows = geo.H - 2 * z.D;
+    const long long We = geo.W + 2 * z.E;
+    Rg.n_ring = 2LL * Rg.band_rows * We + 2LL * Rg.band_rows * Rg.mid_rows;
+    dim3 rgrid((unsigned)((Rg.n_ring + 255) / 256), geo.C);
+    hipLaunchKernelGGL(k_ring<T>, rgrid, dim3(256), 0, st, Rg);
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    total += (int)(rgrid.x * rgrid.y);
+  }
+  // remaining regularisers (3-D TV, a second regulariser, BTV range > 3): direct kernels, accumulating into g
+  if (want_reg) {
+    for (int r = 0; r < p->nreg; ++r) {
+      if (regk && r == z.reg_index) continue;
+      const RegSpec& rs = p->reg[r];
+      if (rs.lambda <= 0.0) continue;
+      const bool onfly = rs.kind != SRMAP_REG_BTV;
+      if (!onfly) {
+        if (!p->d_regvals) SRMAP_HIP(p->ctx, hipMalloc(&p->d_regvals, p->hr_count() * sizeof(T)));
+        rc = launch_reg_values<T>(p, geo, rs, x, (T*)p->d_regvals, st);
+        if (rc) return rc;
+      }
+      const T* w2 = rs.weights ? (const T*)rs.weights + (size_t)obs_c0 * N : nullptr;
+      int nb2 = 0;
+      rc = launch_reg_gradient_direct<T>(p, geo, rs, x, w2, rs.lambda, onfly ? nullptr : (const T*)p->d_regvals, g, true,
+                                         partials + total, &nb2, st);
+      if (rc) return rc;
+      total += nb2;
+    }
+  }
+  *nblocks = total;
+  return SRMAP_OK;
+}
+
+template int launch_eval_ztile<float>(srmap_problem*, const Geometry&, int, unsigned, const float*, float*,
+                                      double*, int*, hipStream_t);
+template int launch_eval_ztile<double>(srmap_problem*, const Geometry&, int, unsigned, const double*,
+                                       double*, double*, int*, hipStream_t);
+
+}  // namespace srmap

@@ -218,7 +218,7 @@ static size_t partials_needed(const srmap_problem* p) {
   const size_t fwd = (size_t)((g.w * g.h + 255) / 256) * g.C * g.K;
   const size_t reg_blocks = std::max((size_t)((g.W * g.H + 255) / 256), (size_t)((g.W + 63) / 64) * ((g.H + 3) / 4));
   const size_t reg = reg_blocks * g.C * kMaxRegularizers;
-  const size_t n = fwd + reg + 16;
+  const size_t n = fwd + reg + ztile_partials_needed(p) + 16;
   return n + (size_t)reduce_scratch_slots(n) + 16;  // + the second-stage scratch of launch_reduce_partials
 }
 
@@ -233,11 +233,15 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
   if (rc) return rc;
   if ((terms & SRMAP_TERM_DATA) && !p->have_obs)
     return set_error(p->ctx, SRMAP_EINVAL, "data term requested but no observations set");
-  const bool tiled = p->impl != SRMAP_IMPL_DIRECT && p->plan.usable;
-  if (p->impl == SRMAP_IMPL_TILED && !p->plan.usable)
+  const bool ztile = (p->impl == SRMAP_IMPL_AUTO || p->impl == SRMAP_IMPL_TILED) && p->zplan != nullptr;
+  const bool tiled = !ztile && p->impl != SRMAP_IMPL_DIRECT && p->plan.usable;
+  if ((p->impl == SRMAP_IMPL_TILED && !ztile && !p->plan.usable) || (p->impl == SRMAP_IMPL_TILED_V1 && !p->plan.usable))
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "tiled kernels do not cover this geometry");
   int nparts = 0;
-  if (tiled) {
+  if (ztile) {
+    rc = launch_eval_ztile<T>(p, geo, c0, terms, x, g, p->d_partials, &nparts, st);
+    if (rc) return rc;
+  } else if (tiled) {
     rc = launch_eval_tiled<T>(p, geo, c0, terms, x, g, p->d_partials, &nparts, st);
     if (rc) return rc;
   } else {
@@ -443,6 +447,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   (void)hipMemset(p->d_cost, 0, sizeof(double) * 8);
   (void)hipMemset(p->d_counters, 0, sizeof(unsigned) * 64 * 34);
   p->plan.usable = tiled_plan(p);
+  (void)ztile_plan(p);
   *out = p;
   return SRMAP_OK;
 }
@@ -450,6 +455,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
 void srmap_problem_destroy(srmap_problem* p) {
   if (!p) return;
   tiled_release(p);
+  ztile_release(p);
   void* bufs[] = {p->d_fwd_warps, p->d_bwd_warps, p->d_blur, p->d_blur_t, p->d_col_map, p->d_row_map,
                   p->d_obs, p->d_resid, p->d_regvals, p->d_x, p->d_g, p->d_tmp, p->d_partials, p->d_cost, p->d_counters};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -459,7 +465,7 @@ void srmap_problem_destroy(srmap_problem* p) {
 
 int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
-  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
+  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED_V1) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
   return SRMAP_OK;
 }
@@ -538,6 +544,7 @@ int srmap_add_regularizer(srmap_problem* p, int kind, double lambda, int btv_ran
   if (reg_index) *reg_index = p->nreg;
   p->nreg++;
   p->plan.usable = tiled_plan(p);
+  (void)ztile_plan(p);
   return SRMAP_OK;
 }
 
@@ -546,6 +553,7 @@ int srmap_clear_regularizers(srmap_problem* p) {
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) { (void)hipFree(p->reg[r].weights); p->reg[r].weights = nullptr; }
   p->nreg = 0;
   p->plan.usable = tiled_plan(p);
+  (void)ztile_plan(p);
   return SRMAP_OK;
 }
 

@@ -100,6 +100,7 @@ struct srmap_problem {
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
   srmap::TilePlan plan;
+  void* zplan = nullptr;          // srmap::ZPlan of the z-tile kernels (kernels_ztile.hip), owned; nullptr = not covered
   // channel view of the current evaluation (split_channels solves one channel
   // at a time, irls_map_solver.cpp:200-262); default = all channels
   int view_c0 = 0, view_C = 0;
@@ -156,6 +157,14 @@ bool tiled_plan(srmap_problem* p);
 void tiled_release(srmap_problem* p);
 template <typename T>
 int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,
+                      const T* x, T* g, double* partials, int* nblocks, hipStream_t st);
+
+// ---- z-tile kernels (kernels_ztile.hip): the hot path ----
+bool ztile_plan(srmap_problem* p);
+void ztile_release(srmap_problem* p);
+size_t ztile_partials_needed(const srmap_problem* p);
+template <typename T>
+int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,
                       const T* x, T* g, double* partials, int* nblocks, hipStream_t st);
 
 // ---- vector kernels for the solver (solver.hip) ----

@@ -11,6 +11,17 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "super-resoluti
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# On a GPU box initialise torch's HIP runtime BEFORE libsrmap.so is loaded: torch ships its own libamdhip64, and a
+# process that has already initialised the system runtime through libsrmap.so makes torch report "no ROCm-capable
+# device" (the full-size tests generate their data with torch on the GPU).  No effect without a GPU.
+try:
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+        torch.zeros(1, device="cuda")
+except Exception:  # pragma: no cover
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
