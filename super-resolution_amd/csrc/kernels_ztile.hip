@@ -16,12 +16,20 @@
 // ("owner computes"), from a full-resolution blur of x at its own pixels; the
 // K per-frame transposes become one blur of z.  Per HR pixel this is 9 + 9 FMAs
 // and K/S^2 observation loads instead of K gathers.  The reference clips every
-// stage to the H x W domain separately (SURVEY.md section 8a'), which the
-// commuted form does not reproduce within D = max|shift| + 2*floor(B/2) pixels of
-// the border: the tiled kernel therefore counts cost and data gradient only for
-// the CORE (pixels at distance >= D), and k_ring evaluates the border frame --
-// gradient of the ring pixels and cost of every residual whose z position is
-// outside the core -- with the reference's literal per-frame formulas.
+// stage to the H x W domain separately (SURVEY.md section 8a'); in owner-computes
+// form the clips are:
+//   (a) warp zero fill: x outside the image reads 0            -> zero-filled tile;
+//   (b) blur zero padding on the WARPED image: blur taps whose warped coordinate
+//       leaves the image are dropped.  With B <= S + 1 that is blur tap row 0 of LR
+//       row 0 and tap column 0 of LR column 0 only              -> subtracted for those
+//       residuals in tiles at the top / left image edge (EDGE code path);
+//   (c) LR pixels exist only inside the LR image                -> validity mask (EDGE);
+//   (d) the transpose warp clips its SOURCE: frame k contributes to output pixel q
+//       only if q - o_k is inside the image.  That depends on (q, k), so it cannot
+//       be folded into the frame-summed z: the tile kernel adds every frame and
+//       k_border subtracts the excluded contributions for the pixels within
+//       E = max|shift| of the image edge; k_border also adds the cost of the
+//       residuals whose z position lies outside the image (they have no owner).
 //
 // Tile kernel k_eval_z: a workgroup of 8 waves owns 8 HR rows x 64*S columns;
 // wave = HR row, lane = LR cell, a thread owns the S consecutive pixels of its
@@ -74,7 +82,8 @@ struct ZCfg {
   static constexpr int NP = REGK == 2 ? 2 * R + 1 : 1;
 };
 
-struct ZEntry { int k, io, jo, pad; };  // frame, LR row / column offset of the residual a pixel of this phase owns
+struct ZEntry { int k, io, jo, oyx; };  // frame, LR row / column offset of the residual a pixel of this phase owns,
+                                         // forward offset packed (oy << 16) | (ox & 0xffff)
 
 template <typename T, int B, int NP>
 struct ZArgs {
@@ -87,7 +96,7 @@ struct ZArgs {
   const ZEntry* ent;
   int W, H, wl, hl;
   int obs_C, obs_c0;
-  int D;             // core margin
+  int E;             // max |shift| (edge tiles take the masked code path)
   int cr0, cr1;      // HR rows whose cost terms are counted (row-band sharding; default 0, H)
   int banded;        // tile rows on blockIdx.x, dealt to the 8 XCDs in contiguous bands
   int terms;         // SRMAP_TERM_*
@@ -117,8 +126,9 @@ __device__ __forceinline__ T obs_at(const T* __restrict__ yk, int i, int j, int 
 
 // ---- data term, phase 1, for the S pixels of one cell in tile row `rowrel` (wave-uniform) ----
 // B x at NV pixels, residuals of the frames whose LR grid hits each pixel, z; returns z (B == 1) or writes the
-// horizontal half of B^T z to LDS (B == 3).  COUNT: the row is owned by this tile (cost is counted, with mk).
-template <typename T, int S, int B, typename C, typename ArgsT>
+// horizontal half of B^T z to LDS (B == 3).  `count`: the row is owned by this tile (cost is counted, with mk).
+// EDGE: tiles near the image border -- LR validity masks and the dropped blur taps of LR row 0 / column 0.
+template <typename T, int S, int B, typename C, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ zs, int rowrel,
                                       int R0, int cellg, int lane, const T* __restrict__ ybase, bool use_pre,
                                       const T (&ypre)[C::NV], bool count, const T (&mk)[S], T (&zout)[S],
@@ -129,9 +139,9 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
   const int rc = (gr >= 0) ? gr / S : -((-gr + S - 1) / S);
   const int pr = gr - rc * S;
   const int xrow = rowrel + C::HU;
-  T bx[NV];
+  T bx[NV], btop[NV], bleft[NV], bcorner[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) bx[v] = T(0);
+  for (int v = 0; v < NV; ++v) { bx[v] = T(0); btop[v] = T(0); bleft[v] = T(0); bcorner[v] = T(0); }
 #pragma unroll
   for (int a = 0; a < B; ++a) {
     T xr[NV + B - 1];
@@ -141,6 +151,14 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
       for (int e = 0; e < B; ++e) bx[v] += A.blur[a * B + e] * xr[v + e];
+      if (EDGE && B > 1) {
+        bleft[v] += A.blur[a * B] * xr[v];  // tap column 0
+        if (a == 0) {
+#pragma unroll
+          for (int e = 0; e < B; ++e) btop[v] += A.blur[e] * xr[v + e];  // tap row 0
+          bcorner[v] = A.blur[0] * xr[v];
+        }
+      }
     }
   }
   T z[NV];
@@ -154,10 +172,19 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
     for (int t = 0; t < h.x; ++t) {
       const ZEntry e = A.ent[h.y + t];
       const int i = rc + e.io, j = cellg + dc + e.jo;
+      if (EDGE && (unsigned)i >= (unsigned)A.hl) continue;  // no such LR row (uniform)
       T yv;
       if (t == 0 && use_pre) yv = ypre[v];
       else yv = obs_at<T>(ybase + (size_t)e.k * A.obs_C * nl, i, j, A.hl, A.wl);
-      const T rr = bx[v] - yv;
+      T bxv = bx[v];
+      if (EDGE && B > 1) {
+        // filter2D's zero padding acts on the warped image: LR row 0 loses blur tap row 0, LR column 0 tap column 0
+        const bool j0 = j == 0;
+        if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
+        else bxv = bxv - (j0 ? bleft[v] : T(0));
+      }
+      T rr = bxv - yv;
+      if (EDGE) rr = ((unsigned)j < (unsigned)A.wl) ? rr : T(0);  // no such LR column
       za += rr;
       if (own && count && S * i >= A.cr0 && S * i < A.cr1) {  // uniform
         const double rd = (double)(rr * mk[own ? pcv : 0]);
@@ -438,15 +465,10 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   }
   __syncthreads();
 
-  // core mask of this thread's pixels: the tile kernel counts data cost / gradient only at distance >= D from
-  // the image border (k_ring evaluates the rest exactly)
+  // in-image mask of this thread's pixels (partial tiles at the right / bottom edge)
   T mk[S];
-  {
-    const bool row_core = (unsigned)(gr - A.D) < (unsigned)(A.H - 2 * A.D);
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc)
-      mk[pc] = (row_core && (unsigned)(gc0 + pc - A.D) < (unsigned)(A.W - 2 * A.D)) ? T(1) : T(0);
-  }
+  for (int pc = 0; pc < S; ++pc) mk[pc] = (gr < A.H && gc0 + pc < A.W) ? T(1) : T(0);
 
   T acc[S], zown[S];
 #pragma unroll
@@ -455,12 +477,19 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 
   // ---------------- phase 1: data term ----------------
   if (want_data) {
-    z_row<T, S, B, C>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
-    if (B > 1 && A.g != nullptr && wv < 2) {  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
-      T dummy[S];
-      double dc = 0.0;
-      z_row<T, S, B, C>(A, xs, zs, wv == 0 ? -HB : C::TH - 1 + HB, R0, cellg, lane, ybase, false, ypre, false, mk,
-                        dummy, dc);
+    // tiles whose residuals can touch LR row / column 0 or leave the LR image take the masked path (uniform)
+    const int rm = A.E + HB + 1, cm = (A.E + HB + S) / S + 1;
+    const bool edge = (R0 - rm < 0) || (R0 + C::TH + rm > A.H) || (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl);
+    const int hrowz = wv == 0 ? -HB : C::TH - 1 + HB;  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
+    const bool has_z_halo = B > 1 && A.g != nullptr && wv < 2;
+    T dummy[S];
+    double dcost = 0.0;
+    if (edge) {
+      z_row<T, S, B, C, true>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
+      if (has_z_halo) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, cellg, lane, ybase, false, ypre, false, mk, dummy, dcost);
+    } else {
+      z_row<T, S, B, C, false>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
+      if (has_z_halo) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, cellg, lane, ybase, false, ypre, false, mk, dummy, dcost);
     }
   }
   // ---------------- phase 1: regulariser ----------------
@@ -502,7 +531,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 #pragma unroll
         for (int a = 0; a < B; ++a) zz += A.k1[a] * zs[(wv + a) * C::ZROW + pc * C::CW + lane];  // rows wv-HB+a
       }
-      acc[pc] += (sc * mk[pc]) * zz;
+      acc[pc] += sc * zz;
     }
   }
   if (want_reg && A.g != nullptr) reg_pass2z<T, S, REGK, R, C>(acc, xs, cs, wv, lane, A.powtab);
@@ -530,36 +559,36 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_ring: the border frame, with the reference's literal per-frame formulas (SURVEY.md section 8a').
-// One thread per pixel q of the EXTENDED ring: [-E, H+E) x [-E, W+E) minus the core [D, H-D) x [D, W-D), where
-// E = max |shift| (z positions of LR pixels can lie outside the image).
-//   (1) q inside the image: g[q] += 2 S^2 sum_k M_k^T B^T D^T r_k at q  (image_model.cpp:93-101, gather form);
-//   (2) cost: every LR pixel (k, i, j) whose z position (S i + oy_k, S j + ox_k) equals q  (each residual has
-//       exactly one z position, so tile kernel + ring count every residual once).
-struct RingFrame { int ox, oy; };  // forward source offset: warped(r, c) = x(r + oy, c + ox)
-
+// k_border: what the frame-summed tile kernel cannot express, with the reference's literal per-frame formulas
+// (SURVEY.md section 8a').  One thread per pixel q of the frame of width 2E around the image edge,
+// [-E, H+E) x [-E, W+E) minus [E, H-E) x [E, W-E), E = max |shift|:
+//   q OUTSIDE the image: cost of the residuals whose z position is q (they have no owner thread in k_eval_z);
+//   q INSIDE: the transpose warp clips its source (motion_module.cpp:40-51 on an H x W image): frame k reaches
+//       q only if q - o_k is inside the image.  k_eval_z added every frame; subtract the excluded ones:
+//       g[q] -= 2 S^2 sum_tap B^T[tap] sum_{k in L(q + tap), q - o_k outside} r_k.
 template <typename T>
-struct RingArgs {
+struct BorderArgs {
   const T* x;
   const T* y;
   T* g;
   double* partials;
-  const RingFrame* frames;
+  const int2* hdr;
+  const ZEntry* ent;
   const T* blur;    // [b*b]
   const T* blur_t;  // [b*b]
-  int W, H, wl, hl, K, S, b, hb;
+  int W, H, wl, hl, S, b, hb;
   int obs_C, obs_c0;
-  int D, E;
+  int E;
   int cr0, cr1;
-  int band_rows;    // D + E
-  int mid_rows;     // H - 2 D
-  long long n_ring; // pixels of the extended ring
+  long long n_ring;  // pixels of the frame
 };
+
+__device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
 template <typename T>
-__device__ __forceinline__ T ring_residual(const RingArgs<T>& A, const T* __restrict__ xplane,
-                                           const T* __restrict__ yk, int ox, int oy, int i, int j) {
+__device__ __forceinline__ T border_residual(const BorderArgs<T>& A, const T* __restrict__ xplane,
+                                             const T* __restrict__ yk, int ox, int oy, int i, int j) {
   T acc = T(0);
   for (int a = 0; a < A.b; ++a) {
     const int rr = A.S * i + a - A.hb;
@@ -578,68 +607,66 @@ __device__ __forceinline__ T ring_residual(const RingArgs<T>& A, const T* __rest
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_ring(RingArgs<T> A) {
+__global__ __launch_bounds__(256) void k_border(BorderArgs<T> A) {
   __shared__ double red[4];
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int ch = blockIdx.y;
   const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
   double cost = 0.0;
   if (t < A.n_ring) {
-    // decode: top band, bottom band (band_rows x We each), then the left / right strips of the middle rows
-    const int We = A.W + 2 * A.E;
-    const long long band = (long long)A.band_rows * We;
+    // decode: top band, bottom band (2E rows x We each), then the left / right strips of the middle rows
+    const int We = A.W + 2 * A.E, E2 = 2 * A.E;
+    const long long band = (long long)E2 * We;
     int qr, qc;
     if (t < band) { qr = -A.E + (int)(t / We); qc = -A.E + (int)(t % We); }
-    else if (t < 2 * band) { const long long u = t - band; qr = A.H - A.D + (int)(u / We); qc = -A.E + (int)(u % We); }
+    else if (t < 2 * band) { const long long u = t - band; qr = A.H - A.E + (int)(u / We); qc = -A.E + (int)(u % We); }
     else {
       const long long u = t - 2 * band;
-      const int per = 2 * A.band_rows;
-      qr = A.D + (int)(u / per);
+      const int per = 2 * E2;
+      qr = A.E + (int)(u / per);
       const int m = (int)(u % per);
-      qc = m < A.band_rows ? -A.E + m : A.W - A.D + (m - A.band_rows);
+      qc = m < E2 ? -A.E + m : A.W - A.E + (m - E2);
     }
     const T* xplane = A.x + (size_t)ch * N;
+    const T* ybase = A.y + (size_t)(ch + A.obs_c0) * nl;
     const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
-    T gsum = T(0);
-    for (int k = 0; k < A.K; ++k) {
-      const int ox = A.frames[k].ox, oy = A.frames[k].oy;
-      const T* yk = A.y + ((size_t)k * A.obs_C + ch + A.obs_c0) * nl;
-      // (2) the residual whose z position is q
-      {
-        const int ri = qr - oy, rj = qc - ox;
-        if (ri >= 0 && rj >= 0 && ri % A.S == 0 && rj % A.S == 0) {
-          const int i = ri / A.S, j = rj / A.S;
-          if (i < A.hl && j < A.wl && A.S * i >= A.cr0 && A.S * i < A.cr1) {
-            const double r = (double)ring_residual<T>(A, xplane, yk, ox, oy, i, j);
-            cost += r * r;
+    if (!inside) {
+      const int rc = dfdiv(qr, A.S), cc = dfdiv(qc, A.S);
+      const int2 h = A.hdr[(qr - rc * A.S) * A.S + (qc - cc * A.S)];
+      for (int n = 0; n < h.x; ++n) {
+        const ZEntry e = A.ent[h.y + n];
+        const int i = rc + e.io, j = cc + e.jo;
+        if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
+        if (A.S * i < A.cr0 || A.S * i >= A.cr1) continue;
+        const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
+        const double r = (double)border_residual<T>(A, xplane, ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
+        cost += r * r;
+      }
+    } else if (A.g != nullptr) {
+      T corr = T(0);
+      bool any = false;
+      for (int a = 0; a < A.b; ++a) {
+        for (int b2 = 0; b2 < A.b; ++b2) {
+          const int pr = qr + a - A.hb, pc = qc + b2 - A.hb;
+          const int rc = dfdiv(pr, A.S), cc = dfdiv(pc, A.S);
+          const int2 h = A.hdr[(pr - rc * A.S) * A.S + (pc - cc * A.S)];
+          for (int n = 0; n < h.x; ++n) {
+            const ZEntry e = A.ent[h.y + n];
+            const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
+            const int ur = qr - oy, uc = qc - ox;
+            if (ur >= 0 && ur < A.H && uc >= 0 && uc < A.W) continue;  // frame reaches q: already correct
+            const int i = rc + e.io, j = cc + e.jo;
+            if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
+            corr += A.blur_t[a * A.b + b2] *
+                    border_residual<T>(A, xplane, ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
+            any = true;
           }
         }
       }
-      // (1) transpose at q: t_k(q) = [v_k(q - o_k)], v_k = B^T (zero-inserted r_k), every stage clipped
-      if (inside && A.g != nullptr) {
-        const int vr = qr - oy, vc = qc - ox;
-        if (vr >= 0 && vr < A.H && vc >= 0 && vc < A.W) {
-          T v = T(0);
-          for (int a = 0; a < A.b; ++a) {
-            const int Rr = vr + a - A.hb;
-            if (Rr < 0 || Rr >= A.H || (Rr % A.S) != 0) continue;
-            const int i = Rr / A.S;
-            if (i >= A.hl) continue;
-            for (int e = 0; e < A.b; ++e) {
-              const int Cc = vc + e - A.hb;
-              if (Cc < 0 || Cc >= A.W || (Cc % A.S) != 0) continue;
-              const int j = Cc / A.S;
-              if (j >= A.wl) continue;
-              v += A.blur_t[a * A.b + e] * ring_residual<T>(A, xplane, yk, ox, oy, i, j);
-            }
-          }
-          gsum += v;
-        }
+      if (any) {
+        T* gp = A.g + (size_t)ch * N + (size_t)qr * A.W + qc;
+        *gp -= (T)(2 * A.S * A.S) * corr;
       }
-    }
-    if (inside && A.g != nullptr) {
-      T* gp = A.g + (size_t)ch * N + (size_t)qr * A.W + qc;
-      *gp += (T)(2 * A.S * A.S) * gsum;
     }
   }
   // block partial (s^2 * sum of squares)
@@ -662,10 +689,9 @@ __global__ __launch_bounds__(256) void k_ring(RingArgs<T> A) {
 struct ZPlan {
   int S = 0, B = 1;
   int regk = 0, regr = 0, reg_index = -1;
-  int D = 0, E = 0;
+  int E = 0;  // max |shift|
   int2* d_hdr = nullptr;
   ZEntry* d_ent = nullptr;
-  RingFrame* d_frames = nullptr;
 };
 
 void ztile_release(srmap_problem* p) {
@@ -673,7 +699,6 @@ void ztile_release(srmap_problem* p) {
   if (!z) return;
   if (z->d_hdr) (void)hipFree(z->d_hdr);
   if (z->d_ent) (void)hipFree(z->d_ent);
-  if (z->d_frames) (void)hipFree(z->d_frames);
   delete z;
   p->zplan = nullptr;
 }
@@ -702,9 +727,8 @@ bool ztile_plan(srmap_problem* p) {
   ZPlan* z = new ZPlan();
   z->S = S; z->B = B;
   z->E = amax;
-  z->D = amax + 2 * g.hb;
-  // the core must exist and the ring must stay a small part of the work
-  if (g.W <= 2 * z->D + 2 * S || g.H <= 2 * z->D + 2 * S) { delete z; return false; }
+  // the border frame (k_border, width 2E) must stay a small part of the image
+  if (g.W <= 4 * z->E + 2 * S || g.H <= 4 * z->E + 2 * S) { delete z; return false; }
   // the one regulariser handled in-kernel (first TV / BTV with lambda > 0)
   for (int r = 0; r < p->nreg && z->regk == 0; ++r) {
     const RegSpec& rs = p->reg[r];
@@ -722,21 +746,18 @@ bool ztile_plan(srmap_problem* p) {
       int2 h; h.x = 0; h.y = (int)ent.size();
       for (int k = 0; k < K; ++k) {
         if (pmod(pr - oy[k], S) != 0 || pmod(pc - ox[k], S) != 0) continue;
-        ZEntry e; e.k = k; e.io = fdiv(pr - oy[k], S); e.jo = fdiv(pc - ox[k], S); e.pad = 0;
+        ZEntry e; e.k = k; e.io = fdiv(pr - oy[k], S); e.jo = fdiv(pc - ox[k], S);
+        e.oyx = (int)(((unsigned)oy[k] << 16) | ((unsigned)ox[k] & 0xffffu));
         ent.push_back(e);
         h.x++;
       }
       hdr[(size_t)pr * S + pc] = h;
     }
   if (ent.empty()) { ZEntry e = {0, 0, 0, 0}; ent.push_back(e); }
-  std::vector<RingFrame> fr(K);
-  for (int k = 0; k < K; ++k) { fr[k].ox = ox[k]; fr[k].oy = oy[k]; }
   bool ok = hipMalloc((void**)&z->d_hdr, sizeof(int2) * hdr.size()) == hipSuccess &&
             hipMemcpy(z->d_hdr, hdr.data(), sizeof(int2) * hdr.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipMalloc((void**)&z->d_ent, sizeof(ZEntry) * ent.size()) == hipSuccess &&
-            hipMemcpy(z->d_ent, ent.data(), sizeof(ZEntry) * ent.size(), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMalloc((void**)&z->d_frames, sizeof(RingFrame) * fr.size()) == hipSuccess &&
-            hipMemcpy(z->d_frames, fr.data(), sizeof(RingFrame) * fr.size(), hipMemcpyHostToDevice) == hipSuccess;
+            hipMemcpy(z->d_ent, ent.data(), sizeof(ZEntry) * ent.size(), hipMemcpyHostToDevice) == hipSuccess;
   p->zplan = z;
   if (!ok) { ztile_release(p); return false; }
   return true;
@@ -747,9 +768,9 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   const size_t tiles = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * g.C;
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   size_t ring = 0;
-  if (z) {
-    const long long We = g.W + 2 * z->E, band = z->D + z->E;
-    const long long n = 2 * band * We + 2 * band * (long long)std::max(0, g.H - 2 * z->D);
+  if (z && z->E > 0) {
+    const long long We = g.W + 2 * z->E, E2 = 2 * z->E;
+    const long long n = 2 * E2 * We + 2 * E2 * (long long)(g.H - 2 * z->E);
     ring = (size_t)((n + 255) / 256) * g.C;
   }
   return tiles + ring;
@@ -764,7 +785,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.hdr = z.d_hdr; A.ent = z.d_ent;
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
   A.obs_C = p->geo.C; A.obs_c0 = obs_c0;
-  A.D = z.D;
+  A.E = z.E;
   A.cr0 = geo.cr0; A.cr1 = geo.cr1;
   A.terms = (int)terms;
   for (int i = 0; i < B * B; ++i) A.blur[i] = (T)p->blur2d[i];
@@ -823,20 +844,18 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
   if (rc) return rc;
   int total = nb;
-  // the border frame of the data term
-  if ((terms & SRMAP_TERM_DATA) && (z.D > 0 || z.E > 0)) {
-    RingArgs<T> Rg;
-    Rg.x = x; Rg.y = (const T*)p->d_obs; Rg.g = g; Rg.partials = partials + total;
-    Rg.frames = z.d_frames; Rg.blur = (const T*)p->d_blur; Rg.blur_t = (const T*)p->d_blur_t;
-    Rg.W = geo.W; Rg.H = geo.H; Rg.wl = geo.w; Rg.hl = geo.h; Rg.K = geo.K; Rg.S = geo.s; Rg.b = geo.b; Rg.hb = geo.hb;
-    Rg.obs_C = p->geo.C; Rg.obs_c0 = obs_c0;
-    Rg.D = z.D; Rg.E = z.E; Rg.cr0 = geo.cr0; Rg.cr1 = geo.cr1;
-    Rg.band_rows = z.D + z.E;
-    Rg.mid_rows = geo.H - 2 * z.D;
-    const long long We = geo.W + 2 * z.E;
-    Rg.n_ring = 2LL * Rg.band_rows * We + 2LL * Rg.band_rows * Rg.mid_rows;
-    dim3 rgrid((unsigned)((Rg.n_ring + 255) / 256), geo.C);
-    hipLaunchKernelGGL(k_ring<T>, rgrid, dim3(256), 0, st, Rg);
+  // the border frame of the data term (nothing to do without motion: no clipped transpose, no z position outside)
+  if ((terms & SRMAP_TERM_DATA) && z.E > 0) {
+    BorderArgs<T> Bd;
+    Bd.x = x; Bd.y = (const T*)p->d_obs; Bd.g = g; Bd.partials = partials + total;
+    Bd.hdr = z.d_hdr; Bd.ent = z.d_ent; Bd.blur = (const T*)p->d_blur; Bd.blur_t = (const T*)p->d_blur_t;
+    Bd.W = geo.W; Bd.H = geo.H; Bd.wl = geo.w; Bd.hl = geo.h; Bd.S = geo.s; Bd.b = geo.b; Bd.hb = geo.hb;
+    Bd.obs_C = p->geo.C; Bd.obs_c0 = obs_c0;
+    Bd.E = z.E; Bd.cr0 = geo.cr0; Bd.cr1 = geo.cr1;
+    const long long We = geo.W + 2 * z.E, E2 = 2 * z.E;
+    Bd.n_ring = 2 * E2 * We + 2 * E2 * (long long)(geo.H - 2 * z.E);
+    dim3 rgrid((unsigned)((Bd.n_ring + 255) / 256), geo.C);
+    hipLaunchKernelGGL(k_border<T>, rgrid, dim3(256), 0, st, Bd);
     SRMAP_HIP(p->ctx, hipGetLastError());
     total += (int)(rgrid.x * rgrid.y);
   }
