@@ -92,8 +92,10 @@ struct ZArgs {
   const T* w;        // IRLS weights or nullptr
   T* g;              // nullptr = cost only
   double* partials;
-  const int2* hdr;   // [S*S] (count, first entry) per (row phase, column phase)
-  const ZEntry* ent;
+  const int* cnt;        // [S][8]  residuals per (row phase, column phase); [pr][S] = max over the column phases
+  const long long* off;  // [S][MS][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
+  const ZEntry* aux;     // [S][MS][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
+  int MS;                // slots per (row phase, column phase)
   int W, H, wl, hl;
   int obs_C, obs_c0;
   int E;             // max |shift| (edge tiles take the masked code path)
@@ -124,6 +126,37 @@ __device__ __forceinline__ T obs_at(const T* __restrict__ yk, int i, int j, int 
   return yk[(size_t)ic * wl + jc];
 }
 
+// Row phase / LR cell row of HR row gr (floor division; gr may be negative in the top halo).
+template <int S>
+__device__ __forceinline__ void row_phase(int gr, int& rc, int& pr) {
+  rc = (gr >= 0) ? gr / S : -((-gr + S - 1) / S);
+  pr = gr - rc * S;
+}
+
+// Observations of the t-th residual of each of the NV pixels of the thread's cell in an HR row of phase pr
+// (frame table: SURVEY.md section 8a' restated per HR pixel).  Interior tiles: one scalar offset per pixel phase,
+// address = row base + offset + cell.  EDGE: explicit (frame, LR row, LR column), clamped into the image.
+template <typename T, int S, typename C, bool EDGE, typename ArgsT>
+__device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int t, int cellg,
+                                             const T* __restrict__ ybase, const int (&cn)[S], T (&yv)[C::NV]) {
+  constexpr int HB = C::HB, NV = C::NV;
+  const size_t slot = (size_t)(pr * A.MS + t) * S;  // uniform
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+    yv[v] = T(0);
+    if (t < cn[pc]) {  // uniform
+      if (!EDGE) {
+        const T* yp = ybase + (A.off[slot + pc] + (long long)rc * A.wl);  // uniform pointer
+        yv[v] = yp[cellg + dc];
+      } else {
+        const ZEntry e = A.aux[slot + pc];
+        yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cellg + dc + e.jo, A.hl, A.wl);
+      }
+    }
+  }
+}
+
 // ---- data term, phase 1, for the S pixels of one cell in tile row `rowrel` (wave-uniform) ----
 // B x at NV pixels, residuals of the frames whose LR grid hits each pixel, z; returns z (B == 1) or writes the
 // horizontal half of B^T z to LDS (B == 3).  `count`: the row is owned by this tile (cost is counted, with mk).
@@ -134,10 +167,8 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
                                       const T (&ypre)[C::NV], bool count, const T (&mk)[S], T (&zout)[S],
                                       double& cost) {
   constexpr int HB = C::HB, NV = C::NV;
-  const int gr = R0 + rowrel;
-  // row phase and LR cell row of this HR row (floor division; gr may be negative in the top halo)
-  const int rc = (gr >= 0) ? gr / S : -((-gr + S - 1) / S);
-  const int pr = gr - rc * S;
+  int rc, pr;
+  row_phase<S>(R0 + rowrel, rc, pr);
   const int xrow = rowrel + C::HU;
   T bx[NV], btop[NV], bleft[NV], bcorner[NV];
 #pragma unroll
@@ -161,37 +192,53 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
       }
     }
   }
-  T z[NV];
-  const size_t nl = (size_t)A.wl * A.hl;
+  int cn[S];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-    const bool own = pcv >= 0 && pcv < S;
-    const int2 h = A.hdr[pr * S + pc];  // scalar load: (count, first entry)
-    T za = T(0);
-    for (int t = 0; t < h.x; ++t) {
-      const ZEntry e = A.ent[h.y + t];
-      const int i = rc + e.io, j = cellg + dc + e.jo;
-      if (EDGE && (unsigned)i >= (unsigned)A.hl) continue;  // no such LR row (uniform)
-      T yv;
-      if (t == 0 && use_pre) yv = ypre[v];
-      else yv = obs_at<T>(ybase + (size_t)e.k * A.obs_C * nl, i, j, A.hl, A.wl);
-      T bxv = bx[v];
-      if (EDGE && B > 1) {
-        // filter2D's zero padding acts on the warped image: LR row 0 loses blur tap row 0, LR column 0 tap column 0
-        const bool j0 = j == 0;
-        if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
-        else bxv = bxv - (j0 ? bleft[v] : T(0));
-      }
-      T rr = bxv - yv;
-      if (EDGE) rr = ((unsigned)j < (unsigned)A.wl) ? rr : T(0);  // no such LR column
-      za += rr;
-      if (own && count && S * i >= A.cr0 && S * i < A.cr1) {  // uniform
-        const double rd = (double)(rr * mk[own ? pcv : 0]);
-        cost += rd * (double)rr;
+  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
+  const int mmax = A.cnt[pr * 8 + S];
+  T z[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) z[v] = T(0);
+  for (int t = 0; t < mmax; ++t) {
+    T yv[NV];
+    if (t == 0 && use_pre) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) yv[v] = ypre[v];
+    } else {
+      load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cellg, ybase, cn, yv);
+    }
+    const size_t slot = (size_t)(pr * A.MS + t) * S;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+      const bool own = pcv >= 0 && pcv < S;
+      if (t < cn[pc]) {  // uniform
+        T rr;
+        bool cost_on = own && count;
+        if (!EDGE) {
+          rr = bx[v] - yv[v];
+        } else {
+          const ZEntry e = A.aux[slot + pc];
+          const int i = rc + e.io, j = cellg + dc + e.jo;
+          T bxv = bx[v];
+          if (B > 1) {
+            // filter2D's zero padding acts on the warped image: LR row 0 loses blur tap row 0, LR column 0 tap column 0
+            const bool j0 = j == 0;
+            if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
+            else bxv = bxv - (j0 ? bleft[v] : T(0));
+          }
+          rr = bxv - yv[v];
+          // no such LR pixel (row: uniform, column: per lane)
+          rr = ((unsigned)i < (unsigned)A.hl && (unsigned)j < (unsigned)A.wl) ? rr : T(0);
+          cost_on = cost_on && S * i >= A.cr0 && S * i < A.cr1;
+        }
+        z[v] += rr;
+        if (cost_on) {
+          const double rd = (double)(rr * mk[own ? pcv : 0]);
+          cost += rd * (double)rr;
+        }
       }
     }
-    z[v] = za;
   }
   if (B == 1) {
 #pragma unroll
@@ -209,23 +256,15 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
 
 // t = 0 observations of the NV pixels of the thread's cell in tile row `rowrel`, issued at kernel start.
 template <typename T, int S, int B, typename C, typename ArgsT>
-__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cellg,
+__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cellg, bool edge,
                                                const T* __restrict__ ybase, T (&ypre)[C::NV]) {
-  constexpr int HB = C::HB, NV = C::NV;
-  const int gr = R0 + rowrel;
-  const int rc = (gr >= 0) ? gr / S : -((-gr + S - 1) / S);
-  const int pr = gr - rc * S;
-  const size_t nl = (size_t)A.wl * A.hl;
+  int rc, pr;
+  row_phase<S>(R0 + rowrel, rc, pr);
+  int cn[S];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-    const int2 h = A.hdr[pr * S + pc];
-    ypre[v] = T(0);
-    if (h.x > 0) {  // uniform
-      const ZEntry e = A.ent[h.y];
-      ypre[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * nl, rc + e.io, cellg + dc + e.jo, A.hl, A.wl);
-    }
-  }
+  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
+  if (edge) load_obs_row<T, S, C, true>(A, pr, rc, 0, cellg, ybase, cn, ypre);
+  else load_obs_row<T, S, C, false>(A, pr, rc, 0, cellg, ybase, cn, ypre);
 }
 
 // ---- regulariser pass 1 for the S pixels of one cell (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
@@ -371,12 +410,156 @@ __device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs
   for (int pc = 0; pc < S; ++pc) acc[pc] += sum[pc];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Border blocks: what the frame-summed tile path cannot express, with the reference's literal per-frame formulas
+// (SURVEY.md section 8a').  They are extra workgroups at the FRONT of k_eval_z's grid (dispatched first, they run
+// beside the first tiles and cost no launch of their own).  One thread per pixel q of the frame of width 2E around
+// the image edge, [-E, H+E) x [-E, W+E) minus [E, H-E) x [E, W-E), E = max |shift|:
+//   q OUTSIDE the image: cost of the residuals whose z position is q (they have no owner thread among the tiles);
+//   q INSIDE: the transpose warp clips its source (motion_module.cpp:40-51 on an H x W image): frame k reaches
+//       q only if q - o_k is inside the image.  The tiles add every frame; the excluded ones are collected here,
+//       corr[q] = 2 S^2 sum_tap B^T[tap] sum_{k in L(q + tap), q - o_k outside} r_k, and subtracted from g by
+//       k_finish_eval after the tile kernel.
+constexpr int kBorderTabEntries = 256;  // frame-table entries staged in LDS by the border blocks
+
+template <typename T>
+struct BorderArgs {
+  const int2* hdr;       // flat frame table: (count, first entry) per (row phase, column phase)
+  const ZEntry* ent;
+  const T* blur_d;       // [b*b] device copies (dynamic indexing)
+  T* corr;               // [C][n_ring]
+  int S, b, hb;
+  int n_ring;            // pixels of the frame
+  int n_ent;             // entries of the frame table
+  int nby;               // grid rows (blockIdx.y) taken by border blocks; 0 = none
+  int n_tile_partials;   // border partials are stored behind the tile partials
+};
+
+__device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// pixel of the frame for thread index t: top band, bottom band (2E rows x We each), then the left / right strips
+__device__ __forceinline__ void ring_pixel(int t, int W, int H, int E, int& qr, int& qc) {
+  const int We = W + 2 * E, E2 = 2 * E;
+  const int band = E2 * We;
+  if (t < band) { qr = -E + t / We; qc = -E + t % We; }
+  else if (t < 2 * band) { const int u = t - band; qr = H - E + u / We; qc = -E + u % We; }
+  else {
+    const int u = t - 2 * band;
+    const int per = 2 * E2;
+    qr = E + u / per;
+    const int m = u % per;
+    qc = m < E2 ? -E + m : W - E + (m - E2);
+  }
+}
+
+// r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
+template <typename T>
+__device__ __forceinline__ T border_residual(const T* __restrict__ blur, int S, int b, int hb, int W, int H, int wl,
+                                             const T* __restrict__ xplane, const T* __restrict__ yk, int ox, int oy,
+                                             int i, int j) {
+  T acc = T(0);
+  for (int a = 0; a < b; ++a) {
+    const int rr = S * i + a - hb;
+    const int sr = rr + oy;
+    // filter2D BORDER_CONSTANT on the warped image, warpAffine BORDER_CONSTANT on the source
+    const bool rok = rr >= 0 && rr < H && sr >= 0 && sr < H;
+    for (int e = 0; e < b; ++e) {
+      const int cc = S * j + e - hb;
+      const int sc = cc + ox;
+      const bool ok = rok && cc >= 0 && cc < W && sc >= 0 && sc < W;
+      const T v = xplane[ok ? (size_t)sr * W + sc : (size_t)0];
+      acc += ok ? blur[a * b + e] * v : T(0);
+    }
+  }
+  return acc - yk[(size_t)i * wl + j];
+}
+
+// One border block of NT threads; smem: scratch of at least 16 int2 + kBorderTabEntries ZEntry + 8 doubles.
+template <typename T, int NT, typename ArgsT>
+__device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>& Bd, int bidx, int ch, void* smem) {
+  int2* s_hdr = reinterpret_cast<int2*>(smem);
+  ZEntry* s_ent = reinterpret_cast<ZEntry*>(s_hdr + 16);
+  double* red = reinterpret_cast<double*>(s_ent + kBorderTabEntries);
+  const int tid = threadIdx.x;
+  const int t = bidx * NT + tid;
+  const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
+  // the frame table -> LDS (one global latency for the whole block instead of one per lookup)
+  if (tid < Bd.S * Bd.S) s_hdr[tid] = Bd.hdr[tid];
+  for (int i = tid; i < Bd.n_ent; i += NT) s_ent[i] = Bd.ent[i];
+  __syncthreads();
+  double cost = 0.0;
+  if (t < Bd.n_ring) {
+    int qr, qc;
+    ring_pixel(t, A.W, A.H, A.E, qr, qc);
+    const int S = Bd.S;
+    const T* xplane = A.x + (size_t)ch * N;
+    const T* ybase = A.y + (size_t)(ch + A.obs_c0) * nl;
+    const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
+    T corr = T(0);
+    if (!inside) {
+      if (A.terms & SRMAP_TERM_DATA) {
+        const int rc = dfdiv(qr, S), cc = dfdiv(qc, S);
+        const int2 h = s_hdr[(qr - rc * S) * S + (qc - cc * S)];
+        for (int n = 0; n < h.x; ++n) {
+          const ZEntry e = s_ent[h.y + n];
+          const int i = rc + e.io, j = cc + e.jo;
+          if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
+          if (S * i < A.cr0 || S * i >= A.cr1) continue;
+          const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
+          const double r = (double)border_residual<T>(Bd.blur_d, S, Bd.b, Bd.hb, A.W, A.H, A.wl, xplane,
+                                                      ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
+          cost += r * r;
+        }
+      }
+    } else if (A.g != nullptr && (A.terms & SRMAP_TERM_DATA)) {
+      for (int a = 0; a < Bd.b; ++a) {
+        for (int b2 = 0; b2 < Bd.b; ++b2) {
+          const int pr = qr + a - Bd.hb, pc = qc + b2 - Bd.hb;
+          const int rc = dfdiv(pr, S), cc = dfdiv(pc, S);
+          const int2 h = s_hdr[(pr - rc * S) * S + (pc - cc * S)];
+          for (int n = 0; n < h.x; ++n) {
+            const ZEntry e = s_ent[h.y + n];
+            const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
+            const int ur = qr - oy, uc = qc - ox;
+            if (ur >= 0 && ur < A.H && uc >= 0 && uc < A.W) continue;  // frame reaches q: already correct
+            const int i = rc + e.io, j = cc + e.jo;
+            if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
+            // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
+            corr += Bd.blur_d[b2 * Bd.b + a] *
+                    border_residual<T>(Bd.blur_d, S, Bd.b, Bd.hb, A.W, A.H, A.wl, xplane,
+                                       ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
+          }
+        }
+      }
+      corr *= (T)(2 * S * S);
+    }
+    if (A.g != nullptr) Bd.corr[(size_t)ch * Bd.n_ring + t] = corr;
+  }
+  // block partial (s^2 * sum of squares), stored behind the tile partials
+  {
+    double v = cost;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = tid & 63, wid = tid >> 6;
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double sum = 0.0;
+      for (int i = 0; i < NT / 64; ++i) sum += red[i];
+      const int nbb = Bd.nby * gridDim.x;
+      A.partials[(size_t)Bd.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(Bd.S * Bd.S) * sum;
+    }
+  }
+}
+
 template <typename T, int S, int B, int REGK, int R>
 __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_z(
-    ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
+    ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A, BorderArgs<T> Bd) {
   using C = ZCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
-  __shared__ T xs[C::XS_ELEMS];
+  // border blocks borrow the x tile's LDS for the frame table
+  constexpr int kBorderLds = (int)((16 * sizeof(int2) + kBorderTabEntries * sizeof(ZEntry) + 16 * sizeof(double) + sizeof(T) - 1) / sizeof(T));
+  __shared__ T xs[C::XS_ELEMS > kBorderLds ? C::XS_ELEMS : kBorderLds];
   __shared__ T zs[C::ZS_ELEMS > 0 ? C::ZS_ELEMS : 1];
   __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
   __shared__ double red[2][C::NW];
@@ -387,11 +570,21 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin in launch order and every XCD has its
   // own L2; with the tile ROW on blockIdx.x and launch index n -> row band (n mod 8) the workgroups an XCD runs at
   // the same time are vertical neighbours and share their x halo rows in that L2.  Bijective for any row count.
-  int tby = blockIdx.y, tbx = blockIdx.x;
+  if ((int)blockIdx.y < Bd.nby) {  // border blocks come first in dispatch order (uniform branch)
+    const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
+    if (bidx * C::NT < Bd.n_ring) border_block<T, C::NT>(A, Bd, bidx, blockIdx.z, xs);
+    else if (threadIdx.x == 0) {
+      const int nbb = Bd.nby * gridDim.x;
+      A.partials[(size_t)Bd.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
+    }
+    return;
+  }
+  const int by = blockIdx.y - Bd.nby, nby_t = gridDim.y - Bd.nby;
+  int tby = by, tbx = blockIdx.x;
   if (A.banded) {
     const int n = blockIdx.x, q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
     tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
-    tbx = blockIdx.y;
+    tbx = by;
   }
   const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;
   const int ch = blockIdx.z;
@@ -429,7 +622,18 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   T ypre[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) ypre[v] = T(0);
-  if (want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, cellg, ybase, ypre);
+  // tiles whose residuals can touch LR row / column 0 or leave the LR image take the masked path (uniform);
+  // so do row-band problems (cost rows restricted)
+  const int rm = A.E + HB + 1, cm = (A.E + HB + S) / S + 1;
+  const bool edge = (R0 - rm < 0) || (R0 + C::TH + rm > A.H) || (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl) ||
+                    A.cr0 > 0 || A.cr1 < A.H;
+  const int hrowz = wv == 0 ? -HB : C::TH - 1 + HB;  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
+  const bool has_z_halo = want_data && B > 1 && A.g != nullptr && wv < 2;
+  T ypre2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) ypre2[v] = T(0);
+  if (want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, cellg, edge, ybase, ypre);
+  if (has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, cellg, edge, ybase, ypre2);
   const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
   T wreg[S];
 #pragma unroll
@@ -477,19 +681,14 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 
   // ---------------- phase 1: data term ----------------
   if (want_data) {
-    // tiles whose residuals can touch LR row / column 0 or leave the LR image take the masked path (uniform)
-    const int rm = A.E + HB + 1, cm = (A.E + HB + S) / S + 1;
-    const bool edge = (R0 - rm < 0) || (R0 + C::TH + rm > A.H) || (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl);
-    const int hrowz = wv == 0 ? -HB : C::TH - 1 + HB;  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
-    const bool has_z_halo = B > 1 && A.g != nullptr && wv < 2;
     T dummy[S];
     double dcost = 0.0;
     if (edge) {
       z_row<T, S, B, C, true>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
-      if (has_z_halo) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, cellg, lane, ybase, false, ypre, false, mk, dummy, dcost);
+      if (has_z_halo) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, cellg, lane, ybase, true, ypre2, false, mk, dummy, dcost);
     } else {
       z_row<T, S, B, C, false>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
-      if (has_z_halo) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, cellg, lane, ybase, false, ypre, false, mk, dummy, dcost);
+      if (has_z_halo) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, cellg, lane, ybase, true, ypre2, false, mk, dummy, dcost);
     }
   }
   // ---------------- phase 1: regulariser ----------------
@@ -552,133 +751,40 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
       double d = 0.0, r = 0.0;
 #pragma unroll
       for (int i = 0; i < C::NW; ++i) { d += red[0][i]; r += red[1][i]; }
-      const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const size_t b = ((size_t)blockIdx.z * nby_t + by) * gridDim.x + blockIdx.x;
       A.partials[b] = (double)(S * S) * d + r;
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k_border: what the frame-summed tile kernel cannot express, with the reference's literal per-frame formulas
-// (SURVEY.md section 8a').  One thread per pixel q of the frame of width 2E around the image edge,
-// [-E, H+E) x [-E, W+E) minus [E, H-E) x [E, W-E), E = max |shift|:
-//   q OUTSIDE the image: cost of the residuals whose z position is q (they have no owner thread in k_eval_z);
-//   q INSIDE: the transpose warp clips its source (motion_module.cpp:40-51 on an H x W image): frame k reaches
-//       q only if q - o_k is inside the image.  k_eval_z added every frame; subtract the excluded ones:
-//       g[q] -= 2 S^2 sum_tap B^T[tap] sum_{k in L(q + tap), q - o_k outside} r_k.
+// After the tile kernel: subtract the border corrections from g and reduce every cost partial of the evaluation
+// in index order (deterministic).  Block 0 reduces; all blocks apply corrections.
 template <typename T>
-struct BorderArgs {
-  const T* x;
-  const T* y;
-  T* g;
-  double* partials;
-  const int2* hdr;
-  const ZEntry* ent;
-  const T* blur;    // [b*b]
-  const T* blur_t;  // [b*b]
-  int W, H, wl, hl, S, b, hb;
-  int obs_C, obs_c0;
-  int E;
-  int cr0, cr1;
-  long long n_ring;  // pixels of the frame
-};
-
-__device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
-
-// r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
-template <typename T>
-__device__ __forceinline__ T border_residual(const BorderArgs<T>& A, const T* __restrict__ xplane,
-                                             const T* __restrict__ yk, int ox, int oy, int i, int j) {
-  T acc = T(0);
-  for (int a = 0; a < A.b; ++a) {
-    const int rr = A.S * i + a - A.hb;
-    if (rr < 0 || rr >= A.H) continue;  // filter2D BORDER_CONSTANT on the warped image
-    const int sr = rr + oy;
-    if (sr < 0 || sr >= A.H) continue;  // warpAffine BORDER_CONSTANT
-    for (int e = 0; e < A.b; ++e) {
-      const int cc = A.S * j + e - A.hb;
-      if (cc < 0 || cc >= A.W) continue;
-      const int sc = cc + ox;
-      if (sc < 0 || sc >= A.W) continue;
-      acc += A.blur[a * A.b + e] * xplane[(size_t)sr * A.W + sc];
-    }
-  }
-  return acc - yk[(size_t)i * A.wl + j];
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_border(BorderArgs<T> A) {
+__global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T* __restrict__ corr, int n_ring, int W,
+                                                     int H, int E, int C, const double* __restrict__ partials,
+                                                     int n_partials, double* __restrict__ cost_out) {
   __shared__ double red[4];
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int ch = blockIdx.y;
-  const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
-  double cost = 0.0;
-  if (t < A.n_ring) {
-    // decode: top band, bottom band (2E rows x We each), then the left / right strips of the middle rows
-    const int We = A.W + 2 * A.E, E2 = 2 * A.E;
-    const long long band = (long long)E2 * We;
+  double v = 0.0;
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_partials; i += 256) v += partials[i];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (g != nullptr && t < n_ring) {
     int qr, qc;
-    if (t < band) { qr = -A.E + (int)(t / We); qc = -A.E + (int)(t % We); }
-    else if (t < 2 * band) { const long long u = t - band; qr = A.H - A.E + (int)(u / We); qc = -A.E + (int)(u % We); }
-    else {
-      const long long u = t - 2 * band;
-      const int per = 2 * E2;
-      qr = A.E + (int)(u / per);
-      const int m = (int)(u % per);
-      qc = m < E2 ? -A.E + m : A.W - A.E + (m - E2);
-    }
-    const T* xplane = A.x + (size_t)ch * N;
-    const T* ybase = A.y + (size_t)(ch + A.obs_c0) * nl;
-    const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
-    if (!inside) {
-      const int rc = dfdiv(qr, A.S), cc = dfdiv(qc, A.S);
-      const int2 h = A.hdr[(qr - rc * A.S) * A.S + (qc - cc * A.S)];
-      for (int n = 0; n < h.x; ++n) {
-        const ZEntry e = A.ent[h.y + n];
-        const int i = rc + e.io, j = cc + e.jo;
-        if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
-        if (A.S * i < A.cr0 || A.S * i >= A.cr1) continue;
-        const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-        const double r = (double)border_residual<T>(A, xplane, ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
-        cost += r * r;
-      }
-    } else if (A.g != nullptr) {
-      T corr = T(0);
-      bool any = false;
-      for (int a = 0; a < A.b; ++a) {
-        for (int b2 = 0; b2 < A.b; ++b2) {
-          const int pr = qr + a - A.hb, pc = qc + b2 - A.hb;
-          const int rc = dfdiv(pr, A.S), cc = dfdiv(pc, A.S);
-          const int2 h = A.hdr[(pr - rc * A.S) * A.S + (pc - cc * A.S)];
-          for (int n = 0; n < h.x; ++n) {
-            const ZEntry e = A.ent[h.y + n];
-            const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-            const int ur = qr - oy, uc = qc - ox;
-            if (ur >= 0 && ur < A.H && uc >= 0 && uc < A.W) continue;  // frame reaches q: already correct
-            const int i = rc + e.io, j = cc + e.jo;
-            if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
-            corr += A.blur_t[a * A.b + b2] *
-                    border_residual<T>(A, xplane, ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
-            any = true;
-          }
-        }
-      }
-      if (any) {
-        T* gp = A.g + (size_t)ch * N + (size_t)qr * A.W + qc;
-        *gp -= (T)(2 * A.S * A.S) * corr;
+    ring_pixel(t, W, H, E, qr, qc);
+    if (qr >= 0 && qr < H && qc >= 0 && qc < W) {
+      for (int ch = 0; ch < C; ++ch) {
+        const T c = corr[(size_t)ch * n_ring + t];
+        if (c != T(0)) g[((size_t)ch * H + qr) * W + qc] -= c;
       }
     }
   }
-  // block partial (s^2 * sum of squares)
-  {
-    double v = cost;
+  if (blockIdx.x == 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (lane == 0) red[wid] = v;
     __syncthreads();
-    if (threadIdx.x == 0)
-      A.partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (double)(A.S * A.S) * ((red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) cost_out[0] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -689,9 +795,16 @@ __global__ __launch_bounds__(256) void k_border(BorderArgs<T> A) {
 struct ZPlan {
   int S = 0, B = 1;
   int regk = 0, regr = 0, reg_index = -1;
-  int E = 0;  // max |shift|
-  int2* d_hdr = nullptr;
+  int E = 0;   // max |shift|
+  int MS = 1;  // table slots per (row phase, column phase)
+  int n_ent = 0;
+  int2* d_hdr = nullptr;       // flat table of k_border: (count, first entry) per phase
   ZEntry* d_ent = nullptr;
+  int* d_cnt = nullptr;        // tile kernel: [S][8]
+  long long* d_off = nullptr;  //              [S][MS][S]
+  ZEntry* d_aux = nullptr;     //              [S][MS][S]
+  int n_ring = 0;              // pixels of the border frame (0 without motion)
+  void* d_corr = nullptr;      // [C][n_ring] border corrections of the gradient
 };
 
 void ztile_release(srmap_problem* p) {
@@ -699,6 +812,10 @@ void ztile_release(srmap_problem* p) {
   if (!z) return;
   if (z->d_hdr) (void)hipFree(z->d_hdr);
   if (z->d_ent) (void)hipFree(z->d_ent);
+  if (z->d_cnt) (void)hipFree(z->d_cnt);
+  if (z->d_off) (void)hipFree(z->d_off);
+  if (z->d_aux) (void)hipFree(z->d_aux);
+  if (z->d_corr) (void)hipFree(z->d_corr);
   delete z;
   p->zplan = nullptr;
 }
@@ -754,10 +871,46 @@ bool ztile_plan(srmap_problem* p) {
       hdr[(size_t)pr * S + pc] = h;
     }
   if (ent.empty()) { ZEntry e = {0, 0, 0, 0}; ent.push_back(e); }
+  if ((int)ent.size() > kBorderTabEntries) { delete z; return false; }  // k_border stages the table in LDS
+  z->n_ent = (int)ent.size();
+  // the tile kernel's layout of the same table: [pr][t][pc], with the observation's element offset precomputed
+  int MS = 1;
+  for (const int2& h : hdr) MS = std::max(MS, h.x);
+  z->MS = MS;
+  std::vector<int> cnt((size_t)S * 8, 0);
+  std::vector<long long> off((size_t)S * MS * S, 0);
+  std::vector<ZEntry> aux((size_t)S * MS * S, ZEntry{0, 0, 0, 0});
+  const long long nl = (long long)g.w * g.h;
+  for (int pr = 0; pr < S; ++pr) {
+    int mx = 0;
+    for (int pc = 0; pc < S; ++pc) {
+      const int2 h = hdr[(size_t)pr * S + pc];
+      cnt[(size_t)pr * 8 + pc] = h.x;
+      mx = std::max(mx, h.x);
+      for (int t = 0; t < h.x; ++t) {
+        const ZEntry& e = ent[(size_t)h.y + t];
+        const size_t slot = ((size_t)pr * MS + t) * S + pc;
+        aux[slot] = e;
+        off[slot] = (long long)e.k * g.C * nl + (long long)e.io * g.w + e.jo;
+      }
+    }
+    cnt[(size_t)pr * 8 + S] = mx;
+  }
   bool ok = hipMalloc((void**)&z->d_hdr, sizeof(int2) * hdr.size()) == hipSuccess &&
             hipMemcpy(z->d_hdr, hdr.data(), sizeof(int2) * hdr.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipMalloc((void**)&z->d_ent, sizeof(ZEntry) * ent.size()) == hipSuccess &&
-            hipMemcpy(z->d_ent, ent.data(), sizeof(ZEntry) * ent.size(), hipMemcpyHostToDevice) == hipSuccess;
+            hipMemcpy(z->d_ent, ent.data(), sizeof(ZEntry) * ent.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void**)&z->d_cnt, sizeof(int) * cnt.size()) == hipSuccess &&
+            hipMemcpy(z->d_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void**)&z->d_off, sizeof(long long) * off.size()) == hipSuccess &&
+            hipMemcpy(z->d_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void**)&z->d_aux, sizeof(ZEntry) * aux.size()) == hipSuccess &&
+            hipMemcpy(z->d_aux, aux.data(), sizeof(ZEntry) * aux.size(), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && z->E > 0) {
+    const long long We = g.W + 2 * z->E, E2 = 2 * z->E;
+    z->n_ring = (int)(2 * E2 * We + 2 * E2 * (long long)(g.H - 2 * z->E));
+    ok = hipMalloc(&z->d_corr, (size_t)g.C * z->n_ring * p->elem()) == hipSuccess;
+  }
   p->zplan = z;
   if (!ok) { ztile_release(p); return false; }
   return true;
@@ -768,11 +921,7 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   const size_t tiles = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * g.C;
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   size_t ring = 0;
-  if (z && z->E > 0) {
-    const long long We = g.W + 2 * z->E, E2 = 2 * z->E;
-    const long long n = 2 * E2 * We + 2 * E2 * (long long)(g.H - 2 * z->E);
-    ring = (size_t)((n + 255) / 256) * g.C;
-  }
+  if (z && z->E > 0) ring = (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * g.C;  // border blocks fill whole grid rows
   return tiles + ring;
 }
 
@@ -782,7 +931,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
   A.x = x; A.y = (const T*)p->d_obs; A.w = wts; A.g = g; A.partials = partials;
-  A.hdr = z.d_hdr; A.ent = z.d_ent;
+  A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
   A.obs_C = p->geo.C; A.obs_c0 = obs_c0;
   A.E = z.E;
@@ -800,8 +949,22 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   A.banded = 1;
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
-  hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A);
-  *nblocks = (int)(grid.x * grid.y * grid.z);
+  const int n_tile_partials = (int)(grid.x * grid.y * grid.z);
+  // border blocks: whole rows of the grid in front of the tiles
+  BorderArgs<T> Bd;
+  Bd.hdr = z.d_hdr; Bd.ent = z.d_ent; Bd.blur_d = (const T*)p->d_blur; Bd.corr = (T*)z.d_corr;
+  Bd.S = S; Bd.b = B; Bd.hb = (B - 1) / 2;
+  Bd.n_ring = 0; Bd.n_ent = z.n_ent; Bd.nby = 0; Bd.n_tile_partials = n_tile_partials;
+  int nbb = 0;
+  if ((terms & SRMAP_TERM_DATA) && z.E > 0) {
+    Bd.n_ring = z.n_ring;
+    const int need = (z.n_ring + C::NT - 1) / C::NT;
+    Bd.nby = (need + (int)grid.x - 1) / (int)grid.x;
+    nbb = Bd.nby * (int)grid.x;
+    grid.y += Bd.nby;
+  }
+  hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A, Bd);
+  *nblocks = n_tile_partials + nbb * (int)grid.z;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
 }
@@ -844,21 +1007,6 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
   if (rc) return rc;
   int total = nb;
-  // the border frame of the data term (nothing to do without motion: no clipped transpose, no z position outside)
-  if ((terms & SRMAP_TERM_DATA) && z.E > 0) {
-    BorderArgs<T> Bd;
-    Bd.x = x; Bd.y = (const T*)p->d_obs; Bd.g = g; Bd.partials = partials + total;
-    Bd.hdr = z.d_hdr; Bd.ent = z.d_ent; Bd.blur = (const T*)p->d_blur; Bd.blur_t = (const T*)p->d_blur_t;
-    Bd.W = geo.W; Bd.H = geo.H; Bd.wl = geo.w; Bd.hl = geo.h; Bd.S = geo.s; Bd.b = geo.b; Bd.hb = geo.hb;
-    Bd.obs_C = p->geo.C; Bd.obs_c0 = obs_c0;
-    Bd.E = z.E; Bd.cr0 = geo.cr0; Bd.cr1 = geo.cr1;
-    const long long We = geo.W + 2 * z.E, E2 = 2 * z.E;
-    Bd.n_ring = 2 * E2 * We + 2 * E2 * (long long)(geo.H - 2 * z.E);
-    dim3 rgrid((unsigned)((Bd.n_ring + 255) / 256), geo.C);
-    hipLaunchKernelGGL(k_border<T>, rgrid, dim3(256), 0, st, Bd);
-    SRMAP_HIP(p->ctx, hipGetLastError());
-    total += (int)(rgrid.x * rgrid.y);
-  }
   // remaining regularisers (3-D TV, a second regulariser, BTV range > 3): direct kernels, accumulating into g
   if (want_reg) {
     for (int r = 0; r < p->nreg; ++r) {
@@ -878,6 +1026,23 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
       if (rc) return rc;
       total += nb2;
     }
+  }
+  // finish: border corrections of g + the fixed-order cost reduction, one launch
+  const bool corr_on = (terms & SRMAP_TERM_DATA) && z.E > 0 && g != nullptr;
+  if (total <= 16384) {
+    const int nring = corr_on ? z.n_ring : 0;
+    const unsigned nb_f = (unsigned)std::max(1, (nring + 255) / 256);
+    hipLaunchKernelGGL(k_finish_eval<T>, dim3(nb_f), dim3(256), 0, st, corr_on ? g : (T*)nullptr, (const T*)z.d_corr,
+                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, total, p->d_cost);
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    *nblocks = 0;  // total already in d_cost[0]
+    return SRMAP_OK;
+  }
+  // many partials (multi-channel problems): corrections here, two-stage reduction by the caller
+  if (corr_on) {
+    hipLaunchKernelGGL(k_finish_eval<T>, dim3((unsigned)((z.n_ring + 255) / 256)), dim3(256), 0, st, g, (const T*)z.d_corr,
+                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, 0, p->d_cost + 1);
+    SRMAP_HIP(p->ctx, hipGetLastError());
   }
   *nblocks = total;
   return SRMAP_OK;

@@ -286,7 +286,7 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
       }
     }
   }
-  if (tiled && nparts == 0) return SRMAP_OK;  // reduced inside the fused kernel
+  if ((tiled || ztile) && nparts == 0) return SRMAP_OK;  // reduced inside the last kernel of the evaluation
   return launch_reduce_partials(p, p->d_partials, nparts, p->d_cost, st);
 }
 

@@ -310,9 +310,11 @@ def test_solver_psnr_parity_with_cpu_reference(sr, ctx, dtype, reg):
     # f64 is the parity mode (0.01 dB); f32 storage changes the CG path enough
     # to move the stopping point, so its bound is looser
     assert abs(psnr_ref - psnr_gpu) < (0.01 if dtype == 0 else 0.05)
-    # the iterates follow the reference's up to reduction order; on the
-    # non-smooth TV/BTV objective that can move a stopping decision by a round
-    assert abs(rep.irls_rounds - rep_ref.irls_rounds) <= 2
+    # the iterates follow the reference's up to reduction order; on the non-smooth TV/BTV objective a last-bit
+    # difference can move the |cost difference| < threshold stopping decision by a few IRLS rounds (each late round
+    # changes the cost by ~the threshold), so the round count is only loosely bounded; the result is not affected
+    assert abs(rep.irls_rounds - rep_ref.irls_rounds) <= 4
+    assert abs(rep.final_cost - rep_ref.final_cost) <= 2e-3 * abs(rep_ref.final_cost)
 
 
 # --------------------------------------------- full-size property tests (cfg2)
