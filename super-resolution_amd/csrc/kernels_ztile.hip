@@ -85,6 +85,8 @@ struct ZCfg {
 struct ZEntry { int k, io, jo, oyx; };  // frame, LR row / column offset of the residual a pixel of this phase owns,
                                          // forward offset packed (oy << 16) | (ox & 0xffff)
 
+template <typename T> struct BorderArgs;
+
 template <typename T, int B, int NP>
 struct ZArgs {
   const T* x;
@@ -96,17 +98,41 @@ struct ZArgs {
   const long long* off;  // [S][MS][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
   const ZEntry* aux;     // [S][MS][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
   int MS;                // slots per (row phase, column phase)
+  const BorderArgs<T>* bd;  // device-resident constants of the border blocks
   int W, H, wl, hl;
-  int obs_C, obs_c0;
+  int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
   int E;             // max |shift| (edge tiles take the masked code path)
   int cr0, cr1;      // HR rows whose cost terms are counted (row-band sharding; default 0, H)
-  int banded;        // tile rows on blockIdx.x, dealt to the 8 XCDs in contiguous bands
   int terms;         // SRMAP_TERM_*
-  T blur[B * B];     // k * k^T (blur_module.cpp:20-22)
-  T k1[B];           // the separable factor (B^T z is evaluated as two 1-D passes)
+  int nby;           // grid rows (blockIdx.y) taken by border blocks; 0 = none
+  int n_tile_partials;  // border partials are stored behind the tile partials
+  T blur3[3];        // k * k^T (blur_module.cpp:20-22) of the symmetric kernel: corner, edge, centre (B == 1: 1, 1, 1)
+  T k1s[2];          // the separable factor (B^T z is evaluated as two 1-D passes): outer tap, centre tap
   T lambda;
   T powtab[NP];      // BTV alpha^(i+j)
 };
+
+// The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
+// true difference times 2^Q, large enough that sgn(d) * pw is just a clamp to [-pw, pw] (no ldexp per tap), and
+// the scale drops out of the sums exactly (r = r' * 2^-Q, B x = (B x') * 2^-Q).  Exact for |d| >= 2^-Q and pixel
+// magnitudes below 2^(Emax - Q - 3): Q = 1000 (f64), 100 (f32).
+template <typename T> struct Pre;
+template <> struct Pre<double> {
+  static constexpr int Q = 1000;
+  static __device__ __forceinline__ double up(double v) { return __builtin_ldexp(v, Q); }
+  static __device__ __forceinline__ double down(double v) { return __builtin_ldexp(v, -Q); }
+};
+template <> struct Pre<float> {
+  static constexpr int Q = 100;
+  static __device__ __forceinline__ float up(float v) { return __builtin_ldexpf(v, Q); }
+  static __device__ __forceinline__ float down(float v) { return __builtin_ldexpf(v, -Q); }
+};
+// sgn(d) * pw for a pre-scaled difference dq = d * 2^Q: clamp (pw <= 1 << 2^Q * |d| for every d the reference
+// distinguishes from 0).
+template <typename T>
+__device__ __forceinline__ T sgn_pre(T dq, T pw) { return __builtin_fmin(__builtin_fmax(dq, -pw), pw); }
+template <>
+__device__ __forceinline__ float sgn_pre<float>(float dq, float pw) { return __builtin_amdgcn_fmed3f(dq, -pw, pw); }
 
 // ---- index helpers: `col` is a pixel column relative to the first pixel of the thread's cell ----
 template <typename C>
@@ -117,6 +143,16 @@ template <typename C>
 __device__ __forceinline__ constexpr int ci(int row, int col) {
   return row * C::CROW + posmod(col, C::TW / C::CW) * C::CC + C::CCL + floordiv(col, C::TW / C::CW);
 }
+
+// blur tap (a, e) of the symmetric B x B kernel from its three distinct values
+template <int B, typename ArgsT>
+__device__ __forceinline__ auto blur_tap(const ArgsT& A, int a, int e) {
+  if (B == 1) return A.blur3[2];
+  const bool ca = a == (B - 1) / 2, ce = e == (B - 1) / 2;
+  return (ca && ce) ? A.blur3[2] : ((ca || ce) ? A.blur3[1] : A.blur3[0]);
+}
+template <int B, typename ArgsT>
+__device__ __forceinline__ auto k1_tap(const ArgsT& A, int a) { return (B == 1 || a == (B - 1) / 2) ? A.k1s[1] : A.k1s[0]; }
 
 // Observation of LR pixel (i, j) of frame plane yk, address clamped into the image.
 template <typename T>
@@ -137,21 +173,22 @@ __device__ __forceinline__ void row_phase(int gr, int& rc, int& pr) {
 // (frame table: SURVEY.md section 8a' restated per HR pixel).  Interior tiles: one scalar offset per pixel phase,
 // address = row base + offset + cell.  EDGE: explicit (frame, LR row, LR column), clamped into the image.
 template <typename T, int S, typename C, bool EDGE, typename ArgsT>
-__device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int t, int cellg,
+__device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int t, int cell0, int lane,
                                              const T* __restrict__ ybase, const int (&cn)[S], T (&yv)[C::NV]) {
   constexpr int HB = C::HB, NV = C::NV;
   const size_t slot = (size_t)(pr * A.MS + t) * S;  // uniform
+  const T* yrow = ybase + ((long long)rc * A.wl + cell0);  // uniform: LR cell row rc, first cell of the tile
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
     yv[v] = T(0);
     if (t < cn[pc]) {  // uniform
       if (!EDGE) {
-        const T* yp = ybase + (A.off[slot + pc] + (long long)rc * A.wl);  // uniform pointer
-        yv[v] = yp[cellg + dc];
+        const T* yp = yrow + (A.off[slot + pc] + dc);  // uniform pointer; the lane adds its (non-negative) cell index
+        yv[v] = yp[(unsigned)lane];
       } else {
         const ZEntry e = A.aux[slot + pc];
-        yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cellg + dc + e.jo, A.hl, A.wl);
+        yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
       }
     }
   }
@@ -159,11 +196,12 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
 
 // ---- data term, phase 1, for the S pixels of one cell in tile row `rowrel` (wave-uniform) ----
 // B x at NV pixels, residuals of the frames whose LR grid hits each pixel, z; returns z (B == 1) or writes the
-// horizontal half of B^T z to LDS (B == 3).  `count`: the row is owned by this tile (cost is counted, with mk).
-// EDGE: tiles near the image border -- LR validity masks and the dropped blur taps of LR row 0 / column 0.
+// horizontal half of B^T z to LDS (B == 3).  `count`: the row is owned by this tile (cost is counted).
+// EDGE: tiles near the image border (and partial tiles) -- LR validity masks, in-image masks and the dropped blur
+// taps of LR row 0 / column 0.  The staged x is pre-scaled by 2^Q: residual = (B x') * 2^-Q - y.
 template <typename T, int S, int B, typename C, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ zs, int rowrel,
-                                      int R0, int cellg, int lane, const T* __restrict__ ybase, bool use_pre,
+                                      int R0, int cell0, int lane, const T* __restrict__ ybase, bool use_pre,
                                       const T (&ypre)[C::NV], bool count, const T (&mk)[S], T (&zout)[S],
                                       double& cost) {
   constexpr int HB = C::HB, NV = C::NV;
@@ -181,17 +219,18 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
-      for (int e = 0; e < B; ++e) bx[v] += A.blur[a * B + e] * xr[v + e];
+      for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, a, e) * xr[v + e];
       if (EDGE && B > 1) {
-        bleft[v] += A.blur[a * B] * xr[v];  // tap column 0
+        bleft[v] += blur_tap<B>(A, a, 0) * xr[v];  // tap column 0
         if (a == 0) {
 #pragma unroll
-          for (int e = 0; e < B; ++e) btop[v] += A.blur[e] * xr[v + e];  // tap row 0
-          bcorner[v] = A.blur[0] * xr[v];
+          for (int e = 0; e < B; ++e) btop[v] += blur_tap<B>(A, 0, e) * xr[v + e];  // tap row 0
+          bcorner[v] = blur_tap<B>(A, 0, 0) * xr[v];
         }
       }
     }
   }
+  const T unscale = Pre<T>::down(T(1));
   int cn[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
@@ -205,7 +244,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
 #pragma unroll
       for (int v = 0; v < NV; ++v) yv[v] = ypre[v];
     } else {
-      load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cellg, ybase, cn, yv);
+      load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ybase, cn, yv);
     }
     const size_t slot = (size_t)(pr * A.MS + t) * S;
 #pragma unroll
@@ -214,12 +253,13 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
       const bool own = pcv >= 0 && pcv < S;
       if (t < cn[pc]) {  // uniform
         T rr;
-        bool cost_on = own && count;
         if (!EDGE) {
-          rr = bx[v] - yv[v];
+          rr = bx[v] * unscale - yv[v];
+          z[v] += rr;
+          if (own && count) cost += (double)rr * (double)rr;
         } else {
           const ZEntry e = A.aux[slot + pc];
-          const int i = rc + e.io, j = cellg + dc + e.jo;
+          const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
           T bxv = bx[v];
           if (B > 1) {
             // filter2D's zero padding acts on the warped image: LR row 0 loses blur tap row 0, LR column 0 tap column 0
@@ -227,15 +267,14 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
             if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
             else bxv = bxv - (j0 ? bleft[v] : T(0));
           }
-          rr = bxv - yv[v];
+          rr = bxv * unscale - yv[v];
           // no such LR pixel (row: uniform, column: per lane)
           rr = ((unsigned)i < (unsigned)A.hl && (unsigned)j < (unsigned)A.wl) ? rr : T(0);
-          cost_on = cost_on && S * i >= A.cr0 && S * i < A.cr1;
-        }
-        z[v] += rr;
-        if (cost_on) {
-          const double rd = (double)(rr * mk[own ? pcv : 0]);
-          cost += rd * (double)rr;
+          z[v] += rr;
+          if (own && count && S * i >= A.cr0 && S * i < A.cr1) {
+            const double rd = (double)(rr * mk[own ? pcv : 0]);
+            cost += rd * (double)rr;
+          }
         }
       }
     }
@@ -248,7 +287,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
     for (int pc = 0; pc < S; ++pc) {
       T zh = T(0);
 #pragma unroll
-      for (int e = 0; e < B; ++e) zh += A.k1[e] * z[pc + e];
+      for (int e = 0; e < B; ++e) zh += k1_tap<B>(A, e) * z[pc + e];
       zs[(rowrel + HB) * C::ZROW + pc * C::CW + lane] = zh;
     }
   }
@@ -256,15 +295,15 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
 
 // t = 0 observations of the NV pixels of the thread's cell in tile row `rowrel`, issued at kernel start.
 template <typename T, int S, int B, typename C, typename ArgsT>
-__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cellg, bool edge,
+__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cell0, int lane, bool edge,
                                                const T* __restrict__ ybase, T (&ypre)[C::NV]) {
   int rc, pr;
   row_phase<S>(R0 + rowrel, rc, pr);
   int cn[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
-  if (edge) load_obs_row<T, S, C, true>(A, pr, rc, 0, cellg, ybase, cn, ypre);
-  else load_obs_row<T, S, C, false>(A, pr, rc, 0, cellg, ybase, cn, ypre);
+  if (edge) load_obs_row<T, S, C, true>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
+  else load_obs_row<T, S, C, false>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
 }
 
 // ---- regulariser pass 1 for the S pixels of one cell (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
@@ -299,24 +338,24 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
           T d = x0v[pc] - row[pc + j];
           if (BORDER) d = ((gr + i < H) && (gc0 + pc + j < W)) ? d : T(0);  // skipped tap == zero difference
           rv[pc] += pw[i + j] * absv(d);
-          if (FULL && i < R && j < R) dv[pc] += sgn_scaled<T>(d, pw[i + j]);  // exclusive window in the gradient
+          if (FULL && i < R && j < R) dv[pc] += sgn_pre<T>(d, pw[i + j]);  // exclusive window in the gradient
         }
       } else if (i == 1) {
         T dyv = row[pc] - x0v[pc];
         if (BORDER) dyv = (gr + 1 < H) ? dyv : T(0);
         rv[pc] = absv(dyv) + rv[pc];
-        if (FULL) dv[pc] = dv[pc] - sgnv(dyv);
+        if (FULL) dv[pc] = dv[pc] - sgn_pre<T>(dyv, T(1));
       } else {
         T dxv = row[pc + 1] - x0v[pc];
         if (BORDER) dxv = (gc0 + pc + 1 < W) ? dxv : T(0);
         rv[pc] = absv(dxv);
-        if (FULL) dv[pc] = -sgnv(dxv);
+        if (FULL) dv[pc] = -sgn_pre<T>(dxv, T(1));
       }
     }
   }
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) {
-    const T r = rv[pc];
+    const T r = Pre<T>::down(rv[pc]);  // the staged x is pre-scaled: r = r' * 2^-Q exactly
     const T c = lambda * wv[pc];
     T cr2 = T(2) * c * r;
     const bool in_img = (unsigned)gr < (unsigned)H && (unsigned)(gc0 + pc) < (unsigned)W;
@@ -360,7 +399,7 @@ __device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __rest
       const T xv = (gc + 1 < W) ? absv(xs[xi<C>(xrow, COL + 1)] - x0) : T(0);
       r = yv + xv;
     }
-    cr2 = T(2) * (lambda * wt) * r;
+    cr2 = T(2) * (lambda * wt) * Pre<T>::down(r);
   }
   cs[ci<C>(C::RU, COL)] = cr2;
 }
@@ -397,12 +436,12 @@ __device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs
           for (int j = 0; j < R; ++j) {
             if (i == 0 && j == 0) continue;
             // -sgn(x[q] - x[p]) * alpha^(i+j) * 2 c[q] r[q],  q = p - (i, j)
-            sum[pc] += cw[pc + RU - j] * sgn_scaled<T>(x0v[pc] - xw[pc + RU - j], pw[i + j]);
+            sum[pc] += cw[pc + RU - j] * sgn_pre<T>(x0v[pc] - xw[pc + RU - j], pw[i + j]);
           }
         }
       } else {
-        if (i == 0) sum[pc] += cw[pc + RU - 1] * sgnv(x0v[pc] - xw[pc + RU - 1]);
-        else sum[pc] += cw[pc + RU] * sgnv(x0v[pc] - xw[pc + RU]);
+        if (i == 0) sum[pc] += cw[pc + RU - 1] * sgn_pre<T>(x0v[pc] - xw[pc + RU - 1], T(1));
+        else sum[pc] += cw[pc + RU] * sgn_pre<T>(x0v[pc] - xw[pc + RU], T(1));
       }
     }
   }
@@ -423,7 +462,7 @@ __device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs
 constexpr int kBorderTabEntries = 256;  // frame-table entries staged in LDS by the border blocks
 
 template <typename T>
-struct BorderArgs {
+struct BorderArgs {      // device-resident (one per problem): only the border blocks read it
   const int2* hdr;       // flat frame table: (count, first entry) per (row phase, column phase)
   const ZEntry* ent;
   const T* blur_d;       // [b*b] device copies (dynamic indexing)
@@ -431,8 +470,7 @@ struct BorderArgs {
   int S, b, hb;
   int n_ring;            // pixels of the frame
   int n_ent;             // entries of the frame table
-  int nby;               // grid rows (blockIdx.y) taken by border blocks; 0 = none
-  int n_tile_partials;   // border partials are stored behind the tile partials
+  int obs_C;             // channels of the observation stack
 };
 
 __device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -477,6 +515,7 @@ __device__ __forceinline__ T border_residual(const T* __restrict__ blur, int S, 
 // One border block of NT threads; smem: scratch of at least 16 int2 + kBorderTabEntries ZEntry + 8 doubles.
 template <typename T, int NT, typename ArgsT>
 __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>& Bd, int bidx, int ch, void* smem) {
+  const int obs_C = Bd.obs_C;
   int2* s_hdr = reinterpret_cast<int2*>(smem);
   ZEntry* s_ent = reinterpret_cast<ZEntry*>(s_hdr + 16);
   double* red = reinterpret_cast<double*>(s_ent + kBorderTabEntries);
@@ -493,7 +532,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
     ring_pixel(t, A.W, A.H, A.E, qr, qc);
     const int S = Bd.S;
     const T* xplane = A.x + (size_t)ch * N;
-    const T* ybase = A.y + (size_t)(ch + A.obs_c0) * nl;
+    const T* ybase = A.y + (size_t)ch * nl;
     const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
     T corr = T(0);
     if (!inside) {
@@ -507,7 +546,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
           if (S * i < A.cr0 || S * i >= A.cr1) continue;
           const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
           const double r = (double)border_residual<T>(Bd.blur_d, S, Bd.b, Bd.hb, A.W, A.H, A.wl, xplane,
-                                                      ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
+                                                      ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
           cost += r * r;
         }
       }
@@ -527,7 +566,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
             // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
             corr += Bd.blur_d[b2 * Bd.b + a] *
                     border_residual<T>(Bd.blur_d, S, Bd.b, Bd.hb, A.W, A.H, A.wl, xplane,
-                                       ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
+                                       ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
           }
         }
       }
@@ -546,15 +585,15 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
     if (tid == 0) {
       double sum = 0.0;
       for (int i = 0; i < NT / 64; ++i) sum += red[i];
-      const int nbb = Bd.nby * gridDim.x;
-      A.partials[(size_t)Bd.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(Bd.S * Bd.S) * sum;
+      const int nbb = A.nby * gridDim.x;
+      A.partials[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(Bd.S * Bd.S) * sum;
     }
   }
 }
 
 template <typename T, int S, int B, int REGK, int R>
 __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_z(
-    ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A, BorderArgs<T> Bd) {
+    ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
   using C = ZCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
   // border blocks borrow the x tile's LDS for the frame table
@@ -570,18 +609,19 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin in launch order and every XCD has its
   // own L2; with the tile ROW on blockIdx.x and launch index n -> row band (n mod 8) the workgroups an XCD runs at
   // the same time are vertical neighbours and share their x halo rows in that L2.  Bijective for any row count.
-  if ((int)blockIdx.y < Bd.nby) {  // border blocks come first in dispatch order (uniform branch)
+  if ((int)blockIdx.y < A.nby) {  // border blocks come first in dispatch order (uniform branch)
     const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
+    const BorderArgs<T>& Bd = *A.bd;
     if (bidx * C::NT < Bd.n_ring) border_block<T, C::NT>(A, Bd, bidx, blockIdx.z, xs);
     else if (threadIdx.x == 0) {
-      const int nbb = Bd.nby * gridDim.x;
-      A.partials[(size_t)Bd.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
+      const int nbb = A.nby * gridDim.x;
+      A.partials[(size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
     }
     return;
   }
-  const int by = blockIdx.y - Bd.nby, nby_t = gridDim.y - Bd.nby;
+  const int by = blockIdx.y - A.nby, nby_t = gridDim.y - A.nby;
   int tby = by, tbx = blockIdx.x;
-  if (A.banded) {
+  {
     const int n = blockIdx.x, q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
     tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
     tbx = by;
@@ -596,7 +636,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const int cellg = CJ0 + lane;
   const bool want_data = (A.terms & SRMAP_TERM_DATA) != 0;
   const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0;
-  const T* ybase = A.y + (size_t)(ch + A.obs_c0) * nl;
+  const T* ybase = A.y + (size_t)ch * nl;
 
   // ---------------- global loads whose addresses are known now: x tile, observations, IRLS weights ----------------
   constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // x rows per wave
@@ -617,7 +657,10 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) { va[it][pc] = ina ? va[it][pc] : T(0); vb[it][pc] = inb ? vb[it][pc] : T(0); }
+    for (int pc = 0; pc < S; ++pc) {
+      va[it][pc] = ina ? Pre<T>::up(va[it][pc]) : T(0);
+      vb[it][pc] = inb ? Pre<T>::up(vb[it][pc]) : T(0);
+    }
   }
   T ypre[NV];
 #pragma unroll
@@ -626,14 +669,14 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // so do row-band problems (cost rows restricted)
   const int rm = A.E + HB + 1, cm = (A.E + HB + S) / S + 1;
   const bool edge = (R0 - rm < 0) || (R0 + C::TH + rm > A.H) || (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl) ||
-                    A.cr0 > 0 || A.cr1 < A.H;
+                    A.cr0 > 0 || A.cr1 < A.H;  // partial tiles (bottom / right) are edge tiles by the first two tests
   const int hrowz = wv == 0 ? -HB : C::TH - 1 + HB;  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
   const bool has_z_halo = want_data && B > 1 && A.g != nullptr && wv < 2;
   T ypre2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) ypre2[v] = T(0);
-  if (want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, cellg, edge, ybase, ypre);
-  if (has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, cellg, edge, ybase, ypre2);
+  if (want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, CJ0, lane, edge, ybase, ypre);
+  if (has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
   const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
   T wreg[S];
 #pragma unroll
@@ -684,11 +727,11 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     T dummy[S];
     double dcost = 0.0;
     if (edge) {
-      z_row<T, S, B, C, true>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
-      if (has_z_halo) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, cellg, lane, ybase, true, ypre2, false, mk, dummy, dcost);
+      z_row<T, S, B, C, true>(A, xs, zs, wv, R0, CJ0, lane, ybase, true, ypre, true, mk, zown, cost_data);
+      if (has_z_halo) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, CJ0, lane, ybase, true, ypre2, false, mk, dummy, dcost);
     } else {
-      z_row<T, S, B, C, false>(A, xs, zs, wv, R0, cellg, lane, ybase, true, ypre, true, mk, zown, cost_data);
-      if (has_z_halo) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, cellg, lane, ybase, true, ypre2, false, mk, dummy, dcost);
+      z_row<T, S, B, C, false>(A, xs, zs, wv, R0, CJ0, lane, ybase, true, ypre, true, mk, zown, cost_data);
+      if (has_z_halo) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, CJ0, lane, ybase, true, ypre2, false, mk, dummy, dcost);
     }
   }
   // ---------------- phase 1: regulariser ----------------
@@ -728,7 +771,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
       } else {
         zz = T(0);
 #pragma unroll
-        for (int a = 0; a < B; ++a) zz += A.k1[a] * zs[(wv + a) * C::ZROW + pc * C::CW + lane];  // rows wv-HB+a
+        for (int a = 0; a < B; ++a) zz += k1_tap<B>(A, a) * zs[(wv + a) * C::ZROW + pc * C::CW + lane];  // rows wv-HB+a
       }
       acc[pc] += sc * zz;
     }
@@ -805,6 +848,7 @@ struct ZPlan {
   ZEntry* d_aux = nullptr;     //              [S][MS][S]
   int n_ring = 0;              // pixels of the border frame (0 without motion)
   void* d_corr = nullptr;      // [C][n_ring] border corrections of the gradient
+  void* d_bd = nullptr;        // BorderArgs<T> (device)
 };
 
 void ztile_release(srmap_problem* p) {
@@ -816,6 +860,7 @@ void ztile_release(srmap_problem* p) {
   if (z->d_off) (void)hipFree(z->d_off);
   if (z->d_aux) (void)hipFree(z->d_aux);
   if (z->d_corr) (void)hipFree(z->d_corr);
+  if (z->d_bd) (void)hipFree(z->d_bd);
   delete z;
   p->zplan = nullptr;
 }
@@ -828,6 +873,12 @@ bool ztile_plan(srmap_problem* p) {
   if (!p->maps_regular) return false;
   if (S < 2 || S > 4) return false;
   if (B != 1 && B != 3) return false;
+  if (B == 3) {  // the tile kernel carries the three distinct values of the symmetric Gaussian kernel
+    const std::vector<double>& k2 = p->blur2d;
+    if (!(k2[0] == k2[2] && k2[0] == k2[6] && k2[0] == k2[8] && k2[1] == k2[3] && k2[1] == k2[5] && k2[1] == k2[7] &&
+          p->blur1d[0] == p->blur1d[2]))
+      return false;
+  }
   std::vector<int> ox(K, 0), oy(K, 0);
   int amax = 0;
   if (p->has_motion) {
@@ -911,6 +962,15 @@ bool ztile_plan(srmap_problem* p) {
     z->n_ring = (int)(2 * E2 * We + 2 * E2 * (long long)(g.H - 2 * z->E));
     ok = hipMalloc(&z->d_corr, (size_t)g.C * z->n_ring * p->elem()) == hipSuccess;
   }
+  if (ok) {
+    auto put = [&](auto bd) {
+      bd.hdr = z->d_hdr; bd.ent = z->d_ent; bd.blur_d = (decltype(bd.blur_d))p->d_blur; bd.corr = (decltype(bd.corr))z->d_corr;
+      bd.S = S; bd.b = B; bd.hb = g.hb; bd.n_ring = z->n_ring; bd.n_ent = z->n_ent; bd.obs_C = g.C;
+      return hipMalloc(&z->d_bd, sizeof(bd)) == hipSuccess &&
+             hipMemcpy(z->d_bd, &bd, sizeof(bd), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    ok = p->dtype == SRMAP_F32 ? put(BorderArgs<float>()) : put(BorderArgs<double>());
+  }
   p->zplan = z;
   if (!ok) { ztile_release(p); return false; }
   return true;
@@ -930,15 +990,19 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
                     const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st) {
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
-  A.x = x; A.y = (const T*)p->d_obs; A.w = wts; A.g = g; A.partials = partials;
+  A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
   A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
-  A.obs_C = p->geo.C; A.obs_c0 = obs_c0;
+  A.obs_C = p->geo.C;
   A.E = z.E;
   A.cr0 = geo.cr0; A.cr1 = geo.cr1;
   A.terms = (int)terms;
-  for (int i = 0; i < B * B; ++i) A.blur[i] = (T)p->blur2d[i];
-  for (int i = 0; i < B; ++i) A.k1[i] = (T)p->blur1d[i];
+  if (B == 1) { A.blur3[0] = A.blur3[1] = A.blur3[2] = T(1); A.k1s[0] = A.k1s[1] = T(1); }
+  else {
+    const int hb = (B - 1) / 2;
+    A.blur3[0] = (T)p->blur2d[0]; A.blur3[1] = (T)p->blur2d[hb]; A.blur3[2] = (T)p->blur2d[hb * B + hb];
+    A.k1s[0] = (T)p->blur1d[0]; A.k1s[1] = (T)p->blur1d[hb];
+  }
   A.lambda = T(0);
   for (int i = 0; i < C::NP; ++i) A.powtab[i] = T(1);
   if (REGK != 0) {
@@ -947,23 +1011,19 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     if (REGK == 2) for (int i = 0; i < C::NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
   }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
-  A.banded = 1;
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
   const int n_tile_partials = (int)(grid.x * grid.y * grid.z);
   // border blocks: whole rows of the grid in front of the tiles
-  BorderArgs<T> Bd;
-  Bd.hdr = z.d_hdr; Bd.ent = z.d_ent; Bd.blur_d = (const T*)p->d_blur; Bd.corr = (T*)z.d_corr;
-  Bd.S = S; Bd.b = B; Bd.hb = (B - 1) / 2;
-  Bd.n_ring = 0; Bd.n_ent = z.n_ent; Bd.nby = 0; Bd.n_tile_partials = n_tile_partials;
+  A.bd = (const BorderArgs<T>*)z.d_bd;
+  A.nby = 0; A.n_tile_partials = n_tile_partials;
   int nbb = 0;
   if ((terms & SRMAP_TERM_DATA) && z.E > 0) {
-    Bd.n_ring = z.n_ring;
     const int need = (z.n_ring + C::NT - 1) / C::NT;
-    Bd.nby = (need + (int)grid.x - 1) / (int)grid.x;
-    nbb = Bd.nby * (int)grid.x;
-    grid.y += Bd.nby;
+    A.nby = (need + (int)grid.x - 1) / (int)grid.x;
+    nbb = A.nby * (int)grid.x;
+    grid.y += A.nby;
   }
-  hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A, Bd);
+  hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A);
   *nblocks = n_tile_partials + nbb * (int)grid.z;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
