@@ -202,19 +202,85 @@ typedef struct {
   double final_cost;
 } srmap_solve_report;
 
-/* Hook for multi-GPU solves where each rank holds a shard of the unknowns
- * (channel or row sharding): sums `n` doubles in place across ranks.  NULL for
- * single-GPU solves. */
-typedef void (*srmap_allreduce_fn)(double* values, int n, void* user);
-
 /* IRLSMapSolver::Solve(initial_estimate) irls_map_solver.cpp:192-265:
  * x0 / x_out are [C][H][W] host doubles.  The iterate, gradient and CG vectors
  * stay on the GPU; only scalars cross PCIe per evaluation. */
 int srmap_solve(srmap_problem* p, const srmap_irls_options* options,
                 const double* x0, double* x_out, srmap_solve_report* report);
-int srmap_solve_ex(srmap_problem* p, const srmap_irls_options* options,
-                   const double* x0, double* x_out, srmap_solve_report* report,
-                   srmap_allreduce_fn allreduce, void* user);
+
+/* ------------------------------------------------- multi-GPU (one rank per GPU) */
+/* The reference is single-process.  Its objective shards three ways (SURVEY.md
+ * section 8e); a communicator carries the exchanges the sharded evaluation and the
+ * sharded solve need, INSIDE the library, on the evaluation's HIP stream:
+ *   - RCCL over xGMI (the production backend, ncclAllReduce / ncclSend / ncclRecv),
+ *   - or caller-supplied host callbacks (MPI / gloo harnesses and the one-GPU
+ *     tests: the library stages device buffers through pinned host memory). */
+typedef struct srmap_comm srmap_comm;
+#define SRMAP_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to every rank. */
+int srmap_comm_get_unique_id(srmap_ctx* ctx, char* id128);
+/* ncclCommInitRank on this context's device. */
+int srmap_comm_create_rccl(srmap_ctx* ctx, const char* id128, int rank, int world,
+                           srmap_comm** out);
+/* op: 0 = sum, 1 = max.  dtype: srmap_dtype of the elements.  In place, all ranks. */
+typedef int (*srmap_host_allreduce_fn)(void* buf, size_t count, int dtype, int op, void* user);
+/* Send `send_bytes` to rank dst (skip if dst < 0) and receive `recv_bytes` from rank
+ * src (skip if src < 0); must not deadlock when every rank calls it at once. */
+typedef int (*srmap_host_sendrecv_fn)(const void* send, size_t send_bytes, int dst,
+                                      void* recv, size_t recv_bytes, int src, void* user);
+int srmap_comm_create_host(srmap_ctx* ctx, int rank, int world,
+                           srmap_host_allreduce_fn allreduce,
+                           srmap_host_sendrecv_fn sendrecv, void* user, srmap_comm** out);
+void srmap_comm_destroy(srmap_comm* comm);
+/* In-place all-reduce of a device buffer (op 0 = sum, 1 = max) on `hip_stream`: what the sharded evaluation
+ * and solver use internally, exposed for harnesses. */
+int srmap_comm_allreduce(srmap_comm* comm, void* dev_buf, size_t count, int dtype, int op,
+                         void* hip_stream);
+
+typedef enum {
+  SRMAP_SHARD_NONE = 0,
+  SRMAP_SHARD_FRAMES = 1,   /* rank owns a frame subset + a replica of x: all-reduce of the
+                               gradient (C*N elements) and of the cost after every
+                               evaluation (objective_data_term.cpp:98-116 summed over ranks) */
+  SRMAP_SHARD_ROWS = 2,     /* rank owns a band of HR rows; its problem is the band + halo
+                               rows; halo rows of x are exchanged with the two neighbours
+                               before every evaluation, scalars all-reduced */
+  SRMAP_SHARD_CHANNELS = 3  /* rank owns a channel block (+ one halo channel plane per
+                               neighbour when a 3-D TV regulariser couples them,
+                               tv_regularizer.cpp:205-222); scalars all-reduced */
+} srmap_shard_mode;
+
+typedef struct {
+  int mode;                        /* srmap_shard_mode */
+  int own_row0, own_row1;          /* ROWS: HR rows of THIS problem the rank owns (the rest is halo) */
+  int send_up_rows, send_down_rows;/* ROWS: owned boundary rows the upper / lower neighbour's halo holds */
+  int own_ch0, own_ch1;            /* CHANNELS: channels of THIS problem the rank owns (others: halo planes) */
+  int reg_rank;                    /* FRAMES: the rank whose evaluation carries the regulariser terms */
+} srmap_shard_desc;
+
+/* One ObjectiveFunction::ComputeAllTerms of the JOINT objective on device buffers of
+ * this rank's shard: halo exchange (ROWS / CHANNELS), the local evaluation, the
+ * gradient all-reduce (FRAMES) and -- when cost != NULL -- the all-reduced cost.
+ * comm == NULL or mode NONE: plain srmap_eval_device. */
+int srmap_eval_sharded_device(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard,
+                              unsigned terms, void* x_dev, void* g_dev, double* cost,
+                              void* hip_stream);
+/* IRLSMapSolver::Solve of the joint problem with the unknowns sharded as described:
+ * every rank calls it with its shard of x0 and receives its shard of the result (halo
+ * rows / planes of x_out are valid copies of the neighbours' values).  The CG scalars
+ * (dot products, max-norm) are reduced over owned elements only and all-reduced, so
+ * every rank follows the trajectory of the single-GPU solve up to reduction order. */
+int srmap_solve_sharded(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard,
+                        const srmap_irls_options* options, const double* x0, double* x_out,
+                        srmap_solve_report* report);
+
+/* One run of the nonlinear CG (alglib_objective.cpp:47-75 / mincg, no IRLS re-weighting) on
+ * the problem's current objective, with the cost of EVERY evaluation recorded in order
+ * (f_trace[0 .. min(*trace_len, trace_cap))): the trajectory the parity tests compare with
+ * ALGLIB's.  epsg / epsf / epsx / maxits are mincgsetcond's arguments. */
+int srmap_cg_trace(srmap_problem* p, double epsg, double epsf, double epsx, int maxits,
+                   const double* x0, double* x_out, int* iterations, int* nfev,
+                   int* termination, double* f_trace, int trace_cap, int* trace_len);
 
 #ifdef __cplusplus
 }

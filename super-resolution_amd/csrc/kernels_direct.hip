@@ -188,7 +188,7 @@ __device__ __forceinline__ T absval(T v) { return v < T(0) ? -v : v; }
 template <typename T>
 __device__ __forceinline__ T reg_value_at(const T* __restrict__ x, int W, int H, int C,
                                           int c, int r, int col, int kind, int range,
-                                          const PowTable& pw) {
+                                          const PowTable& pw, int zhi = 0) {
   const size_t N = (size_t)W * H;
   const T* plane = x + (size_t)c * N;
   const T x0 = plane[(size_t)r * W + col];
@@ -208,7 +208,7 @@ __device__ __forceinline__ T reg_value_at(const T* __restrict__ x, int W, int H,
   const T yv = (r + 1 < H) ? absval(plane[(size_t)(r + 1) * W + col] - x0) : T(0);
   const T xv = (col + 1 < W) ? absval(plane[(size_t)r * W + col + 1] - x0) : T(0);
   T tv = yv + xv;
-  if (kind == SRMAP_REG_TV3D && c + 1 < C) tv += absval(plane[N + (size_t)r * W + col] - x0);
+  if (kind == SRMAP_REG_TV3D && (c + 1 < C || zhi)) tv += absval(plane[N + (size_t)r * W + col] - x0);
   return tv;
 }
 
@@ -216,12 +216,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_reg_values(const T* __restrict__ x,
                                                    T* __restrict__ values, int W, int H,
                                                    int C, int kind, int range,
-                                                   PowTable pw) {
+                                                   PowTable pw, int zhi) {
   const int hp = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
   if (hp >= W * H) return;
   const int r = hp / W, col = hp - r * W;
-  values[(size_t)c * W * H + hp] = reg_value_at(x, W, H, C, c, r, col, kind, range, pw);
+  values[(size_t)c * W * H + hp] = reg_value_at(x, W, H, C, c, r, col, kind, range, pw, zhi);
 }
 
 static PowTable make_pow(const RegSpec& rs) {
@@ -235,7 +235,7 @@ int launch_reg_values(srmap_problem* p, const Geometry& g, const RegSpec& rs,
                       const T* x, T* values, hipStream_t st) {
   dim3 grid((g.W * g.H + 255) / 256, g.C);
   hipLaunchKernelGGL(k_reg_values<T>, grid, dim3(256), 0, st, x, values, g.W, g.H, g.C,
-                     rs.kind, rs.range, make_pow(rs));
+                     rs.kind, rs.range, make_pow(rs), g.zhi);
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
 }
@@ -339,7 +339,7 @@ template <typename T, bool D3>
 __global__ __launch_bounds__(256) void k_tv_onepass(const T* __restrict__ x, const T* __restrict__ gc, T gc_scale,
                                                     T* __restrict__ gout, int accumulate,
                                                     double* __restrict__ partials, int W, int H, int C, int cr0,
-                                                    int cr1) {
+                                                    int cr1, int zlo, int zhi) {
   __shared__ double red[4];
   constexpr int P = 4;
   const int c0 = (blockIdx.x * 64 + threadIdx.x) * P, r = blockIdx.y * 4 + threadIdx.y, c = blockIdx.z;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_tv_onepass(const T* __restrict__ x, con
     row(plane, r, c0 - 1, P + 2, xc, T(0));      // columns c0-1 .. c0+4
     row(plane, r + 1, c0 - 1, P + 1, xd, T(0));  // c0-1 .. c0+3
     row(plane, r - 1, c0, P + 1, xu, T(0));      // c0 .. c0+4
-    const bool has_next = D3 && c + 1 < C, has_prev = D3 && c > 0;
+    const bool has_next = D3 && (c + 1 < C || zhi), has_prev = D3 && (c > 0 || zlo);
     if (has_next) { row(plane + N, r, c0 - 1, P + 1, xn, T(0)); row(plane + N, r - 1, c0, P, xnu, T(0)); }
     if (has_prev) { row(plane - N, r, c0, P + 1, xp, T(0)); row(plane - N, r + 1, c0, P, xpd, T(0)); }
     if (gcp) {
@@ -441,10 +441,10 @@ int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegS
     dim3 grid2((geo.W + 255) / 256, (geo.H + 3) / 4, geo.C);
     if (rs.kind == SRMAP_REG_TV3D)
       hipLaunchKernelGGL((k_tv_onepass<T, true>), grid2, dim3(64, 4), 0, st, x, gc, (T)gc_scale, g, accumulate ? 1 : 0,
-                         partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1);
+                         partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1, geo.zlo, geo.zhi);
     else
       hipLaunchKernelGGL((k_tv_onepass<T, false>), grid2, dim3(64, 4), 0, st, x, gc, (T)gc_scale, g, accumulate ? 1 : 0,
-                         partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1);
+                         partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1, 0, 0);
     if (nblocks) *nblocks = (int)(grid2.x * grid2.y * grid2.z);
     SRMAP_HIP(p->ctx, hipGetLastError());
     return SRMAP_OK;

@@ -1,20 +1,34 @@
 // solver.hip -- IRLSMapSolver::Solve on the GPU (irls_map_solver.cpp:45-157,
 // 192-265) with the nonlinear CG the reference obtains from ALGLIB 3.10.0
 // (mincg, default settings: DY/HS hybrid beta, More'-Thuente line search,
-// libs/alglib/src/optimization.cpp:17137-17880, alglibinternal.cpp:12313-12632).
+// libs/alglib/src/optimization.cpp:17137-17880, alglibinternal.cpp:12313-12632),
+// single-GPU or sharded over one rank per GPU.
 //
 // Every n-vector (iterate, gradient, directions, line-search base point) lives
-// in HBM and is touched only by the kernels below; per evaluation only the
-// scalars f and g.d cross PCIe.  The control flow (step selection, stopping
-// rules) runs on the host, in double, in ALGLIB's order of operations so that
-// the trajectory follows the reference's up to reduction order.
+// in HBM and is touched only by the kernels below.  The control flow (step
+// selection, stopping rules) runs on the host, in double, in ALGLIB's order of
+// operations, so that the trajectory follows the reference's up to reduction
+// order.  Per CG iteration the host waits for the device 2 + nfev times: once
+// for (g.d, d.d, direction norms), once per trial point for (f, g.d), once for
+// the beta dot products; the n-vector work is three fused passes:
+//   k_direction      dn = -g + beta dk, yk = -g, partials of max|dn| and dn.dn
+//   k_normalize_dots d = (dn / max|dn|) / ||dn / max|dn|||, partials of g.d, d.d
+//                    (the two scale factors are computed on the device from
+//                    the reduced norms: no host round trip in between)
+//   k_beta_dots      yk += g, partials of yk.dk, g.g, g.yk
+// plus x = xk + stp d and g.d per trial point.
+//
+// Sharding.  Reductions run over the elements a rank OWNS (row band or channel
+// block; everything for frame shards) and are all-reduced through the
+// communicator (sum, and max for the max-norm), so every rank takes the same
+// decisions; x halos are refreshed before every evaluation (comm.hpp).
 #include <chrono>
-#include <utility>
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
-#include "srmap_internal.hpp"
+#include "comm.hpp"
 
 namespace srmap {
 
@@ -31,55 +45,61 @@ __device__ __forceinline__ double wmax(double v) {
 
 constexpr int kRedBlocks = 1024;
 
-// Up to three dot products in one pass (pairs (a0,b0), (a1,b1), (a2,b2));
-// block partials -> part[3][gridDim.x].  Products and sums in double.
-template <typename T>
-__global__ __launch_bounds__(256) void k_dots(const T* __restrict__ a0, const T* __restrict__ b0,
-                                             const T* __restrict__ a1, const T* __restrict__ b1,
-                                             const T* __restrict__ a2, const T* __restrict__ b2,
-                                             size_t n, double* __restrict__ part) {
-  __shared__ double red[3][4];
-  double s0 = 0, s1 = 0, s2 = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    s0 += (double)a0[i] * (double)b0[i];
-    if (a1) s1 += (double)a1[i] * (double)b1[i];
-    if (a2) s2 += (double)a2[i] * (double)b2[i];
+// Which elements of an n-vector a rank owns: element range [e0, e1) (channel block) and, inside each H x W plane,
+// rows [r0, r1) (row band).  on == 0: everything.
+struct Owned {
+  size_t e0, e1;
+  int W, H, r0, r1;
+  int on;
+  __device__ __forceinline__ bool has(size_t i) const {
+    if (!on) return true;
+    if (i < e0 || i >= e1) return false;
+    const int row = (int)((i / (size_t)W) % (size_t)H);
+    return row >= r0 && row < r1;
   }
-  s0 = wsum(s0); s1 = wsum(s1); s2 = wsum(s2);
+};
+
+// block partials of up to 3 sums: part[k * gridDim.x + blockIdx.x]
+__device__ __forceinline__ void block_partials3(double s0, double s1, double s2, double* __restrict__ part, bool max0) {
+  __shared__ double red[3][4];
+  s0 = max0 ? wmax(s0) : wsum(s0);
+  s1 = wsum(s1);
+  s2 = wsum(s2);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { red[0][wid] = s0; red[1][wid] = s1; red[2][wid] = s2; }
   __syncthreads();
   if (threadIdx.x < 3) {
     const double* r = red[threadIdx.x];
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
+    const double v = (threadIdx.x == 0 && max0) ? fmax(fmax(r[0], r[1]), fmax(r[2], r[3])) : (r[0] + r[1]) + (r[2] + r[3]);
+    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
   }
 }
 
-// max |a_i| block partials -> part[gridDim.x]
+// dn = -g + beta * dk ; yk = -g ; partials: [0] max |dn| (owned), [1] dn.dn (owned)
 template <typename T>
-__global__ __launch_bounds__(256) void k_absmax(const T* __restrict__ a, size_t n,
-                                               double* __restrict__ part) {
-  __shared__ double red[4];
-  double m = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    m = fmax(m, fabs((double)a[i]));
-  m = wmax(m);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (lane == 0) red[wid] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+__global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, T* __restrict__ yk, const T* __restrict__ g,
+                                                  const T* __restrict__ dk, T beta, size_t n, Owned ow,
+                                                  double* __restrict__ part) {
+  double mx = 0, ss = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const T gi = g[i];
+    T v = -gi;
+    if (dk != nullptr) v += beta * dk[i];
+    dn[i] = v;
+    yk[i] = -gi;
+    if (ow.has(i)) { mx = fmax(mx, fabs((double)v)); ss += (double)v * (double)v; }
+  }
+  block_partials3(mx, ss, 0.0, part, true);
 }
 
-// Second stage: rows x nb partials -> out[rows] (sum or max), fixed order.
-// `out` may be host-mapped pinned memory (the CG loop reads it after one stream
-// sync, no copy kernels); extra_src, when given, is one more device scalar (the
-// cost of the evaluation) forwarded to out[rows].
-__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ part, int nb, int rows,
-                                               int is_max, double* __restrict__ out,
-                                               const double* __restrict__ extra_src) {
+// Second stage: rows x nb partials -> out[rows] in fixed order; row 0 is a max when max0.  extra_src, when given,
+// is one more device scalar (the cost of the evaluation) forwarded to out[rows].
+__global__ __launch_bounds__(256) void k_finish(const double* __restrict__ part, int nb, int rows, int max0,
+                                               double* __restrict__ out, const double* __restrict__ extra_src) {
   __shared__ double red[4];
   if (extra_src != nullptr && threadIdx.x == 0) out[rows] = extra_src[0];
   for (int r = 0; r < rows; ++r) {
+    const bool is_max = max0 && r == 0;
     double v = 0;
     for (int i = threadIdx.x; i < nb; i += 256)
       v = is_max ? fmax(v, part[(size_t)r * nb + i]) : v + part[(size_t)r * nb + i];
@@ -89,36 +109,60 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ part,
     if (lane == 0) red[wid] = v;
     __syncthreads();
     if (threadIdx.x == 0)
-      out[r] = is_max ? fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))
-                      : (red[0] + red[1]) + (red[2] + red[3]);
+      out[r] = is_max ? fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
-// dst = alpha * src
+// linminnormalized (alglibinternal.cpp:12165-12196): d = (dn * s1) * s2 with s1 = 1 / max|dn| and
+// s2 = 1 / sqrt(sum (dn s1)^2); the sum is taken as (dn.dn) * s1^2 from the pass that produced dn.  norms = device
+// {max|dn|, dn.dn} (already all-reduced); every thread derives the same two factors.  Partials: [0] g.d, [1] d.d.
+// Block 0 publishes s1, s2 in scal_out[0..1] for the host's step scaling.
 template <typename T>
-__global__ void k_scale_copy(T* __restrict__ dst, const T* __restrict__ src, T alpha, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = alpha * src[i];
+__global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const T* __restrict__ dn, const T* __restrict__ g,
+                                                       const double* __restrict__ norms, size_t n, Owned ow,
+                                                       double* __restrict__ part, double* __restrict__ scal_out) {
+  const double mx = norms[0], ss = norms[1];
+  double s1 = 1.0, s2 = 1.0;
+  if (mx != 0.0) { s1 = 1.0 / mx; s2 = 1.0 / sqrt(ss * s1 * s1); }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal_out[0] = s1; scal_out[1] = s2; }
+  double gd = 0, dd = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const T v = mx != 0.0 ? (T)(((double)dn[i] * s1) * s2) : dn[i];
+    d[i] = v;
+    if (ow.has(i)) { gd += (double)g[i] * (double)v; dd += (double)v * (double)v; }
+  }
+  block_partials3(gd, dd, 0.0, part, false);
 }
+
+// yk += g ; partials: [0] yk.dk, [1] g.g, [2] g.yk   (mincg's DY / HS betas, optimization.cpp:17700-17760)
+template <typename T>
+__global__ __launch_bounds__(256) void k_beta_dots(T* __restrict__ yk, const T* __restrict__ g, const T* __restrict__ dk,
+                                                  size_t n, Owned ow, double* __restrict__ part) {
+  double a = 0, b = 0, c = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const T gi = g[i];
+    const T y = yk[i] + gi;
+    yk[i] = y;
+    if (ow.has(i)) { a += (double)y * (double)dk[i]; b += (double)gi * (double)gi; c += (double)gi * (double)y; }
+  }
+  block_partials3(a, b, c, part, false);
+}
+
+// partial of a.b over the owned elements: [0]
+template <typename T>
+__global__ __launch_bounds__(256) void k_dot(const T* __restrict__ a, const T* __restrict__ b, size_t n, Owned ow,
+                                            double* __restrict__ part) {
+  double s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    if (ow.has(i)) s += (double)a[i] * (double)b[i];
+  block_partials3(s, 0.0, 0.0, part, false);
+}
+
 // dst = a + alpha * b
 template <typename T>
-__global__ void k_axpy_out(T* __restrict__ dst, const T* __restrict__ a, const T* __restrict__ b,
-                           T alpha, size_t n) {
+__global__ void k_axpy_out(T* __restrict__ dst, const T* __restrict__ a, const T* __restrict__ b, T alpha, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = a[i] + alpha * b[i];
-}
-// dn = -g + beta * dk
-template <typename T>
-__global__ void k_new_direction(T* __restrict__ dn, const T* __restrict__ g, const T* __restrict__ dk,
-                                T beta, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { T v = -g[i]; v += beta * dk[i]; dn[i] = v; }
-}
-// d = (dk * s1) * s2   (linminnormalized's two scalings, alglibinternal.cpp:12165-12196)
-template <typename T>
-__global__ void k_scale2(T* __restrict__ d, const T* __restrict__ dk, T s1, T s2, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) d[i] = (dk[i] * s1) * s2;
 }
 template <typename T>
 __global__ void k_fill(T* __restrict__ d, T v, size_t n) {
@@ -126,20 +170,105 @@ __global__ void k_fill(T* __restrict__ d, T v, size_t n) {
   if (i < n) d[i] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// sharded evaluation (comm.hpp)
+int shard_exchange_x(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, void* x_dev, hipStream_t st) {
+  if (!c || !sd || comm_world(c) <= 1) return SRMAP_OK;
+  const Geometry& g = p->geo;
+  const size_t N = (size_t)g.W * g.H, es = p->elem();
+  const int rank = comm_rank(c), world = comm_world(c);
+  const int up = rank > 0 ? rank - 1 : -1, down = rank + 1 < world ? rank + 1 : -1;
+  char* x = (char*)x_dev;
+  if (sd->mode == SRMAP_SHARD_ROWS) {
+    const int hu = sd->own_row0, hd = g.H - sd->own_row1;  // my halo rows above / below
+    if ((up >= 0 && hu == 0) || (down >= 0 && hd == 0) || sd->send_down_rows > sd->own_row1 - sd->own_row0 ||
+        sd->send_up_rows > sd->own_row1 - sd->own_row0)
+      return set_error(p->ctx, SRMAP_EINVAL, "row shard: halo description inconsistent");
+    std::vector<const void*> s(g.C);
+    std::vector<void*> r(g.C);
+    // downward traffic: my last owned rows -> lower neighbour's top halo; my top halo <- upper neighbour
+    for (int ch = 0; ch < g.C; ++ch) {
+      s[ch] = x + ((size_t)ch * N + (size_t)(sd->own_row1 - sd->send_down_rows) * g.W) * es;
+      r[ch] = x + ((size_t)ch * N) * es;
+    }
+    int rc = comm_exchange(c, s.data(), down, r.data(), up, g.C, down >= 0 ? (size_t)sd->send_down_rows * g.W : 0,
+                           up >= 0 ? (size_t)hu * g.W : 0, p->dtype, st);
+    if (rc) return rc;
+    // upward traffic: my first owned rows -> upper neighbour's bottom halo; my bottom halo <- lower neighbour
+    for (int ch = 0; ch < g.C; ++ch) {
+      s[ch] = x + ((size_t)ch * N + (size_t)sd->own_row0 * g.W) * es;
+      r[ch] = x + ((size_t)ch * N + (size_t)sd->own_row1 * g.W) * es;
+    }
+    return comm_exchange(c, s.data(), up, r.data(), down, g.C, up >= 0 ? (size_t)sd->send_up_rows * g.W : 0,
+                         down >= 0 ? (size_t)hd * g.W : 0, p->dtype, st);
+  }
+  if (sd->mode == SRMAP_SHARD_CHANNELS) {
+    const bool lo = sd->own_ch0 > 0, hi = sd->own_ch1 < g.C;  // halo planes present (3-D TV coupling)
+    if (!lo && !hi) return SRMAP_OK;
+    // downward: my last owned plane -> lower neighbour's low halo plane; my low halo <- upper neighbour
+    const void* s1 = x + (size_t)(sd->own_ch1 - 1) * N * es;
+    void* r1 = x + (size_t)(sd->own_ch0 - 1) * N * es;
+    int rc = comm_exchange(c, &s1, (down >= 0 && hi) ? down : -1, &r1, (up >= 0 && lo) ? up : -1, 1, N, N, p->dtype, st);
+    if (rc) return rc;
+    // upward: my first owned plane -> upper neighbour's high halo plane; my high halo <- lower neighbour
+    const void* s2 = x + (size_t)sd->own_ch0 * N * es;
+    void* r2 = x + (size_t)sd->own_ch1 * N * es;
+    return comm_exchange(c, &s2, (up >= 0 && lo) ? up : -1, &r2, (down >= 0 && hi) ? down : -1, 1, N, N, p->dtype, st);
+  }
+  return SRMAP_OK;
+}
+
+int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsigned terms, void* x_dev, void* g_dev,
+               hipStream_t st) {
+  const int mode = (c && sd && comm_world(c) > 1) ? sd->mode : SRMAP_SHARD_NONE;
+  if (mode == SRMAP_SHARD_NONE) return srmap_eval_device(p, terms, x_dev, g_dev, nullptr, st);
+  int rc = shard_exchange_x(p, c, sd, x_dev, st);
+  if (rc) return rc;
+  const size_t N = (size_t)p->geo.W * p->geo.H, es = p->elem();
+  if (mode == SRMAP_SHARD_FRAMES) {
+    // the regulariser terms are evaluated once, on reg_rank; every rank adds its frames' data term
+    const unsigned t = (comm_rank(c) == sd->reg_rank) ? terms : (terms & SRMAP_TERM_DATA);
+    if (t == 0) {
+      SRMAP_HIP(p->ctx, hipMemsetAsync(p->d_cost, 0, sizeof(double), st));
+      if (g_dev) SRMAP_HIP(p->ctx, hipMemsetAsync(g_dev, 0, p->hr_count() * es, st));
+    } else {
+      rc = srmap_eval_device(p, t, x_dev, g_dev, nullptr, st);
+      if (rc) return rc;
+    }
+    if (g_dev) {
+      rc = comm_allreduce(c, g_dev, p->hr_count(), p->dtype, 0, st);  // the north-star's gradient all-reduce
+      if (rc) return rc;
+    }
+    return comm_allreduce(c, p->d_cost, 1, SRMAP_F64, 0, st);
+  }
+  if (mode == SRMAP_SHARD_CHANNELS) {
+    const int saved_c0 = p->view_c0, saved_C = p->view_C;
+    const bool saved_cp = p->view_coupled;
+    p->view_c0 = sd->own_ch0; p->view_C = sd->own_ch1 - sd->own_ch0; p->view_coupled = true;
+    rc = srmap_eval_device(p, terms, (char*)x_dev + (size_t)sd->own_ch0 * N * es,
+                           g_dev ? (char*)g_dev + (size_t)sd->own_ch0 * N * es : nullptr, nullptr, st);
+    p->view_c0 = saved_c0; p->view_C = saved_C; p->view_coupled = saved_cp;
+    return rc;
+  }
+  return srmap_eval_device(p, terms, x_dev, g_dev, nullptr, st);  // rows: cost rows were set on the problem
+}
+
+// ---------------------------------------------------------------------------------------------------------
 template <typename T>
 struct DeviceCG {
   srmap_problem* p;
   hipStream_t st;
   size_t n;
-  // x, g: current point and gradient; xk/dk: accepted point and direction;
-  // d: normalised direction; yk = -g_k (then g_{k+1}-g_k).  The line-search base is xk itself.
-  T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr,
-    *yk = nullptr;
-  double* part = nullptr;  // [3][kRedBlocks]
-  double* scal = nullptr;  // [4] device
-  double* hs = nullptr;    // host-mapped pinned scalars (ctx->h_scal): written by k_finish, read after a stream sync
-  srmap_allreduce_fn ar = nullptr;
-  void* user = nullptr;
+  srmap_comm* comm = nullptr;
+  const srmap_shard_desc* shard = nullptr;
+  Owned ow{};
+  bool reduce_scalars = false;  // row / channel shards: the owned-element sums are all-reduced
+  // x, g: current point and gradient; xk/dk: accepted point and direction; dn: next direction;
+  // d: normalised direction; yk = -g (then g_{k+1} - g_k).  The line-search base is xk itself.
+  T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr, *yk = nullptr;
+  double* part = nullptr;   // [3][kRedBlocks]
+  double* dscal = nullptr;  // device scalars: [0..3] reduction results, [4..5] direction norms
+  double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal), read after one stream sync
   int evaluations = 0;
 
   unsigned blocks() const { return (unsigned)((n + 255) / 256); }
@@ -149,7 +278,8 @@ struct DeviceCG {
     T** v[] = {&x, &g, &xk, &dk, &dn, &d, &yk};
     for (T** q : v) SRMAP_HIP(p->ctx, hipMalloc((void**)q, n * sizeof(T)));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&part, sizeof(double) * 3 * kRedBlocks));
-    SRMAP_HIP(p->ctx, hipMalloc((void**)&scal, sizeof(double) * 4));
+    SRMAP_HIP(p->ctx, hipMalloc((void**)&dscal, sizeof(double) * 8));
+    SRMAP_HIP(p->ctx, hipMemsetAsync(dscal, 0, sizeof(double) * 8, st));
     int rc = ensure_staging(p->ctx);
     if (rc) return rc;
     hs = p->ctx->h_scal;
@@ -159,50 +289,54 @@ struct DeviceCG {
     T* v[] = {x, g, xk, dk, dn, d, yk};
     for (T* q : v) if (q) (void)hipFree(q);
     if (part) (void)hipFree(part);
-    if (scal) (void)hipFree(scal);
+    if (dscal) (void)hipFree(dscal);
   }
   int copy(T* dst, const T* src) {
     SRMAP_HIP(p->ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice, st));
     return SRMAP_OK;
   }
-  // out[0..count) = dot products of the given pairs (global over ranks)
-  int dots(const T* a0, const T* b0, const T* a1, const T* b1, const T* a2, const T* b2, int count,
-           double* out) {
-    hipLaunchKernelGGL(k_dots<T>, dim3(nb()), dim3(256), 0, st, a0, b0, a1, b1, a2, b2, n, part);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 3, 0, hs, (const double*)nullptr);
-    SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
-    double h[3] = {hs[0], hs[1], hs[2]};
-    if (ar) ar(h, count, user);
-    for (int i = 0; i < count; ++i) out[i] = h[i];
-    return SRMAP_OK;
-  }
-  int absmax(const T* a, double* out) {
-    hipLaunchKernelGGL(k_absmax<T>, dim3(nb()), dim3(256), 0, st, a, n, part);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 1, 1, hs, (const double*)nullptr);
-    SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
-    *out = hs[0];
-    return SRMAP_OK;
-  }
-  // f, g <- objective at x; dg <- g.d (when d_vec != nullptr)
-  int evaluate(double* f, const T* d_vec, double* dg) {
-    int rc = srmap_eval_device(p, SRMAP_TERM_ALL, x, g, nullptr, st);
-    if (rc) return rc;
-    evaluations++;
-    double h[2] = {0, 0};
-    if (d_vec) {
-      hipLaunchKernelGGL(k_dots<T>, dim3(nb()), dim3(256), 0, st, (const T*)g, d_vec, (const T*)nullptr,
-                         (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, n, part);
-      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 1, 0, hs, (const double*)p->d_cost);
+  // Reduce the `rows` partial rows (+ the evaluation's cost when with_cost) and bring them to the host:
+  // out[0..rows) (+ out[rows] = cost).  One stream synchronisation.
+  int finish(int rows, bool max0, bool with_cost, double* out) {
+    const int cnt = rows + (with_cost ? 1 : 0);
+    if (!reduce_scalars) {
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, hs,
+                         with_cost ? (const double*)p->d_cost : (const double*)nullptr);
       SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
-      h[1] = hs[0]; h[0] = hs[1];
     } else {
-      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, 0, 0, 0, hs, (const double*)p->d_cost);
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, dscal,
+                         with_cost ? (const double*)p->d_cost : (const double*)nullptr);
+      int rc = SRMAP_OK;
+      if (max0) {
+        rc = comm_allreduce(comm, dscal, 1, SRMAP_F64, 1, st);
+        if (rc) return rc;
+        if (cnt > 1) rc = comm_allreduce(comm, dscal + 1, (size_t)cnt - 1, SRMAP_F64, 0, st);
+      } else {
+        rc = comm_allreduce(comm, dscal, (size_t)cnt, SRMAP_F64, 0, st);
+      }
+      if (rc) return rc;
+      SRMAP_HIP(p->ctx, hipMemcpyAsync(hs, dscal, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
       SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
-      h[0] = hs[0];
     }
-    if (ar) ar(h, 2, user);
-    *f = h[0];
-    if (dg) *dg = h[1];
+    for (int i = 0; i < cnt; ++i) out[i] = hs[i];
+    return SRMAP_OK;
+  }
+  // objective at x: g <- gradient; the cost stays on the device (finish(with_cost) fetches it)
+  int evaluate() {
+    evaluations++;
+    return shard_eval(p, comm, shard, SRMAP_TERM_ALL, x, g, st);
+  }
+  // dn = -g + beta dk (dk may be null), yk = -g; direction norms -> dscal[4..5] (device, all-reduced)
+  int direction(const T* dk_or_null, double beta) {
+    hipLaunchKernelGGL(k_direction<T>, dim3(nb()), dim3(256), 0, st, dn, yk, (const T*)g, dk_or_null, (T)beta, n, ow, part);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr);
+    if (reduce_scalars) {
+      int rc = comm_allreduce(comm, dscal + 4, 1, SRMAP_F64, 1, st);
+      if (rc) return rc;
+      rc = comm_allreduce(comm, dscal + 5, 1, SRMAP_F64, 0, st);
+      if (rc) return rc;
+    }
+    SRMAP_HIP(p->ctx, hipGetLastError());
     return SRMAP_OK;
   }
 };
@@ -293,7 +427,7 @@ static void mt_step(Bracket* b, double* stp, double fp, double dp, bool* brackt,
 // trimfunction after each evaluation as mincgiteration does, optimization.cpp:17594).
 template <typename T>
 static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, double gtol,
-                       int* info, int* nfev, double trim) {
+                       int* info, int* nfev, double trim, std::vector<double>* trace) {
   const double ftol = 0.001, xtol = 100 * 5E-16, stpmin = 1.0e-50, stpmax = 1.0e+50, p5 = 0.5,
                p66 = 0.66, xtrapf = 4.0;
   const int maxfev = 20;
@@ -322,9 +456,15 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
       *stp = b.stx;
     hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
                        (const T*)cg.d, (T)*stp, cg.n);
-    double dg = 0;
-    rc = cg.evaluate(f, cg.d, &dg);
+    rc = cg.evaluate();
     if (rc) return rc;
+    hipLaunchKernelGGL(k_dot<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.d, cg.n, cg.ow, cg.part);
+    double h[2];
+    rc = cg.finish(1, false, true, h);  // h[0] = g.d, h[1] = f
+    if (rc) return rc;
+    double dg = h[0];
+    *f = h[1];
+    if (trace) trace->push_back(*f);
     if (*f >= trim) {  // trimfunction: F = threshold, G = 0
       *f = trim;
       hipLaunchKernelGGL(k_fill<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.g, T(0), cg.n);
@@ -371,93 +511,88 @@ struct CgResult { int type = 0, its = 0, nfev = 0; double f = 0; };
 
 // mincgiteration (optimization.cpp:17137-17880), default configuration: no
 // preconditioner, unit scales, cgtype = 1, no stpmax.  On return cg.x holds
-// the accepted point XN.
+// the accepted point XN.  trace (optional): f of every evaluation, in order.
 template <typename T>
-static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int maxits, CgResult* out) {
+static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int maxits, CgResult* out,
+                  std::vector<double>* trace) {
   const double gtol = 0.3;
   const int rscountdownlen = 10;
   if (epsg == 0 && epsf == 0 && epsx == 0 && maxits == 0) epsx = 1.0E-6;
   const size_t n = cg.n;
-  const unsigned nbk = cg.blocks();
-  hipStream_t st = cg.st;
   CgResult res;
   double f = 0, gg = 0;
   int rc = cg.copy(cg.xk, cg.x);
   if (rc) return rc;
-  rc = cg.evaluate(&f, nullptr, nullptr);
+  rc = cg.evaluate();
   if (rc) return rc;
+  // dk = -g (written as dn, swapped below), yk = -g, norms of dk; g.g = dk.dk comes with them
+  rc = cg.direction(nullptr, 0.0);
+  if (rc) return rc;
+  {
+    double h[1];
+    // fetch f and g.g (= dn.dn, already reduced on the device) with one synchronisation
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, cg.st, cg.part, 0, 0, 0, cg.reduce_scalars ? cg.dscal : cg.hs,
+                       (const double*)cg.p->d_cost);
+    if (cg.reduce_scalars) {
+      rc = comm_allreduce(cg.comm, cg.dscal, 1, SRMAP_F64, 0, cg.st);
+      if (rc) return rc;
+      SRMAP_HIP(cg.p->ctx, hipMemcpyAsync(cg.hs, cg.dscal, sizeof(double), hipMemcpyDeviceToHost, cg.st));
+    }
+    SRMAP_HIP(cg.p->ctx, hipMemcpyAsync(cg.hs + 8, cg.dscal + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, cg.st));
+    SRMAP_HIP(cg.p->ctx, hipStreamSynchronize(cg.st));
+    h[0] = cg.hs[0];
+    f = h[0];
+    gg = cg.hs[9];
+  }
+  if (trace) trace->push_back(f);
+  std::swap(cg.dk, cg.dn);
   const double trim = 10 * (std::fabs(f) + 1);
-  hipLaunchKernelGGL(k_scale_copy<T>, dim3(nbk), dim3(256), 0, st, cg.dk, (const T*)cg.g, T(-1), n);
-  rc = cg.dots(cg.g, cg.g, nullptr, nullptr, nullptr, nullptr, 1, &gg);
-  if (rc) return rc;
   if (std::sqrt(gg) <= epsg) { res.type = 4; res.f = f; *out = res; return cg.copy(cg.x, cg.xk); }
   res.nfev = 1;
   double fold = f, lastgoodstep = 1.0;
   int rstimer = rscountdownlen;
   for (;;) {
-    // yk = -g ; d = normalised dk ; x = xk
-    hipLaunchKernelGGL(k_scale_copy<T>, dim3(nbk), dim3(256), 0, st, cg.yk, (const T*)cg.g, T(-1), n);
-    // (x = xk is not materialised: the line search writes every trial point x = xk + stp * d itself)
-    double stp = 1.0, dginit = 0;
+    // d = normalised dk (linminnormalized), g.d, d.d; x = xk is not materialised: the line search writes every
+    // trial point x = xk + stp * d itself
+    double stp = 1.0, dginit = 0, dd = 0;
     {
-      // linminnormalized: d *= 1/max|d| ; d *= 1/sqrt(d.d).  Under a multi-rank
-      // allreduce hook (sum only) the first scaling uses the 2-norm instead of
-      // the max norm; both only guard against overflow of the squares.
-      double mx = 0;
-      if (cg.ar) {
-        double s2 = 0;
-        rc = cg.dots(cg.dk, cg.dk, nullptr, nullptr, nullptr, nullptr, 1, &s2);
-        if (rc) return rc;
-        mx = std::sqrt(s2);
-      } else {
-        rc = cg.absmax(cg.dk, &mx);
-        if (rc) return rc;
-      }
-      if (mx != 0) {
-        const double s1 = 1 / mx;
-        stp = stp / s1;
-        // sum (dk*s1)^2 evaluated on the scaled vector
-        hipLaunchKernelGGL(k_scale_copy<T>, dim3(nbk), dim3(256), 0, st, cg.d, (const T*)cg.dk, (T)s1, n);
-        double ss = 0;
-        rc = cg.dots(cg.d, cg.d, nullptr, nullptr, nullptr, nullptr, 1, &ss);
-        if (rc) return rc;
-        const double s2 = 1 / std::sqrt(ss);
-        hipLaunchKernelGGL(k_scale2<T>, dim3(nbk), dim3(256), 0, st, cg.d, (const T*)cg.dk, (T)s1, (T)s2, n);
-        stp = stp / s2;
-      } else {
-        rc = cg.copy(cg.d, cg.dk);
-        if (rc) return rc;
-      }
-    }
-    if (lastgoodstep != 0) stp = lastgoodstep;
-    double dd = 0;
-    {
+      hipLaunchKernelGGL(k_normalize_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
+                         (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6);
+      SRMAP_HIP(cg.p->ctx, hipMemcpyAsync(cg.hs + 8, cg.dscal + 4, sizeof(double) * 4, hipMemcpyDeviceToHost, cg.st));
       double h[2];
-      rc = cg.dots(cg.g, cg.d, cg.d, cg.d, nullptr, nullptr, 2, h);
+      rc = cg.finish(2, false, false, h);
       if (rc) return rc;
       dginit = h[0];
       dd = h[1];
+      const double mx = cg.hs[8], s1 = cg.hs[10], s2 = cg.hs[11];
+      if (mx != 0) { stp = stp / s1; stp = stp / s2; }
     }
+    if (lastgoodstep != 0) stp = lastgoodstep;
     int mcinfo = 0, nfev = 0;
-    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim);
+    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace);
     if (rc) return rc;
     double betak = 0;
-    double dots3[3] = {0, 0, 0};
     if (mcinfo == 1) {
       // yk += g ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv
-      hipLaunchKernelGGL(k_axpy_out<T>, dim3(nbk), dim3(256), 0, st, cg.yk, (const T*)cg.yk, (const T*)cg.g, T(1), n);
-      rc = cg.dots(cg.yk, cg.dk, cg.g, cg.g, cg.g, cg.yk, 3, dots3);
+      hipLaunchKernelGGL(k_beta_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, cg.yk, (const T*)cg.g, (const T*)cg.dk, n,
+                         cg.ow, cg.part);
+      double h[3];
+      rc = cg.finish(3, false, false, h);
       if (rc) return rc;
-      const double vv = dots3[0];
-      betak = dmax(0.0, dmin(dots3[1] / vv, dots3[2] / vv));
-      gg = dots3[1];
+      const double vv = h[0];
+      betak = dmax(0.0, dmin(h[1] / vv, h[2] / vv));
+      gg = h[1];
     } else {
-      rc = cg.dots(cg.g, cg.g, nullptr, nullptr, nullptr, nullptr, 1, &gg);
+      hipLaunchKernelGGL(k_dot<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow, cg.part);
+      double h[1];
+      rc = cg.finish(1, false, false, h);
       if (rc) return rc;
+      gg = h[0];
     }
     if (res.its > 0 && res.its % (3 + (long long)n) == 0) betak = 0;
     if (mcinfo == 1 || mcinfo == 5) rstimer = rscountdownlen; else rstimer -= 1;
-    hipLaunchKernelGGL(k_new_direction<T>, dim3(nbk), dim3(256), 0, st, cg.dn, (const T*)cg.g, (const T*)cg.dk, (T)betak, n);
+    rc = cg.direction(cg.dk, betak);  // dn, yk = -g, norms of dn (device)
+    if (rc) return rc;
     const double lastscaledstep = stp * std::sqrt(dd);
     if (mcinfo == 1) lastgoodstep = stp * std::sqrt(dd);
     if (!std::isfinite(gg) || !std::isfinite(f)) { res.type = -8; break; }
@@ -478,20 +613,46 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
 }
 
 template <typename T>
-static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const double* x0, double* x_out,
-                       srmap_solve_report* report, srmap_allreduce_fn ar, void* user) {
+static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard, const srmap_irls_options* opt,
+                       const double* x0, double* x_out, srmap_solve_report* report) {
   if (!p->have_obs) return set_error(p->ctx, SRMAP_EINVAL, "cannot super-resolve with 0 low-res images");
   const Geometry& geo = p->geo;
   const size_t N = (size_t)geo.W * geo.H;
   const int C = geo.C;
+  const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
+  if (mode != SRMAP_SHARD_NONE && opt->split_channels)
+    return set_error(p->ctx, SRMAP_EUNSUPPORTED, "split_channels solves are independent per channel: run them unsharded");
+  if (mode == SRMAP_SHARD_ROWS &&
+      (shard->own_row0 < 0 || shard->own_row1 > geo.H || shard->own_row0 >= shard->own_row1 ||
+       shard->own_row0 != geo.cr0 || shard->own_row1 != geo.cr1))
+    return set_error(p->ctx, SRMAP_EINVAL, "row shard: owned rows must equal the problem's cost rows");
+  if (mode == SRMAP_SHARD_CHANNELS && (shard->own_ch0 < 0 || shard->own_ch1 > C || shard->own_ch0 >= shard->own_ch1))
+    return set_error(p->ctx, SRMAP_EINVAL, "channel shard: bad owned channel range");
   const int per_split = opt->split_channels ? 1 : C;
   const int rounds = C / per_split;
   const size_t npts = (size_t)per_split * N;
   srmap_irls_options o = *opt;
   double lambda_sum = 0.0;
   for (int r = 0; r < p->nreg; ++r) lambda_sum += p->reg[r].lambda;
-  {  // AdjustThresholdsAdaptively (map_solver.cpp:16-26, irls_map_solver.cpp:161-171)
-    const double scale = (double)(int)npts * lambda_sum;
+  {  // AdjustThresholdsAdaptively (map_solver.cpp:16-26, irls_map_solver.cpp:161-171) on the JOINT problem size
+    double params = (double)(int)npts;
+    if (mode == SRMAP_SHARD_ROWS || mode == SRMAP_SHARD_CHANNELS) {
+      double own = mode == SRMAP_SHARD_ROWS ? (double)C * geo.W * (shard->own_row1 - shard->own_row0)
+                                            : (double)(shard->own_ch1 - shard->own_ch0) * N;
+      // every rank must derive the same thresholds: total parameter count = sum of the owned counts
+      double* tmp = nullptr;
+      SRMAP_HIP(p->ctx, hipMalloc((void**)&tmp, sizeof(double)));
+      SRMAP_HIP(p->ctx, hipMemcpy(tmp, &own, sizeof(double), hipMemcpyHostToDevice));
+      int rc0 = comm_allreduce(comm, tmp, 1, SRMAP_F64, 0, p->ctx->stream);
+      if (rc0 == SRMAP_OK) {
+        SRMAP_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
+        SRMAP_HIP(p->ctx, hipMemcpy(&own, tmp, sizeof(double), hipMemcpyDeviceToHost));
+      }
+      (void)hipFree(tmp);
+      if (rc0) return rc0;
+      params = (double)(int)own;
+    }
+    const double scale = params * lambda_sum;
     if (!(scale < 1.0)) {
       o.gradient_norm_threshold *= scale;
       o.cost_decrease_threshold *= scale;
@@ -501,14 +662,13 @@ static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const do
   }
   srmap_solve_report rep = {0, 0, 0, 0, 0.0};
   hipStream_t st = p->ctx->stream;
-  static const bool timing = getenv("SRMAP_DEBUG_SOLVE_TIMING") != nullptr;  // phase wall times (profiling aid)
-  auto now = [&]() { if (timing) (void)hipStreamSynchronize(st); return std::chrono::steady_clock::now(); };
-  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-    return std::chrono::duration<double, std::milli>(b - a).count(); };
-  double t_alloc = 0, t_up = 0, t_loop = 0, t_down = 0;
-  auto t0 = now();
   DeviceCG<T> cg;
-  cg.p = p; cg.st = st; cg.n = npts; cg.ar = ar; cg.user = user;
+  cg.p = p; cg.st = st; cg.n = npts; cg.comm = comm; cg.shard = shard;
+  cg.ow.on = 0; cg.ow.e0 = 0; cg.ow.e1 = npts; cg.ow.W = geo.W; cg.ow.H = geo.H; cg.ow.r0 = 0; cg.ow.r1 = geo.H;
+  if (mode == SRMAP_SHARD_ROWS) { cg.ow.on = 1; cg.ow.r0 = shard->own_row0; cg.ow.r1 = shard->own_row1; cg.reduce_scalars = true; }
+  if (mode == SRMAP_SHARD_CHANNELS) {
+    cg.ow.on = 1; cg.ow.e0 = (size_t)shard->own_ch0 * N; cg.ow.e1 = (size_t)shard->own_ch1 * N; cg.reduce_scalars = true;
+  }
   int rc = cg.alloc();
   // IRLS weights live in the problem's RegSpec (full [C][H][W]); make sure they exist.
   for (int r = 0; r < p->nreg && rc == SRMAP_OK; ++r) {
@@ -521,18 +681,13 @@ static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const do
   if (rc == SRMAP_OK && p->nreg > 0 && hipMalloc((void**)&regvals, npts * sizeof(T)) != hipSuccess)
     rc = set_error(p->ctx, SRMAP_ENOMEM, "hipMalloc failed");
   const int saved_c0 = p->view_c0, saved_C = p->view_C;
-  t_alloc = ms(t0, now());
   for (int round = 0; round < rounds && rc == SRMAP_OK; ++round) {
     const int c0 = round * per_split;
-    p->view_c0 = c0;
-    p->view_C = per_split;
+    if (opt->split_channels) { p->view_c0 = c0; p->view_C = per_split; }
     Geometry vg = geo;
     vg.C = per_split;
-    auto t1 = now();
     rc = convert_upload(p, x0 + (size_t)c0 * N, cg.x, npts, st);
     if (rc) break;
-    auto t2 = now();
-    t_up += ms(t1, t2);
     // w <- 1  (irls_map_solver.cpp:66-74)
     for (int r = 0; r < p->nreg; ++r)
       hipLaunchKernelGGL(k_fill<T>, dim3(cg.blocks()), dim3(256), 0, st, (T*)p->reg[r].weights + (size_t)c0 * N, T(1), npts);
@@ -542,13 +697,17 @@ static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const do
     while (std::fabs(cost_difference) >= o.irls_cost_difference_threshold) {
       CgResult cr;
       rc = run_cg(cg, o.gradient_norm_threshold, o.cost_decrease_threshold, o.parameter_variation_threshold,
-                  o.max_num_solver_iterations, &cr);
+                  o.max_num_solver_iterations, &cr, nullptr);
       if (rc) break;
       rep.cg_iterations += cr.its;
       rep.last_termination = cr.type;
       rep.final_cost = cr.f;
       if (p->nreg == 0) { ran++; break; }
-      for (int r = 0; r < p->nreg; ++r) {  // w = 1/max(1e-5, reg(x)), :128-143
+      // w = 1/max(1e-5, reg(x)), :128-143 -- on fresh halos (the weights of a halo plane / halo rows feed the
+      // owned gradient through the neighbour terms)
+      rc = shard_exchange_x(p, comm, mode == SRMAP_SHARD_NONE ? nullptr : shard, cg.x, st);
+      if (rc) break;
+      for (int r = 0; r < p->nreg; ++r) {
         rc = launch_reg_values<T>(p, vg, p->reg[r], (const T*)cg.x, regvals, st);
         if (rc) break;
         rc = launch_irls_weights<T>(p, (const T*)regvals, (T*)p->reg[r].weights + (size_t)c0 * N, npts, st);
@@ -562,28 +721,85 @@ static int solve_typed(srmap_problem* p, const srmap_irls_options* opt, const do
     }
     if (rc) break;
     rep.irls_rounds += ran;
-    auto t3 = now();
-    t_loop += ms(t2, t3);
+    rc = shard_exchange_x(p, comm, mode == SRMAP_SHARD_NONE ? nullptr : shard, cg.x, st);  // x_out carries valid halos
+    if (rc) break;
     rc = convert_download(p, cg.x, x_out + (size_t)c0 * N, npts, st);
-    t_down += ms(t3, now());
   }
   rep.evaluations = cg.evaluations;
   p->view_c0 = saved_c0;
   p->view_C = saved_C;
-  auto t4 = now();
   if (regvals) (void)hipFree(regvals);
   cg.release();
-  if (timing)
-    fprintf(stderr, "[solve] alloc %.2f ms, upload %.2f, irls/cg loop %.2f (%d evaluations), download %.2f, free %.2f\n", t_alloc,
-            t_up, t_loop, cg.evaluations, t_down, ms(t4, now()));
   if (report) *report = rep;
   return rc;
 }
 
-int solve_impl(srmap_problem* p, const srmap_irls_options* o, const double* x0, double* x_out,
-               srmap_solve_report* rep, srmap_allreduce_fn ar, void* user) {
-  if (p->dtype == SRMAP_F32) return solve_typed<float>(p, o, x0, x_out, rep, ar, user);
-  return solve_typed<double>(p, o, x0, x_out, rep, ar, user);
+int solve_impl(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard, const srmap_irls_options* o,
+               const double* x0, double* x_out, srmap_solve_report* rep) {
+  if (p->dtype == SRMAP_F32) return solve_typed<float>(p, comm, shard, o, x0, x_out, rep);
+  return solve_typed<double>(p, comm, shard, o, x0, x_out, rep);
+}
+
+// One nonlinear-CG run (no IRLS re-weighting) with the f of every evaluation recorded: the trajectory the tests
+// compare with ALGLIB's mincg on the same objective (tests/test_gpu_parity.py).
+template <typename T>
+static int cg_trace_typed(srmap_problem* p, double epsg, double epsf, double epsx, int maxits, const double* x0,
+                          double* x_out, int* iterations, int* nfev, int* termination, double* f_trace, int trace_cap,
+                          int* trace_len) {
+  const size_t npts = p->hr_count();
+  DeviceCG<T> cg;
+  cg.p = p; cg.st = p->ctx->stream; cg.n = npts;
+  cg.ow.on = 0; cg.ow.e0 = 0; cg.ow.e1 = npts; cg.ow.W = p->geo.W; cg.ow.H = p->geo.H; cg.ow.r0 = 0; cg.ow.r1 = p->geo.H;
+  int rc = cg.alloc();
+  if (rc == SRMAP_OK) rc = convert_upload(p, x0, cg.x, npts, cg.st);
+  CgResult cr;
+  std::vector<double> tr;
+  if (rc == SRMAP_OK) rc = run_cg(cg, epsg, epsf, epsx, maxits, &cr, &tr);
+  if (rc == SRMAP_OK) rc = convert_download(p, cg.x, x_out, npts, cg.st);
+  cg.release();
+  if (rc) return rc;
+  if (iterations) *iterations = cr.its;
+  if (nfev) *nfev = cr.nfev;
+  if (termination) *termination = cr.type;
+  const int m = (int)tr.size() < trace_cap ? (int)tr.size() : trace_cap;
+  for (int i = 0; i < m; ++i) f_trace[i] = tr[i];
+  if (trace_len) *trace_len = (int)tr.size();
+  return SRMAP_OK;
 }
 
 }  // namespace srmap
+
+using namespace srmap;
+
+extern "C" {
+
+int srmap_eval_sharded_device(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard, unsigned terms,
+                              void* x_dev, void* g_dev, double* cost, void* hip_stream) {
+  if (!p || !x_dev) return SRMAP_EINVAL;
+  SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : p->ctx->stream;
+  int rc = shard_eval(p, comm, shard, terms, x_dev, g_dev, st);
+  if (rc) return rc;
+  if (cost) {
+    const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
+    if (mode == SRMAP_SHARD_ROWS || mode == SRMAP_SHARD_CHANNELS) {
+      rc = comm_allreduce(comm, p->d_cost, 1, SRMAP_F64, 0, st);
+      if (rc) return rc;
+    }
+    SRMAP_HIP(p->ctx, hipMemcpyAsync(cost, p->d_cost, sizeof(double), hipMemcpyDeviceToHost, st));
+    SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+  }
+  return SRMAP_OK;
+}
+
+int srmap_cg_trace(srmap_problem* p, double epsg, double epsf, double epsx, int maxits, const double* x0, double* x_out,
+                   int* iterations, int* nfev, int* termination, double* f_trace, int trace_cap, int* trace_len) {
+  if (!p || !x0 || !x_out || (trace_cap > 0 && !f_trace)) return SRMAP_EINVAL;
+  SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
+  if (!p->have_obs) return set_error(p->ctx, SRMAP_EINVAL, "no observations set");
+  if (p->dtype == SRMAP_F32)
+    return cg_trace_typed<float>(p, epsg, epsf, epsx, maxits, x0, x_out, iterations, nfev, termination, f_trace, trace_cap, trace_len);
+  return cg_trace_typed<double>(p, epsg, epsf, epsx, maxits, x0, x_out, iterations, nfev, termination, f_trace, trace_cap, trace_len);
+}
+
+}  // extern "C"

@@ -228,6 +228,8 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
   Geometry geo = p->geo;
   const int c0 = p->view_C > 0 ? p->view_c0 : 0;
   if (p->view_C > 0) geo.C = p->view_C;
+  geo.zlo = (p->view_coupled && c0 > 0) ? 1 : 0;
+  geo.zhi = (p->view_coupled && c0 + geo.C < p->geo.C) ? 1 : 0;
   const size_t N = (size_t)geo.W * geo.H;
   int rc = ensure_partials(p, partials_needed(p));
   if (rc) return rc;
@@ -374,6 +376,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   g.b = blur ? d->blur_ksize : 1;
   g.hb = (g.b - 1) / 2;
   g.cr0 = 0; g.cr1 = g.H;
+  g.zlo = 0; g.zhi = 0;
   // Gaussian kernel: cv::getGaussianKernel (sigma > 0) and k * k^T, blur_module.cpp:20-22
   p->blur2d.assign((size_t)g.b * g.b, 1.0);
   p->blur1d.assign((size_t)g.b, 1.0);
@@ -757,18 +760,19 @@ void srmap_irls_options_default(srmap_irls_options* o) {
   o->irls_cost_difference_threshold = 1.0e-5;
 }
 
-int srmap_solve_ex(srmap_problem* p, const srmap_irls_options* options, const double* x0, double* x_out,
-                   srmap_solve_report* report, srmap_allreduce_fn allreduce, void* user) {
+int srmap_solve_sharded(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard,
+                        const srmap_irls_options* options, const double* x0, double* x_out,
+                        srmap_solve_report* report) {
   if (!p || !x0 || !x_out) return SRMAP_EINVAL;
   srmap_irls_options o;
   if (options) o = *options; else srmap_irls_options_default(&o);
   SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
-  return solve_impl(p, &o, x0, x_out, report, allreduce, user);
+  return solve_impl(p, comm, shard, &o, x0, x_out, report);
 }
 
 int srmap_solve(srmap_problem* p, const srmap_irls_options* options, const double* x0, double* x_out,
                 srmap_solve_report* report) {
-  return srmap_solve_ex(p, options, x0, x_out, report, nullptr, nullptr);
+  return srmap_solve_sharded(p, nullptr, nullptr, options, x0, x_out, report);
 }
 
 }  // extern "C"

@@ -34,6 +34,8 @@ struct Geometry {
   int b, hb;       // blur kernel size (1 = none) and (b-1)/2
   int cr0, cr1;    // HR rows [cr0, cr1) whose cost terms are counted (row-band sharding; default 0, H):
                    // regulariser pixels of those rows, data residuals of LR rows [cr0/s, cr1/s)
+  int zlo, zhi;    // channel sharding: a halo plane exists before channel 0 / after channel C-1 of this view
+                   // (3-D TV couples across it, tv_regularizer.cpp:205-222); 0 otherwise
 };
 
 struct RegSpec {
@@ -104,6 +106,7 @@ struct srmap_problem {
   // channel view of the current evaluation (split_channels solves one channel
   // at a time, irls_map_solver.cpp:200-262); default = all channels
   int view_c0 = 0, view_C = 0;
+  bool view_coupled = false;      // the view's neighbour planes are halo channels of a channel shard (3-D TV reads them)
   size_t elem() const { return dtype == SRMAP_F32 ? 4 : 8; }
   size_t hr_count() const { return (size_t)geo.C * geo.H * geo.W; }
   size_t lr_count() const { return (size_t)geo.K * geo.C * geo.h * geo.w; }
@@ -168,9 +171,9 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
                       const T* x, T* g, double* partials, int* nblocks, hipStream_t st);
 
 // ---- vector kernels for the solver (solver.hip) ----
-int solve_impl(srmap_problem* p, const srmap_irls_options* o, const double* x0,
-               double* x_out, srmap_solve_report* rep, srmap_allreduce_fn ar,
-               void* user);
+int solve_impl(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard,
+               const srmap_irls_options* o, const double* x0, double* x_out,
+               srmap_solve_report* rep);
 
 // conversions / staging
 int ensure_staging(srmap_ctx* ctx);

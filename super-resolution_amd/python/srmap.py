@@ -48,7 +48,15 @@ class SolveReport(C.Structure):
                 ("last_termination", C.c_int), ("final_cost", C.c_double)]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(None, c_double_p, C.c_int, C.c_void_p)
+class ShardDesc(C.Structure):
+    _fields_ = [("mode", C.c_int), ("own_row0", C.c_int), ("own_row1", C.c_int),
+                ("send_up_rows", C.c_int), ("send_down_rows", C.c_int),
+                ("own_ch0", C.c_int), ("own_ch1", C.c_int), ("reg_rank", C.c_int)]
+
+
+SHARD_NONE, SHARD_FRAMES, SHARD_ROWS, SHARD_CHANNELS = 0, 1, 2, 3
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
+HOST_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 # every symbol include/srmap.h declares: (name, restype, argtypes)
 _SIGNATURES = [
@@ -82,7 +90,15 @@ _SIGNATURES = [
     ("srmap_synchronize", C.c_int, [C.c_void_p]),
     ("srmap_irls_options_default", None, [C.POINTER(IrlsOptions)]),
     ("srmap_solve", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
-    ("srmap_solve_ex", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport), ALLREDUCE_FN, C.c_void_p]),
+    ("srmap_comm_get_unique_id", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("srmap_comm_create_rccl", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("srmap_comm_create_host", C.c_int, [C.c_void_p, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_SENDRECV_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("srmap_comm_destroy", None, [C.c_void_p]),
+    ("srmap_comm_allreduce", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
+    ("srmap_eval_sharded_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ShardDesc), C.c_uint, C.c_void_p, C.c_void_p, c_double_p, C.c_void_p]),
+    ("srmap_solve_sharded", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ShardDesc), C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
+    ("srmap_cg_trace", C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, c_double_p, c_double_p,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p, C.c_int, C.POINTER(C.c_int)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -169,7 +185,6 @@ class Problem:
         load().srmap_problem_lr_size(self._h, C.byref(lw), C.byref(lh))
         self.w, self.h = lw.value, lh.value
         self.nreg = 0
-        self._ar = None
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -267,20 +282,100 @@ class Problem:
         self.ctx.check(load().srmap_last_cost(self._h, C.byref(cost)))
         return cost.value
 
-    def solve(self, x0, options=None, allreduce=None):
+    def solve(self, x0, options=None, comm=None, shard=None):
+        """IRLSMapSolver::Solve; with a Comm and a ShardDesc: this rank's shard of the joint solve."""
         a, pa = _d(x0)
         assert a.size == self.C * self.H * self.W
         out = np.empty((self.C, self.H, self.W))
         rep = SolveReport()
         o = options if options is not None else default_irls_options()
-        if allreduce is None:
+        if comm is None:
             st = load().srmap_solve(self._h, C.byref(o), pa, out.ctypes.data_as(c_double_p), C.byref(rep))
         else:
-            def _cb(ptr, n, _user):
-                arr = np.ctypeslib.as_array(ptr, shape=(n,))
-                allreduce(arr)
-            self._ar = ALLREDUCE_FN(_cb)
-            st = load().srmap_solve_ex(self._h, C.byref(o), pa, out.ctypes.data_as(c_double_p), C.byref(rep),
-                                       self._ar, None)
+            st = load().srmap_solve_sharded(self._h, comm._h, C.byref(shard), C.byref(o), pa,
+                                            out.ctypes.data_as(c_double_p), C.byref(rep))
         self.ctx.check(st)
         return out, rep
+
+    def eval_sharded_device(self, comm, shard, x_ptr, g_ptr, terms=TERM_ALL, want_cost=False, stream=None):
+        cost = C.c_double()
+        self.ctx.check(load().srmap_eval_sharded_device(
+            self._h, comm._h if comm is not None else None, C.byref(shard) if shard is not None else None, terms,
+            C.c_void_p(x_ptr), C.c_void_p(g_ptr) if g_ptr else None, C.byref(cost) if want_cost else None,
+            C.c_void_p(stream) if stream else None))
+        return cost.value if want_cost else None
+
+    def cg_trace(self, x0, epsg=0.0, epsf=0.0, epsx=0.0, maxits=0, cap=4096):
+        """One nonlinear-CG run; returns (x, iterations, nfev, termination, [f of every evaluation])."""
+        a, pa = _d(x0)
+        out = np.empty((self.C, self.H, self.W))
+        its, nfev, term, tl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        tr = np.zeros(cap)
+        self.ctx.check(load().srmap_cg_trace(self._h, epsg, epsf, epsx, maxits, pa, out.ctypes.data_as(c_double_p),
+                                             C.byref(its), C.byref(nfev), C.byref(term),
+                                             tr.ctypes.data_as(c_double_p), cap, C.byref(tl)))
+        return out, its.value, nfev.value, term.value, tr[:min(cap, tl.value)].copy()
+
+
+class Comm:
+    """srmap_comm: RCCL (ranks on different GPUs) or host callbacks over a torch.distributed group (gloo / any)."""
+
+    def __init__(self, ctx, rank, world, backend="rccl", unique_id=None, dist=None, group=None):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self._h = C.c_void_p()
+        self._keep = None
+        if backend == "rccl":
+            assert unique_id is not None and len(unique_id) == 128
+            ctx.check(load().srmap_comm_create_rccl(ctx._h, unique_id, rank, world, C.byref(self._h)))
+        else:
+            import torch
+
+            def _arr(ptr, count, dtype):
+                ct = C.c_float if dtype == F32 else C.c_double
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(count,))
+
+            def _ar(buf, count, dtype, op, _user):
+                try:
+                    t = torch.from_numpy(_arr(buf, count, dtype))
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)
+                    return 0
+                except Exception as e:  # pragma: no cover
+                    print("host all-reduce failed:", e)
+                    return 1
+
+            def _sr(send, sbytes, dst, recv, rbytes, src, _user):
+                try:
+                    reqs = []
+                    if dst >= 0 and sbytes:
+                        ts = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(sbytes,)).copy())
+                        reqs.append(dist.isend(ts, dst, group=group))
+                    tr = None
+                    if src >= 0 and rbytes:
+                        tr = torch.empty(rbytes, dtype=torch.uint8)
+                        reqs.append(dist.irecv(tr, src, group=group))
+                    for r in reqs:
+                        r.wait()
+                    if tr is not None:
+                        np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(rbytes,))[:] = tr.numpy()
+                    return 0
+                except Exception as e:  # pragma: no cover
+                    print("host send/recv failed:", e)
+                    return 1
+
+            self._keep = (HOST_ALLREDUCE_FN(_ar), HOST_SENDRECV_FN(_sr))
+            ctx.check(load().srmap_comm_create_host(ctx._h, rank, world, self._keep[0], self._keep[1], None, C.byref(self._h)))
+
+    def allreduce(self, dev_ptr, count, dtype=F64, op=0, stream=None):
+        self.ctx.check(load().srmap_comm_allreduce(self._h, C.c_void_p(dev_ptr), count, dtype, op,
+                                                   C.c_void_p(stream) if stream else None))
+
+    @staticmethod
+    def unique_id(ctx):
+        buf = C.create_string_buffer(128)
+        ctx.check(load().srmap_comm_get_unique_id(ctx._h, buf))
+        return buf.raw
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().srmap_comm_destroy(self._h)
+            self._h = None

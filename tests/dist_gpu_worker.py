@@ -1,0 +1,156 @@
+"""One rank of the multi-process sharded tests (tests/test_gpu_sharded.py): every rank shares GPU 0, talks over gloo
+(through the library's host-callback communicator) and runs its shard of the joint evaluation / solve through the C
+ABI; rank 0 also evaluates the un-sharded problem and writes the comparison as JSON.
+
+    python dist_gpu_worker.py <rank> <world> <port> <mode> <out.json>
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "super-resolution_amd", "python")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def relerr(a, ref):
+    a, ref = np.asarray(a, dtype=float).ravel(), np.asarray(ref, dtype=float).ravel()
+    return float(np.max(np.abs(a - ref) / np.maximum(1.0, np.abs(ref))))
+
+
+def main():
+    rank, world, port, mode, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    torch.cuda.init()
+    torch.zeros(1, device="cuda")  # torch's HIP runtime first (see tests/conftest.py)
+    import srmap
+    import srmap_dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ctx = srmap.Context(0)
+    comm = srmap.Comm(ctx, rank, world, backend="host", dist=dist)
+
+    rng = np.random.default_rng(123)
+    s, b, sigma = 4, 3, 1.0
+    K = 8
+    shifts = [[k % s, (k * 3) % s] for k in range(K)]
+    C = 4 if mode == "channels" else 2
+    W, H = 80, 96
+    w, h = W // s, H // s
+    gt = rng.random((C, H, W))
+    lr = rng.random((K, C, h, w))
+    x0 = rng.random((C, H, W))
+    regs = [(srmap.REG_BTV, 0.02, 3, 0.5)] + ([(srmap.REG_TV3D, 0.03, 0, 0.0)] if mode == "channels" else [])
+    opts = srmap.default_irls_options()
+    opts.max_num_irls_iterations = 2
+    opts.max_num_solver_iterations = 6
+
+    def full_problem():
+        p = srmap.Problem(ctx, W, H, C, K, s, shifts, b, sigma, srmap.F64)
+        p.set_observations(lr)
+        for r in regs:
+            p.add_regularizer(*r)
+        return p
+
+    sd = srmap.ShardDesc()
+    if mode == "frames":
+        ids = srmap_dist.frame_shard(K, world, rank)
+        p = srmap.Problem(ctx, W, H, C, len(ids), s, [shifts[k] for k in ids], b, sigma, srmap.F64)
+        p.set_observations(lr[ids])
+        for r in regs:
+            p.add_regularizer(*r)
+        sd.mode, sd.reg_rank = srmap.SHARD_FRAMES, 0
+        x_loc = x0
+        own = (slice(None), slice(None))
+    elif mode == "rows":
+        halo = srmap_dist.band_halo(s, b, s - 1, 3)
+        bands = [srmap_dist.row_band(H, s, world, r, halo) for r in range(world)]
+        (r0, r1), (e0, e1) = bands[rank]
+        p = srmap.Problem(ctx, W, e1 - e0, C, K, s, shifts, b, sigma, srmap.F64)
+        p.set_observations(lr[:, :, e0 // s:e1 // s, :])
+        for r in regs:
+            p.add_regularizer(*r)
+        p.set_cost_rows(r0 - e0, r1 - e0)
+        sd.mode = srmap.SHARD_ROWS
+        sd.own_row0, sd.own_row1 = r0 - e0, r1 - e0
+        if rank + 1 < world:
+            (n0, n1), (ne0, ne1) = bands[rank + 1]
+            sd.send_down_rows = n0 - ne0
+        if rank > 0:
+            (u0, u1), (ue0, ue1) = bands[rank - 1]
+            sd.send_up_rows = ue1 - u1
+        x_loc = x0[:, e0:e1, :].copy()
+        # stale halos: the library must refresh them before the first evaluation
+        if r0 > e0:
+            x_loc[:, :r0 - e0, :] = -7.0
+        if e1 > r1:
+            x_loc[:, r1 - e0:, :] = -7.0
+        own = (slice(None), slice(r0, r1))
+        loc_rows = (r0 - e0, r1 - e0)
+    else:  # channels, coupled by the 3-D TV regulariser: one halo plane per neighbour
+        c0, c1 = srmap_dist.channel_shard(C, world, rank)
+        lo, hi = (1 if c0 > 0 else 0), (1 if c1 < C else 0)
+        p = srmap.Problem(ctx, W, H, (c1 - c0) + lo + hi, K, s, shifts, b, sigma, srmap.F64)
+        p.set_observations(lr[:, c0 - lo:c1 + hi])
+        for r in regs:
+            p.add_regularizer(*r)
+        sd.mode = srmap.SHARD_CHANNELS
+        sd.own_ch0, sd.own_ch1 = lo, lo + (c1 - c0)
+        x_loc = x0[c0 - lo:c1 + hi].copy()
+        if lo:
+            x_loc[0] = -7.0
+        if hi:
+            x_loc[-1] = -7.0
+        own = (slice(c0, c1), slice(None))
+
+    # ---- one sharded evaluation against the un-sharded one (weights = ones) ----
+    xd = torch.from_numpy(np.ascontiguousarray(x_loc)).cuda()
+    gd = torch.zeros_like(xd)
+    f = p.eval_sharded_device(comm, sd, xd.data_ptr(), gd.data_ptr(), srmap.TERM_ALL, want_cost=True)
+    torch.cuda.synchronize()
+    g_loc = gd.cpu().numpy()
+    res = {"mode": mode}
+    if mode == "frames":
+        g_own = g_loc
+    elif mode == "rows":
+        g_own = g_loc[:, loc_rows[0]:loc_rows[1], :]
+    else:
+        g_own = g_loc[sd.own_ch0:sd.own_ch1]
+    # ---- the sharded solve ----
+    x_sol, rep = p.solve(x_loc, opts, comm=comm, shard=sd)
+    if mode == "frames":
+        x_own = x_sol
+    elif mode == "rows":
+        x_own = x_sol[:, loc_rows[0]:loc_rows[1], :]
+    else:
+        x_own = x_sol[sd.own_ch0:sd.own_ch1]
+    gathered_g = [None] * world
+    gathered_x = [None] * world
+    dist.all_gather_object(gathered_g, g_own)
+    dist.all_gather_object(gathered_x, x_own)
+    if rank == 0:
+        full = full_problem()
+        f_ref, g_ref = full.eval(x0)
+        x_ref, rep_ref = full.solve(x0, opts)
+        if mode == "frames":
+            g_all, x_all = gathered_g[0], gathered_x[0]
+            res["replicas_equal"] = all(np.array_equal(gathered_x[0], gx) for gx in gathered_x)
+        elif mode == "rows":
+            g_all, x_all = np.concatenate(gathered_g, axis=1), np.concatenate(gathered_x, axis=1)
+        else:
+            g_all, x_all = np.concatenate(gathered_g, axis=0), np.concatenate(gathered_x, axis=0)
+        res.update(cost_err=abs(f - f_ref) / max(1.0, abs(f_ref)), grad_err=relerr(g_all, g_ref),
+                   solve_err=relerr(x_all, x_ref), evals=[rep.evaluations, rep_ref.evaluations],
+                   cg=[rep.cg_iterations, rep_ref.cg_iterations], irls=[rep.irls_rounds, rep_ref.irls_rounds],
+                   final_cost=[rep.final_cost, rep_ref.final_cost])
+        with open(out, "w") as fo:
+            json.dump(res, fo)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""Multi-GPU paths of the C ABI on ONE GPU: the sharded evaluation and the sharded IRLS/CG solve
+(srmap_eval_sharded_device, srmap_solve_sharded) with 2 ranks sharing GPU 0 over the host-callback communicator
+(gloo), for frame, row-band and channel (+ 3-D TV halo plane) shards, against the single-process result; the RCCL
+backend with a one-rank communicator; and the CG trajectory against ALGLIB's / the oracle's mincg."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("mode", ["frames", "rows", "channels"])
+def test_two_ranks_on_one_gpu(tmp_path, mode):
+    world, port = 2, _free_port()
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(r), str(world),
+                               str(port), mode, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = json.load(open(out))
+    print(res)
+    assert res["cost_err"] <= 1e-12 and res["grad_err"] <= 1e-11
+    # same decisions on every rank and as the single-process solve; iterates equal up to reduction order
+    assert res["cg"][0] == res["cg"][1] and res["irls"][0] == res["irls"][1] and res["evals"][0] == res["evals"][1]
+    assert res["solve_err"] <= 1e-9
+    if mode == "frames":
+        assert res["replicas_equal"]
+
+
+def test_rccl_backend_world_one():
+    """The RCCL code path (dlopen, ncclCommInitRank, ncclAllReduce on the stream) with a one-rank communicator."""
+    import torch
+    import srmap
+    ctx = srmap.Context(0)
+    uid = srmap.Comm.unique_id(ctx)
+    assert len(uid) == 128
+    comm = srmap.Comm(ctx, 0, 1, backend="rccl", unique_id=uid)
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    comm.allreduce(t.data_ptr(), t.numel(), srmap.F64, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    comm.allreduce(t.data_ptr(), t.numel(), srmap.F64, 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    # a one-rank communicator leaves the solve untouched
+    rng = np.random.default_rng(1)
+    shifts = [[0, 0], [1, 1], [0, 1], [1, 0]]
+    p = srmap.Problem(ctx, 48, 32, 1, 4, 2, shifts, 3, 1.0, srmap.F64)
+    p.set_observations(rng.random((4, 1, 16, 24)))
+    p.add_regularizer(srmap.REG_TV, 0.01)
+    x0 = rng.random((1, 32, 48))
+    sd = srmap.ShardDesc()
+    sd.mode = srmap.SHARD_FRAMES
+    xa, ra = p.solve(x0)
+    xb, rb = p.solve(x0, comm=comm, shard=sd)
+    assert np.array_equal(xa, xb) and ra.evaluations == rb.evaluations
+
+
+@pytest.mark.parametrize("blur", [0, 3])
+def test_cg_trajectory_matches_mincg(blur):
+    """run_cg (csrc/solver.hip) against ALGLIB's mincg (oracle/_ref when built, else the restatement, which is
+    bit-exact against it) on the SMOOTH data term: same iteration count, evaluation count and termination type, the
+    cost of every accepted iterate to 1e-11."""
+    import srmap
+    ctx = srmap.Context(0)
+    rng = np.random.default_rng(9)
+    s, K, h, w = 2, 4, 20, 28
+    H, W = h * s, w * s
+    shifts = [[0, 0], [1, 1], [0, 1], [1, 0]]
+    model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=blur, blur_sigma=1.0 if blur else 0.0)
+    gt = rng.random((1, H, W))
+    lr = np.stack([model.apply(gt, k) for k in range(K)]) + 0.01 * rng.standard_normal((K, 1, h, w))
+    ref = orc.Problem(model, lr)
+    x0 = orc.resize_nearest(lr[0, 0], W, H)[None]
+    eps = 1e-6 * x0.size * 0.0 + 1e-7
+    trace = []
+    x_ref, rep_ref = orc.mincg(lambda x: (lambda fg: (fg[0], fg[1].ravel()))(ref.objective(x.reshape(1, H, W))),
+                               x0, eps, eps, eps, 40, use_alglib=orc.have_ref(), trace=trace)
+    p = srmap.Problem(ctx, W, H, 1, K, s, shifts, blur, 1.0 if blur else 0.0, srmap.F64)
+    p.set_observations(lr)
+    x, its, nfev, term, ftrace = p.cg_trace(x0, eps, eps, eps, 40)
+    print("iterations %d/%d nfev %d/%d termination %d/%d" % (its, rep_ref.iterations, nfev, rep_ref.nfev, term,
+                                                              rep_ref.termination_type))
+    assert (its, nfev, term) == (rep_ref.iterations, rep_ref.nfev, rep_ref.termination_type)
+    assert len(ftrace) == nfev
+    # ALGLIB reports the accepted point of every iteration (xrep): its cost must appear in the GPU's evaluation log
+    f_iter = [f for _, f in trace]
+    for f in f_iter[1:]:
+        assert np.min(np.abs(ftrace - f) / max(1.0, abs(f))) <= 1e-11
+    assert abs(ftrace[-1] - rep_ref.f) <= 1e-11 * max(1.0, abs(rep_ref.f)) or \
+        np.min(np.abs(ftrace - rep_ref.f)) <= 1e-11 * max(1.0, abs(rep_ref.f))
+    assert np.max(np.abs(x - x_ref.reshape(1, H, W))) <= 1e-8
