@@ -200,6 +200,10 @@ typedef struct {
   int evaluations;       /* cost+gradient evaluations ("MAP gradient iterations") */
   int last_termination;  /* ALGLIB-style code of the last CG run */
   double final_cost;
+  double loop_seconds;   /* wall time of the IRLS / CG loop itself (device-resident part: no allocation,
+                            no upload / download of x) */
+  double wait_seconds;   /* part of loop_seconds the host spent waiting for device scalars */
+  int waits;             /* number of such waits (2 + nfev per CG iteration) */
 } srmap_solve_report;
 
 /* IRLSMapSolver::Solve(initial_estimate) irls_map_solver.cpp:192-265:

@@ -973,7 +973,7 @@ bool ztile_plan(srmap_problem* p) {
   }
   p->zplan = z;
   if (!ok) { ztile_release(p); return false; }
-  return true;
+  return true;  // the caller preloads the kernel instance (ztile_preload)
 }
 
 size_t ztile_partials_needed(const srmap_problem* p) {
@@ -1027,6 +1027,39 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   *nblocks = n_tile_partials + nbb * (int)grid.z;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
+}
+
+// HIP loads a kernel's code object lazily at its first launch (milliseconds): touch the instance when the plan is
+// made, not inside the first evaluation of a solve.
+template <typename T, int S, int B, int REGK, int R>
+static void preload_z() {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R>));
+}
+template <typename T, int S, int B>
+static void preload_reg(int regk, int regr) {
+  preload_z<T, S, B, 0, 0>();
+  if (regk == 1) preload_z<T, S, B, 1, 0>();
+  if (regk == 2 && regr == 1) preload_z<T, S, B, 2, 1>();
+  if (regk == 2 && regr == 2) preload_z<T, S, B, 2, 2>();
+  if (regk == 2 && regr == 3) preload_z<T, S, B, 2, 3>();
+}
+template <typename T>
+static void preload_sb(int S, int B, int regk, int regr) {
+  if (S == 2 && B == 1) preload_reg<T, 2, 1>(regk, regr);
+  else if (S == 2 && B == 3) preload_reg<T, 2, 3>(regk, regr);
+  else if (S == 3 && B == 1) preload_reg<T, 3, 1>(regk, regr);
+  else if (S == 3 && B == 3) preload_reg<T, 3, 3>(regk, regr);
+  else if (S == 4 && B == 1) preload_reg<T, 4, 1>(regk, regr);
+  else if (S == 4 && B == 3) preload_reg<T, 4, 3>(regk, regr);
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_finish_eval<T>));
+}
+void ztile_preload(const srmap_problem* p) {
+  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
+  if (!z) return;
+  if (p->dtype == SRMAP_F32) preload_sb<float>(z->S, z->B, z->regk, z->regr);
+  else preload_sb<double>(z->S, z->B, z->regk, z->regr);
 }
 
 template <typename T, int S, int B>

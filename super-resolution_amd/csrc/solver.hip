@@ -92,24 +92,45 @@ __global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, T* __rest
   block_partials3(mx, ss, 0.0, part, true);
 }
 
-// Second stage: rows x nb partials -> out[rows] in fixed order; row 0 is a max when max0.  extra_src, when given,
-// is one more device scalar (the cost of the evaluation) forwarded to out[rows].
+// Second stage: rows (<= 3) x nb partials -> out[rows] in fixed order; row 0 is a max when max0.  extra_src, when
+// given, is one more device scalar (the cost of the evaluation) forwarded to out[rows].  When `tag_slot` is given
+// (host-mapped memory) the kernel finally stores `tag` there behind a system-scope fence: the host polls that word
+// instead of paying a stream synchronisation (tens of microseconds per wait on this runtime).
 __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ part, int nb, int rows, int max0,
-                                               double* __restrict__ out, const double* __restrict__ extra_src) {
-  __shared__ double red[4];
-  if (extra_src != nullptr && threadIdx.x == 0) out[rows] = extra_src[0];
-  for (int r = 0; r < rows; ++r) {
-    const bool is_max = max0 && r == 0;
-    double v = 0;
-    for (int i = threadIdx.x; i < nb; i += 256)
-      v = is_max ? fmax(v, part[(size_t)r * nb + i]) : v + part[(size_t)r * nb + i];
-    v = is_max ? wmax(v) : wsum(v);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wid] = v;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      out[r] = is_max ? fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+                                               double* __restrict__ out, const double* __restrict__ extra_src,
+                                               double* tag_slot, double tag) {
+  __shared__ double red[3][4];
+  double v0 = 0, v1 = 0, v2 = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    if (rows > 0) { const double a = part[i]; v0 = max0 ? fmax(v0, a) : v0 + a; }
+    if (rows > 1) v1 += part[(size_t)nb + i];
+    if (rows > 2) v2 += part[(size_t)2 * nb + i];
+  }
+  v0 = max0 ? wmax(v0) : wsum(v0);
+  v1 = wsum(v1);
+  v2 = wsum(v2);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wid] = v0; red[1][wid] = v1; red[2][wid] = v2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (rows > 0) out[0] = max0 ? fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))
+                                : (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    if (rows > 1) out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (rows > 2) out[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    if (extra_src != nullptr) out[rows] = extra_src[0];
+    if (tag_slot != nullptr) {
+      __threadfence_system();
+      *(volatile double*)tag_slot = tag;
+    }
+  }
+}
+
+// dst[0..n) = src[0..n) (device scalars -> host-mapped memory), then the tag (see k_finish)
+__global__ void k_publish(double* __restrict__ dst, const double* __restrict__ src, int n, double* tag_slot, double tag) {
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < n; ++i) dst[i] = src[i];
+    __threadfence_system();
+    *(volatile double*)tag_slot = tag;
   }
 }
 
@@ -268,8 +289,30 @@ struct DeviceCG {
   T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr, *yk = nullptr;
   double* part = nullptr;   // [3][kRedBlocks]
   double* dscal = nullptr;  // device scalars: [0..3] reduction results, [4..5] direction norms
-  double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal), read after one stream sync
+  double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal): results [0..11], arrival tag [15]
+  double tag = 0;           // last tag handed to a publishing kernel
   int evaluations = 0;
+  double wait_seconds = 0;  // host time spent in wait_tag
+  int waits = 0;
+
+  // Wait until the kernel that was given `tag` has published its results (see k_finish): poll the host-mapped word,
+  // fall back to a stream synchronisation after ~2 s (also surfaces asynchronous errors).
+  int wait_tag() {
+    volatile double* slot = hs + 15;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Acc { DeviceCG* c; std::chrono::steady_clock::time_point t; ~Acc() {
+      c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); c->waits++; } } acc{this, t0};
+    unsigned spins = 0;
+    while (*slot != tag) {
+      if ((++spins & 0x3ff) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+        SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+        if (*slot != tag) return set_error(p->ctx, SRMAP_EHIP, "solver: device results did not arrive");
+        break;
+      }
+    }
+    return SRMAP_OK;
+  }
 
   unsigned blocks() const { return (unsigned)((n + 255) / 256); }
   int nb() const { size_t b = (n + 255) / 256; return (int)(b < (size_t)kRedBlocks ? b : kRedBlocks); }
@@ -283,6 +326,8 @@ struct DeviceCG {
     int rc = ensure_staging(p->ctx);
     if (rc) return rc;
     hs = p->ctx->h_scal;
+    SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+    tag = hs[15];  // tags keep increasing across solves of one context: a stale word can never match
     return SRMAP_OK;
   }
   void release() {
@@ -297,15 +342,21 @@ struct DeviceCG {
   }
   // Reduce the `rows` partial rows (+ the evaluation's cost when with_cost) and bring them to the host:
   // out[0..rows) (+ out[rows] = cost).  One stream synchronisation.
-  int finish(int rows, bool max0, bool with_cost, double* out) {
+  int finish(int rows, bool max0, bool with_cost, double* out, int extra_n = 0) {
     const int cnt = rows + (with_cost ? 1 : 0);
+    tag += 1.0;
     if (!reduce_scalars) {
-      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, hs,
-                         with_cost ? (const double*)p->d_cost : (const double*)nullptr);
-      SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+      if (extra_n > 0) {
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, hs,
+                           with_cost ? (const double*)p->d_cost : (const double*)nullptr, (double*)nullptr, 0.0);
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, hs + 8, (const double*)(dscal + 4), extra_n, hs + 15, tag);
+      } else {
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, hs,
+                           with_cost ? (const double*)p->d_cost : (const double*)nullptr, hs + 15, tag);
+      }
     } else {
       hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, dscal,
-                         with_cost ? (const double*)p->d_cost : (const double*)nullptr);
+                         with_cost ? (const double*)p->d_cost : (const double*)nullptr, (double*)nullptr, 0.0);
       int rc = SRMAP_OK;
       if (max0) {
         rc = comm_allreduce(comm, dscal, 1, SRMAP_F64, 1, st);
@@ -315,9 +366,13 @@ struct DeviceCG {
         rc = comm_allreduce(comm, dscal, (size_t)cnt, SRMAP_F64, 0, st);
       }
       if (rc) return rc;
-      SRMAP_HIP(p->ctx, hipMemcpyAsync(hs, dscal, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
-      SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+      if (extra_n > 0)
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, hs + 8, (const double*)(dscal + 4), extra_n, (double*)(hs + 14), 0.0);
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, hs, (const double*)dscal, cnt, hs + 15, tag);
     }
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    int rc = wait_tag();
+    if (rc) return rc;
     for (int i = 0; i < cnt; ++i) out[i] = hs[i];
     return SRMAP_OK;
   }
@@ -329,7 +384,8 @@ struct DeviceCG {
   // dn = -g + beta dk (dk may be null), yk = -g; direction norms -> dscal[4..5] (device, all-reduced)
   int direction(const T* dk_or_null, double beta) {
     hipLaunchKernelGGL(k_direction<T>, dim3(nb()), dim3(256), 0, st, dn, yk, (const T*)g, dk_or_null, (T)beta, n, ow, part);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr,
+                       (double*)nullptr, 0.0);
     if (reduce_scalars) {
       int rc = comm_allreduce(comm, dscal + 4, 1, SRMAP_F64, 1, st);
       if (rc) return rc;
@@ -529,18 +585,10 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
   rc = cg.direction(nullptr, 0.0);
   if (rc) return rc;
   {
+    // fetch f and g.g (= dn.dn, already reduced on the device) with one wait
     double h[1];
-    // fetch f and g.g (= dn.dn, already reduced on the device) with one synchronisation
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, cg.st, cg.part, 0, 0, 0, cg.reduce_scalars ? cg.dscal : cg.hs,
-                       (const double*)cg.p->d_cost);
-    if (cg.reduce_scalars) {
-      rc = comm_allreduce(cg.comm, cg.dscal, 1, SRMAP_F64, 0, cg.st);
-      if (rc) return rc;
-      SRMAP_HIP(cg.p->ctx, hipMemcpyAsync(cg.hs, cg.dscal, sizeof(double), hipMemcpyDeviceToHost, cg.st));
-    }
-    SRMAP_HIP(cg.p->ctx, hipMemcpyAsync(cg.hs + 8, cg.dscal + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, cg.st));
-    SRMAP_HIP(cg.p->ctx, hipStreamSynchronize(cg.st));
-    h[0] = cg.hs[0];
+    rc = cg.finish(0, false, true, h, 2);
+    if (rc) return rc;
     f = h[0];
     gg = cg.hs[9];
   }
@@ -558,9 +606,8 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     {
       hipLaunchKernelGGL(k_normalize_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
                          (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6);
-      SRMAP_HIP(cg.p->ctx, hipMemcpyAsync(cg.hs + 8, cg.dscal + 4, sizeof(double) * 4, hipMemcpyDeviceToHost, cg.st));
       double h[2];
-      rc = cg.finish(2, false, false, h);
+      rc = cg.finish(2, false, false, h, 4);  // + {max|dk|, dk.dk, s1, s2} -> hs[8..11]
       if (rc) return rc;
       dginit = h[0];
       dd = h[1];
@@ -660,7 +707,7 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
       o.irls_cost_difference_threshold *= scale;
     }
   }
-  srmap_solve_report rep = {0, 0, 0, 0, 0.0};
+  srmap_solve_report rep = {0, 0, 0, 0, 0.0, 0.0, 0.0, 0};
   hipStream_t st = p->ctx->stream;
   DeviceCG<T> cg;
   cg.p = p; cg.st = st; cg.n = npts; cg.comm = comm; cg.shard = shard;
@@ -694,6 +741,8 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
     double previous_cost = INFINITY;
     double cost_difference = o.irls_cost_difference_threshold + 1.0;
     int ran = 0;
+    SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+    const auto t_loop0 = std::chrono::steady_clock::now();
     while (std::fabs(cost_difference) >= o.irls_cost_difference_threshold) {
       CgResult cr;
       rc = run_cg(cg, o.gradient_norm_threshold, o.cost_decrease_threshold, o.parameter_variation_threshold,
@@ -720,12 +769,16 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
       if (o.max_num_irls_iterations > 0 && ran >= o.max_num_irls_iterations) break;
     }
     if (rc) break;
+    (void)hipStreamSynchronize(st);
+    rep.loop_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();
     rep.irls_rounds += ran;
     rc = shard_exchange_x(p, comm, mode == SRMAP_SHARD_NONE ? nullptr : shard, cg.x, st);  // x_out carries valid halos
     if (rc) break;
     rc = convert_download(p, cg.x, x_out + (size_t)c0 * N, npts, st);
   }
   rep.evaluations = cg.evaluations;
+  rep.wait_seconds = cg.wait_seconds;
+  rep.waits = cg.waits;
   p->view_c0 = saved_c0;
   p->view_C = saved_C;
   if (regvals) (void)hipFree(regvals);

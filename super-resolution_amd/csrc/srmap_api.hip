@@ -128,7 +128,7 @@ int ensure_staging(srmap_ctx* ctx) {
     if (!ctx->h_event[i]) SRMAP_HIP(ctx, hipEventCreateWithFlags(&ctx->h_event[i], hipEventDisableTiming));
   }
   if (!ctx->h_scal) {
-    SRMAP_HIP(ctx, hipHostMalloc((void**)&ctx->h_scal, 16 * sizeof(double), hipHostMallocMapped));
+    SRMAP_HIP(ctx, hipHostMalloc((void**)&ctx->h_scal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     for (int i = 0; i < 16; ++i) ctx->h_scal[i] = 0.0;
   }
   return SRMAP_OK;
@@ -321,7 +321,7 @@ int srmap_ctx_create(int device_id, srmap_ctx** out) {
     return SRMAP_EHIP;
   }
   ctx->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return SRMAP_EHIP;
   }
@@ -450,7 +450,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   (void)hipMemset(p->d_cost, 0, sizeof(double) * 8);
   (void)hipMemset(p->d_counters, 0, sizeof(unsigned) * 64 * 34);
   p->plan.usable = tiled_plan(p);
-  (void)ztile_plan(p);
+  if (ztile_plan(p)) ztile_preload(p);
   *out = p;
   return SRMAP_OK;
 }
@@ -547,7 +547,7 @@ int srmap_add_regularizer(srmap_problem* p, int kind, double lambda, int btv_ran
   if (reg_index) *reg_index = p->nreg;
   p->nreg++;
   p->plan.usable = tiled_plan(p);
-  (void)ztile_plan(p);
+  if (ztile_plan(p)) ztile_preload(p);
   return SRMAP_OK;
 }
 
@@ -556,7 +556,7 @@ int srmap_clear_regularizers(srmap_problem* p) {
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) { (void)hipFree(p->reg[r].weights); p->reg[r].weights = nullptr; }
   p->nreg = 0;
   p->plan.usable = tiled_plan(p);
-  (void)ztile_plan(p);
+  if (ztile_plan(p)) ztile_preload(p);
   return SRMAP_OK;
 }
 

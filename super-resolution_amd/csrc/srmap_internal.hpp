@@ -165,6 +165,7 @@ int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
 // ---- z-tile kernels (kernels_ztile.hip): the hot path ----
 bool ztile_plan(srmap_problem* p);
 void ztile_release(srmap_problem* p);
+void ztile_preload(const srmap_problem* p);
 size_t ztile_partials_needed(const srmap_problem* p);
 template <typename T>
 int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,

@@ -45,7 +45,8 @@ class IrlsOptions(C.Structure):
 
 class SolveReport(C.Structure):
     _fields_ = [("irls_rounds", C.c_int), ("cg_iterations", C.c_int), ("evaluations", C.c_int),
-                ("last_termination", C.c_int), ("final_cost", C.c_double)]
+                ("last_termination", C.c_int), ("final_cost", C.c_double), ("loop_seconds", C.c_double),
+                ("wait_seconds", C.c_double), ("waits", C.c_int)]
 
 
 class ShardDesc(C.Structure):
