@@ -11,12 +11,15 @@ N = 1 workload: BASELINE.json configs[1] -- 16-frame grayscale, 4x upscale to
 N > 1 (one process per GPU, torch.distributed over RCCL): the path shards by
 channel (the reference's split_channels semantics, irls_map_solver.cpp:200-262):
 rank r owns channel r of an N-channel problem of the same per-channel geometry,
-so per-GPU work is fixed ("weak" scaling); the only exchange of a joint solve
-is the all-reduce of the scalar cost, which is issued every step over RCCL.
+so per-GPU work is fixed ("weak" scaling) and -- these being the reference's
+independent per-channel solves -- there is no collective in the timed region.
 `value` counts channel-iterations per second summed over ranks (at N = 1 this is
 plain iterations per second).  `--shard frames` runs the north-star's
 frame-sharded variant instead (each rank K/N frames of the SAME image + RCCL
-all-reduce of the HR gradient), reported as strong scaling.
+all-reduce of the HR gradient), `--shard rows` the row-band variant (halo rows of
+x exchanged with ncclSend / ncclRecv); both go through the library's own
+sharded evaluation (srmap_eval_sharded_device: the exchange is issued by the C
+ABI on the evaluation's stream) and are reported as strong scaling.
 
 Prints ONE JSON line on rank 0 (see the task contract), including
   "roofline":     algorithmic bytes of one step / mean step time vs 8 TB/s HBM
@@ -57,7 +60,7 @@ def bilinear_upsample(img, s):
 def pmc_traffic(dtype):
     """HBM bytes per launch of the fused kernel from the committed PMC profile
     of this same command (bench.py cannot run rocprofv3 on itself)."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_bench_hbm_pmc.json")
     try:
         with open(path) as f:
             rec = json.load(f)[dtype]
@@ -117,7 +120,7 @@ def main():
                          "paths; the numbers mean nothing)")
     ap.add_argument("--joint-scalars", action="store_true",
                     help="channel sharding only: also all-reduce the scalar cost every step, as ONE joint solve over "
-                         "all channels would (srmap_solve_ex hook). Default: the reference's split_channels semantics "
+                         "all channels would (srmap_solve_sharded). Default: the reference's split_channels semantics "
                          "(irls_map_solver.cpp:200-210), independent per-channel solves, no collective in the timed region")
     args = ap.parse_args()
 
@@ -188,10 +191,30 @@ def main():
     wts = 1.0 / np.maximum(1e-5, rv0)
     prob.set_irls_weights(reg, wts)
 
-    if world > 1 and args.shard == "rows":
-        prob.set_cost_rows(r0 - e0, r1 - e0)
-        band = srmap_dist.BandObjective((r0, r1), (e0, e1), None, dist)
-        band.set_peer_halos([(b[0][0] - b[1][0], b[1][1] - b[0][1]) for b in bands])
+    # ---- the library's communicator and shard description (N > 1, frames / rows): the exchanges run inside the C ABI
+    comm, sd = None, None
+    if world > 1 and args.shard in ("frames", "rows"):
+        if args.test_single_device:
+            comm = srmap.Comm(ctx, rank, world, backend="host", dist=dist)
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(srmap.Comm.unique_id(ctx)), dtype=torch.uint8).to(dev)
+            dist.broadcast(uid, 0)
+            comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=bytes(uid.cpu().numpy().tobytes()))
+        sd = srmap.ShardDesc()
+        if args.shard == "frames":
+            sd.mode, sd.reg_rank = srmap.SHARD_FRAMES, 0
+        else:
+            prob.set_cost_rows(r0 - e0, r1 - e0)
+            sd.mode = srmap.SHARD_ROWS
+            sd.own_row0, sd.own_row1 = r0 - e0, r1 - e0
+            if rank + 1 < world:
+                (n0, n1), (ne0, ne1) = bands[rank + 1]
+                sd.send_down_rows = n0 - ne0
+            if rank > 0:
+                (u0, u1), (ue0, ue1) = bands[rank - 1]
+                sd.send_up_rows = ue1 - u1
 
     x_dev = torch.from_numpy(x0).to(dev, tdtype).contiguous()
     g_dev = torch.empty_like(x_dev)
@@ -199,22 +222,15 @@ def main():
     sh = stream.cuda_stream
     cost_buf = torch.zeros(1, dtype=torch.float64, device=dev)
     terms = {"all": srmap.TERM_ALL, "data": srmap.TERM_DATA, "reg": srmap.TERM_REG}[args.terms]
-    if world > 1 and args.shard == "frames" and rank != 0:
-        terms = srmap.TERM_DATA  # the regulariser term is evaluated once (rank 0)
 
     def step():
-        if band is not None:
-            with torch.cuda.stream(stream):
-                band.exchange_halos(x_dev)          # boundary rows of x from the neighbour ranks (xGMI p2p)
-        prob.eval_device(x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
-        if dist is not None:
-            with torch.cuda.stream(stream):
-                if args.shard == "frames":
-                    dist.all_reduce(g_dev)          # HR gradient all-reduce over RCCL/xGMI
-                    dist.all_reduce(cost_buf)       # scalar cost of the joint objective
-                elif args.shard == "rows":
-                    dist.all_reduce(cost_buf)       # scalar cost (sum of the owned-row costs)
-                elif args.joint_scalars:
+        if comm is not None:
+            # halo rows of x (rows) / gradient + cost all-reduce (frames): issued by the library on `sh`
+            prob.eval_sharded_device(comm, sd, x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
+        else:
+            prob.eval_device(x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
+            if dist is not None and args.joint_scalars:
+                with torch.cuda.stream(stream):
                     dist.all_reduce(cost_buf)
 
     def barrier():
@@ -268,18 +284,19 @@ def main():
                                    "lambda 0.01, IRLS weights from x0" % (W, H),
                        "frames": K, "scale": s, "channels": C_total, "shard": args.shard if world > 1 else "none",
                        "collective_per_step": ("none" if world == 1 else
-                                               "all-reduce(g, C*N) + all-reduce(cost)" if args.shard == "frames" else
-                                               "p2p halo rows of x + all-reduce(cost)" if args.shard == "rows" else
+                                               "ncclAllReduce(g, C*N) + ncclAllReduce(cost) inside srmap_eval_sharded_device" if args.shard == "frames" else
+                                               "ncclSend/ncclRecv of the halo rows of x inside srmap_eval_sharded_device" if args.shard == "rows" else
                                                "all-reduce(cost)" if args.joint_scalars else
                                                "none (split_channels: independent per-channel solves)"),
                        "impl": args.impl, "device_ms_per_step": dev_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.dtype),
-                         "traffic_source": "profiles/r01_bench_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                         "traffic_source": "profiles/r02_bench_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                            "(separate passes) of this command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                                            "the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md",
                          "algorithmic_bytes_per_step": b_alg / max(C_total, 1),
-                         "kernel": "whole evaluation (all kernels of one step), HIP events on the launch stream"},
+                         "kernel": "whole evaluation (k_eval_z + k_finish_eval: all kernels of one step), HIP events on "
+                                   "the launch stream; the dominant kernel alone is in profiles/r02_bench_*_kernel_stats.csv"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, lr, x0, wts)
