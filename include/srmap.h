@@ -59,8 +59,7 @@ enum {
 
 /* Kernel family selection (for tests and A/B measurements; AUTO picks the
  * LDS-tiled kernels whenever the problem geometry admits them). */
-typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2,
-               SRMAP_IMPL_TILED_V1 = 3 /* round-1 per-frame fused kernel, kept for A/B */ } srmap_impl;
+typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */
 /* Binds HIP device `device_id`.  Replaces nothing in the reference (it has no

@@ -43,11 +43,37 @@
 //   phase 2  vertical half of B^T from zh; regulariser pass 2; g store.
 // No MFMA: stencil path.  Cost partials are reduced in fixed order
 // (deterministic).
-#include "tiled_device.hpp"
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "srmap_internal.hpp"
 
 namespace srmap {
 
+// integer floor division / modulo on the host
+static inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+static inline int pmod(int a, int b) { return a - fdiv(a, b) * b; }
+
 namespace {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+constexpr int posmod(int a, int b) { return a - floordiv(a, b) * b; }
+
+template <typename T>
+__device__ __forceinline__ T absv(T d) { return d < T(0) ? -d : d; }
+template <>
+__device__ __forceinline__ float absv<float>(float d) { return __builtin_fabsf(d); }
+template <>
+__device__ __forceinline__ double absv<double>(double d) { return __builtin_fabs(d); }
 
 constexpr int zmax(int a, int b) { return a > b ? a : b; }
 constexpr int zceil(int a, int b) { return (a + b - 1) / b; }

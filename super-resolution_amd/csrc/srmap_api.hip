@@ -235,16 +235,12 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
   if (rc) return rc;
   if ((terms & SRMAP_TERM_DATA) && !p->have_obs)
     return set_error(p->ctx, SRMAP_EINVAL, "data term requested but no observations set");
-  const bool ztile = (p->impl == SRMAP_IMPL_AUTO || p->impl == SRMAP_IMPL_TILED) && p->zplan != nullptr;
-  const bool tiled = !ztile && p->impl != SRMAP_IMPL_DIRECT && p->plan.usable;
-  if ((p->impl == SRMAP_IMPL_TILED && !ztile && !p->plan.usable) || (p->impl == SRMAP_IMPL_TILED_V1 && !p->plan.usable))
+  const bool ztile = p->impl != SRMAP_IMPL_DIRECT && p->zplan != nullptr;
+  if (p->impl == SRMAP_IMPL_TILED && !ztile)
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "tiled kernels do not cover this geometry");
   int nparts = 0;
   if (ztile) {
     rc = launch_eval_ztile<T>(p, geo, c0, terms, x, g, p->d_partials, &nparts, st);
-    if (rc) return rc;
-  } else if (tiled) {
-    rc = launch_eval_tiled<T>(p, geo, c0, terms, x, g, p->d_partials, &nparts, st);
     if (rc) return rc;
   } else {
     bool g_written = false;
@@ -288,7 +284,7 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
       }
     }
   }
-  if ((tiled || ztile) && nparts == 0) return SRMAP_OK;  // reduced inside the last kernel of the evaluation
+  if (ztile && nparts == 0) return SRMAP_OK;  // reduced inside the last kernel of the evaluation
   return launch_reduce_partials(p, p->d_partials, nparts, p->d_cost, st);
 }
 
@@ -442,14 +438,11 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   }
   if (hipMalloc((void**)&p->d_col_map, sizeof(int) * g.w) != hipSuccess ||
       hipMalloc((void**)&p->d_row_map, sizeof(int) * g.h) != hipSuccess ||
-      hipMalloc((void**)&p->d_cost, sizeof(double) * 8) != hipSuccess ||
-      hipMalloc((void**)&p->d_counters, sizeof(unsigned) * 64 * 34) != hipSuccess)
+      hipMalloc((void**)&p->d_cost, sizeof(double) * 8) != hipSuccess)
     return fail(set_error(ctx, SRMAP_ENOMEM, "hipMalloc failed"));
   (void)hipMemcpy(p->d_col_map, cmap.data(), sizeof(int) * g.w, hipMemcpyHostToDevice);
   (void)hipMemcpy(p->d_row_map, rmap.data(), sizeof(int) * g.h, hipMemcpyHostToDevice);
   (void)hipMemset(p->d_cost, 0, sizeof(double) * 8);
-  (void)hipMemset(p->d_counters, 0, sizeof(unsigned) * 64 * 34);
-  p->plan.usable = tiled_plan(p);
   if (ztile_plan(p)) ztile_preload(p);
   *out = p;
   return SRMAP_OK;
@@ -457,10 +450,9 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
 
 void srmap_problem_destroy(srmap_problem* p) {
   if (!p) return;
-  tiled_release(p);
   ztile_release(p);
   void* bufs[] = {p->d_fwd_warps, p->d_bwd_warps, p->d_blur, p->d_blur_t, p->d_col_map, p->d_row_map,
-                  p->d_obs, p->d_resid, p->d_regvals, p->d_x, p->d_g, p->d_tmp, p->d_partials, p->d_cost, p->d_counters};
+                  p->d_obs, p->d_resid, p->d_regvals, p->d_x, p->d_g, p->d_tmp, p->d_partials, p->d_cost};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) (void)hipFree(p->reg[r].weights);
   delete p;
@@ -468,7 +460,7 @@ void srmap_problem_destroy(srmap_problem* p) {
 
 int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
-  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED_V1) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
+  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
   return SRMAP_OK;
 }
@@ -546,7 +538,6 @@ int srmap_add_regularizer(srmap_problem* p, int kind, double lambda, int btv_ran
   }
   if (reg_index) *reg_index = p->nreg;
   p->nreg++;
-  p->plan.usable = tiled_plan(p);
   if (ztile_plan(p)) ztile_preload(p);
   return SRMAP_OK;
 }
@@ -555,7 +546,6 @@ int srmap_clear_regularizers(srmap_problem* p) {
   if (!p) return SRMAP_EINVAL;
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) { (void)hipFree(p->reg[r].weights); p->reg[r].weights = nullptr; }
   p->nreg = 0;
-  p->plan.usable = tiled_plan(p);
   if (ztile_plan(p)) ztile_preload(p);
   return SRMAP_OK;
 }

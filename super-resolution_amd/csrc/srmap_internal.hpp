@@ -47,12 +47,6 @@ struct RegSpec {
   double pow_table[2 * kMaxBtvRange + 1];  // std::pow(decay, k), host libm
 };
 
-// Tile geometry of the LDS-tiled kernels for one problem.
-struct TilePlan {
-  bool usable = false;
-  int halo_l = 0, halo_r = 0, halo_u = 0, halo_d = 0;  // x halo of the fused tile
-};
-
 }  // namespace srmap
 
 struct srmap_ctx {
@@ -98,10 +92,8 @@ struct srmap_problem {
   double* d_partials = nullptr;   // per-block cost partials
   size_t partials_cap = 0;
   double* d_cost = nullptr;       // [4] reduced scalars
-  unsigned* d_counters = nullptr; // arrival counters of the fused kernel's in-kernel reduction (33 x 256 B)
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
-  srmap::TilePlan plan;
   void* zplan = nullptr;          // srmap::ZPlan of the z-tile kernels (kernels_ztile.hip), owned; nullptr = not covered
   // channel view of the current evaluation (split_channels solves one channel
   // at a time, irls_map_solver.cpp:200-262); default = all channels
@@ -154,13 +146,6 @@ int launch_irls_weights(srmap_problem* p, const T* values, T* weights, size_t n,
 int reduce_scratch_slots(size_t n);
 int launch_reduce_partials(srmap_problem* p, const double* partials, int n,
                            double* out, hipStream_t st);
-
-// ---- LDS-tiled kernels (kernels_tiled.hip) ----
-bool tiled_plan(srmap_problem* p);
-void tiled_release(srmap_problem* p);
-template <typename T>
-int launch_eval_tiled(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,
-                      const T* x, T* g, double* partials, int* nblocks, hipStream_t st);
 
 // ---- z-tile kernels (kernels_ztile.hip): the hot path ----
 bool ztile_plan(srmap_problem* p);

@@ -1,8 +1,9 @@
 // Solver / MapSolver / IRLSMapSolver and their option structs
 // (src/optimization/solver.h:14-43, map_solver.{h,cpp}, irls_map_solver.{h,cpp}),
-// plus ObjectiveFunction / ObjectiveTerm (objective_function.{h,cpp},
-// objective_data_term.{h,cpp}, objective_irls_regularization_term.{h,cpp}), all
-// evaluated on the GPU through the C ABI.  Only the CG solver with analytic
+// evaluated on the GPU through the C ABI; the term-by-term classes
+// (ObjectiveFunction / ObjectiveTerm / ObjectiveDataTerm /
+// ObjectiveIRLSRegularizationTerm) live in optimization/objective_function.h.
+// Only the CG solver with analytic
 // differentiation exists (the reference's L-BFGS / numeric-difference variants
 // are alternatives outside the path; the enum is kept for source parity).
 #pragma once
@@ -15,6 +16,7 @@
 
 #include "image/image_data.h"
 #include "image_model/image_model.h"
+#include "optimization/objective_function.h"
 #include "optimization/regularizer.h"
 #include "util/srmap_host.h"
 

@@ -8,6 +8,8 @@
 //   test/test_map_solver.cpp:369-469   RegularizationTest (PSNR ordering)
 //   test/test_evaluation.cpp:12-47     PSNR literal
 //   test/test_spectral_pca.cpp:19-137  SpectralPCA literal + reconstruction bounds
+//   src/optimization/irls_map_solver.cpp:200-262  the objective assembled term by term (ObjectiveFunction,
+//       ObjectiveDataTerm, ObjectiveIRLSRegularizationTerm) equals MapSolver::ComputeAllTerms
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -172,6 +174,97 @@ static void TestRegularizationOrdering() {
   EXPECT(p_btv > p_none);
 }
 
+static void TestObjectiveTerms() {
+  // The reference assembles its objective term by term (irls_map_solver.cpp:212-236): data term over the
+  // (NN-upsampled) observations + one IRLS term per regulariser, summed by ObjectiveFunction::ComputeAllTerms, which
+  // zeroes the gradient and lets every term ACCUMULATE (objective_function.cpp:5-20).
+  const int W = 24, H = 16, C = 2, s = 2;
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<double> uni(0.0, 1.0);
+  std::vector<double> gt(static_cast<size_t>(W) * H * C), x(gt.size());
+  for (double& v : gt) v = uni(rng);
+  for (double& v : x) v = uni(rng);
+  const ImageData ground_truth(gt.data(), cv::Size(W, H), C);
+  ImageModelParameters params;
+  params.scale = s;
+  params.blur_radius = 3;
+  params.blur_sigma = 1.0;
+  params.motion_sequence = MotionShiftSequence({MotionShift(0, 0), MotionShift(1, 1), MotionShift(0, 1), MotionShift(1, 0)});
+  const ImageModel model = ImageModel::CreateImageModel(params);
+  std::vector<ImageData> low_res, upsampled;
+  for (int k = 0; k < 4; ++k) {
+    low_res.push_back(model.ApplyToImage(ground_truth, k));
+    // what MapSolver hands to the data term in the reference: NN-upsampled to HR (map_solver.cpp:80-85)
+    std::vector<double> up(static_cast<size_t>(W) * H * C);
+    for (int c = 0; c < C; ++c)
+      for (int r = 0; r < H; ++r)
+        for (int q = 0; q < W; ++q) up[(static_cast<size_t>(c) * H + r) * W + q] = low_res[k].GetChannelData(c)[(r / s) * (W / s) + q / s];
+    upsampled.push_back(ImageData(up.data(), cv::Size(W, H), C));
+  }
+  const cv::Size size(W, H);
+  const size_t n = gt.size();
+  std::vector<double> w_tv(n), w_btv(n);
+  for (size_t i = 0; i < n; ++i) { w_tv[i] = 0.5 + uni(rng); w_btv[i] = 0.5 + uni(rng); }
+  auto tv = std::make_shared<TotalVariationRegularizer>(size);
+  auto btv = std::make_shared<BilateralTotalVariationRegularizer>(size, 3, 0.5);
+
+  // reference value: the fused device path
+  IRLSMapSolverOptions options;
+  IRLSMapSolver solver(options, model, low_res, false);
+  solver.AddRegularizer(tv, 0.03);
+  solver.AddRegularizer(btv, 0.02);
+  srmap_host::Check(srmap_set_irls_weights(solver.problem(), 0, w_tv.data()), "weights");
+  srmap_host::Check(srmap_set_irls_weights(solver.problem(), 1, w_btv.data()), "weights");
+  std::vector<double> g_ref(n);
+  const double f_ref = solver.ComputeAllTerms(x.data(), g_ref.data());
+
+  for (int variant = 0; variant < 2; ++variant) {  // LR observations / the reference's NN-upsampled ones
+    ObjectiveFunction objective(static_cast<int>(n));
+    auto data = std::make_shared<ObjectiveDataTerm>(model, variant ? upsampled : low_res, 0, C, size);
+    auto t1 = std::make_shared<ObjectiveIRLSRegularizationTerm>(tv, 0.03, w_tv, C, size);
+    auto t2 = std::make_shared<ObjectiveIRLSRegularizationTerm>(btv, 0.02, w_btv, C, size);
+    auto t0 = std::make_shared<ObjectiveIRLSRegularizationTerm>(btv, 0.0, w_btv, C, size);  // lambda <= 0: skipped
+    objective.AddTerm(data);
+    objective.AddTerm(t1);
+    objective.AddTerm(t2);
+    objective.AddTerm(t0);
+    std::vector<double> g(n, 123.0);  // ComputeAllTerms must zero it first
+    const double f = objective.ComputeAllTerms(x.data(), g.data());
+    EXPECT(std::fabs(f - f_ref) <= 1e-12 * std::fabs(f_ref));
+    double err = 0;
+    for (size_t i = 0; i < n; ++i) err = std::fmax(err, std::fabs(g[i] - g_ref[i]) / std::fmax(1.0, std::fabs(g_ref[i])));
+    EXPECT(err <= 1e-11);
+    EXPECT(std::fabs(objective.ComputeAllTerms(x.data()) - f) <= 1e-12 * std::fabs(f));  // gradient == nullptr: cost only
+    // a term ACCUMULATES into the gradient it is given and returns its own cost
+    std::vector<double> acc(n, 1.0), alone(n, 0.0);
+    const double c1 = t1->Compute(x.data(), alone.data());
+    const double c1b = t1->Compute(x.data(), acc.data());
+    EXPECT(c1 == c1b);
+    double acc_err = 0;
+    for (size_t i = 0; i < n; ++i) acc_err = std::fmax(acc_err, std::fabs(acc[i] - (1.0 + alone[i])));
+    EXPECT(acc_err <= 1e-12);
+    std::vector<double> untouched(n, 5.0);
+    EXPECT(t0->Compute(x.data(), untouched.data()) == 0.0);
+    for (size_t i = 0; i < n; ++i) if (untouched[i] != 5.0) { EXPECT(false); break; }
+    objective.ReportIterationComplete(f);
+    EXPECT(objective.GetNumCompletedIterations() == 1);
+  }
+  // channel ranges (split_channels: irls_map_solver.cpp:200-210): the data term over channel 1 alone
+  {
+    auto d1 = std::make_shared<ObjectiveDataTerm>(model, low_res, 1, 2, size);
+    std::vector<double> g1(static_cast<size_t>(W) * H, 0.0), gall(n, 0.0);
+    const double f1 = d1->Compute(x.data() + static_cast<size_t>(W) * H, g1.data());
+    auto dall = std::make_shared<ObjectiveDataTerm>(model, low_res, 0, C, size);
+    auto d0 = std::make_shared<ObjectiveDataTerm>(model, low_res, 0, 1, size);
+    const double fall = dall->Compute(x.data(), gall.data());
+    const double f0 = d0->Compute(x.data(), nullptr);
+    EXPECT(std::fabs(f0 + f1 - fall) <= 1e-12 * std::fabs(fall));
+    double e = 0;
+    for (size_t i = 0; i < g1.size(); ++i) e = std::fmax(e, std::fabs(g1[i] - gall[static_cast<size_t>(W) * H + i]));
+    EXPECT(e <= 1e-12);
+  }
+}
+
 static void TestPsnr() {
   const double gt[16] = {0.0, 0.1, 0.2, 0.3, 0.7, 0.6, 0.5, 0.4, 0.8, 0.9, 1.0, 0.5, 0.4, 0.6, 0.0, 1.0};
   const ImageData ground_truth(gt, cv::Size(4, 4));
@@ -237,6 +330,7 @@ int main() {
   TestSmallData(10, false);
   TestSmallData(10, true);
   TestRegularizationOrdering();
+  TestObjectiveTerms();
   TestPsnr();
   TestSpectralPca();
   std::printf(g_fail ? "FACADE TESTS FAILED (%d)\n" : "FACADE TESTS PASSED\n", g_fail);
