@@ -32,7 +32,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* smem4) {
 template <typename T>
 __device__ __forceinline__ WarpTaps<T> identity_warp() {
   WarpTaps<T> w;
-  w.ox = 0; w.oy = 0; w.ntaps = 1; w.pad = 0;
+  w.ox = 0; w.oy = 0; w.ntaps = 1; w.fx = 0; w.ytab = nullptr;
   w.w[0] = T(1); w.w[1] = T(0); w.w[2] = T(0); w.w[3] = T(0);
   return w;
 }
@@ -42,8 +42,17 @@ __device__ __forceinline__ WarpTaps<T> identity_warp() {
 template <typename T>
 __device__ __forceinline__ T warp_sample(const T* __restrict__ plane, int W, int H,
                                          const WarpTaps<T>& wt, int rr, int cc) {
-  const int sr = rr + wt.oy, sc = cc + wt.ox;
-  if (wt.ntaps == 1) {
+  int sr = rr + wt.oy;
+  const int sc = cc + wt.ox;
+  T w0 = wt.w[0], w1 = wt.w[1], w2 = wt.w[2], w3 = wt.w[3];
+  if (wt.ytab != nullptr) {
+    // per-row y table (rounding-tie shifts): BilinearTab_f's float32 products for this row's fraction index
+    const int Y = wt.ytab[rr];
+    sr = Y >> 5;
+    const float tx1 = (float)wt.fx * (1.f / 32), tx0 = 1.f - tx1;
+    const float ty1 = (float)(Y & 31) * (1.f / 32), ty0 = 1.f - ty1;
+    w0 = (T)(ty0 * tx0); w1 = (T)(ty0 * tx1); w2 = (T)(ty1 * tx0); w3 = (T)(ty1 * tx1);
+  } else if (wt.ntaps == 1) {
     return (sr >= 0 && sr < H && sc >= 0 && sc < W) ? plane[(size_t)sr * W + sc] : T(0);
   }
   const bool r0 = sr >= 0 && sr < H, r1 = sr + 1 >= 0 && sr + 1 < H;
@@ -52,7 +61,7 @@ __device__ __forceinline__ T warp_sample(const T* __restrict__ plane, int W, int
   const T v1 = (r0 && c1) ? plane[(size_t)sr * W + sc + 1] : T(0);
   const T v2 = (r1 && c0) ? plane[(size_t)(sr + 1) * W + sc] : T(0);
   const T v3 = (r1 && c1) ? plane[(size_t)(sr + 1) * W + sc + 1] : T(0);
-  return ((v0 * wt.w[0] + v1 * wt.w[1]) + v2 * wt.w[2]) + v3 * wt.w[3];
+  return ((v0 * w0 + v1 * w1) + v2 * w2) + v3 * w3;
 }
 
 // ---------------------------------------------------------------------------
@@ -135,8 +144,17 @@ __global__ __launch_bounds__(256) void k_gather_direct(
     const WarpTaps<T> wt = warps ? warps[k0 + kk] : identity_warp<T>();
     const T* rk = resid + ((size_t)kk * g.C + c) * n;
     T tk = T(0);
+    int oy = wt.oy;
+    T wloc[4] = {wt.w[0], wt.w[1], wt.w[2], wt.w[3]};
+    if (wt.ytab != nullptr) {  // per-row y table of the transpose warp (rounding-tie shifts)
+      const int Y = wt.ytab[r];
+      oy = (Y >> 5) - r;
+      const float tx1 = (float)wt.fx * (1.f / 32), tx0 = 1.f - tx1;
+      const float ty1 = (float)(Y & 31) * (1.f / 32), ty0 = 1.f - ty1;
+      wloc[0] = (T)(ty0 * tx0); wloc[1] = (T)(ty0 * tx1); wloc[2] = (T)(ty1 * tx0); wloc[3] = (T)(ty1 * tx1);
+    }
     for (int t = 0; t < wt.ntaps; ++t) {
-      const int pr = r + wt.oy + (t >> 1), pc = col + wt.ox + (t & 1);
+      const int pr = r + oy + (t >> 1), pc = col + wt.ox + (t & 1);
       if (pr < 0 || pr >= g.H || pc < 0 || pc >= g.W) continue;
       T v = T(0);
       for (int a = 0; a < g.b; ++a) {
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(256) void k_gather_direct(
           v += blur_t[a * g.b + e] * rk[(size_t)li * g.w + lj];
         }
       }
-      tk += wt.w[t] * v;
+      tk += wloc[t] * v;
     }
     acc += tk;
   }

@@ -51,18 +51,17 @@ static void warp_tables(int W, int H, double dx, double dy, std::vector<int>* X,
 }
 
 static int make_warp(srmap_ctx* ctx, int W, int H, double dx, double dy,
-                     WarpTaps<double>* out) {
+                     WarpTaps<double>* out, std::vector<int>* ytab) {
   if (!(std::fabs(dx) < 16000.0) || !(std::fabs(dy) < 16000.0))
     return set_error(ctx, SRMAP_EUNSUPPORTED, "motion shift (%g, %g) too large", dx, dy);
   std::vector<int> X, Y;
   warp_tables(W, H, dx, dy, &X, &Y);
   for (int x = 0; x < W; ++x)
-    if (X[x] != X[0] + 32 * x)
+    if (X[x] != X[0] + 32 * x)  // adelta[x] + a constant: cannot happen for a pure translation
       return set_error(ctx, SRMAP_EUNSUPPORTED, "non-uniform warpAffine x table");
+  bool uniform_y = true;
   for (int y = 0; y < H; ++y)
-    if (Y[y] != Y[0] + 32 * y)
-      return set_error(ctx, SRMAP_EUNSUPPORTED,
-                       "non-uniform warpAffine y table (dy=%.17g sits on a 1/32-px rounding tie)", dy);
+    if (Y[y] != Y[0] + 32 * y) uniform_y = false;
   out->ox = X[0] >> 5;
   out->oy = Y[0] >> 5;
   const int fx = X[0] & 31, fy = Y[0] & 31;
@@ -71,7 +70,17 @@ static int make_warp(srmap_ctx* ctx, int W, int H, double dx, double dy,
   const float ty1 = (float)fy * (1.f / 32), ty0 = 1.f - ty1;
   out->w[0] = ty0 * tx0; out->w[1] = ty0 * tx1; out->w[2] = ty1 * tx0; out->w[3] = ty1 * tx1;
   out->ntaps = (fx == 0 && fy == 0) ? 1 : 4;
-  out->pad = 0;
+  out->fx = fx;
+  out->ytab = nullptr;
+  ytab->clear();
+  if (!uniform_y) {
+    // dy within floating-point rounding of a 1/32-px quantisation tie: warpAffine's per-row y coordinate
+    // (cvRound((y + b) * 1024) evaluated in double) lands on either side of the tie depending on the row.  The
+    // kernels then read the source row and fraction of every destination row from a table.
+    ytab->resize(H);
+    for (int y = 0; y < H; ++y) (*ytab)[y] = Y[y] + 0 * 32 * y;  // absolute: source row << 5 | fraction
+    out->ntaps = 4;
+  }
   return SRMAP_OK;
 }
 
@@ -91,7 +100,8 @@ template <typename T>
 static int upload_warps(srmap_problem* p, const std::vector<WarpTaps<double>>& src, void** dst) {
   std::vector<WarpTaps<T>> tmp(src.size());
   for (size_t i = 0; i < src.size(); ++i) {
-    tmp[i].ox = src[i].ox; tmp[i].oy = src[i].oy; tmp[i].ntaps = src[i].ntaps; tmp[i].pad = 0;
+    tmp[i].ox = src[i].ox; tmp[i].oy = src[i].oy; tmp[i].ntaps = src[i].ntaps; tmp[i].fx = src[i].fx;
+    tmp[i].ytab = src[i].ytab;
     for (int t = 0; t < 4; ++t) tmp[i].w[t] = (T)src[i].w[t];
   }
   SRMAP_HIP(p->ctx, hipMalloc(dst, sizeof(WarpTaps<T>) * tmp.size()));
@@ -401,11 +411,24 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
     p->shifts.assign(d->shifts_xy, d->shifts_xy + 2 * (size_t)g.K);
     p->fwd_warps.resize(g.K);
     p->bwd_warps.resize(g.K);
+    auto upload_ytab = [&](const std::vector<int>& t, WarpTaps<double>* wt) -> int {
+      if (t.empty()) return SRMAP_OK;
+      int* d = nullptr;
+      if (hipMalloc((void**)&d, sizeof(int) * t.size()) != hipSuccess ||
+          hipMemcpy(d, t.data(), sizeof(int) * t.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return set_error(ctx, SRMAP_ENOMEM, "hipMalloc failed");
+      p->d_ytabs.push_back(d);
+      wt->ytab = d;
+      return SRMAP_OK;
+    };
+    std::vector<int> ytab;
     for (int k = 0; k < g.K && rc == SRMAP_OK; ++k) {
-      rc = make_warp(ctx, g.W, g.H, p->shifts[2 * k], p->shifts[2 * k + 1], &p->fwd_warps[k]);
+      rc = make_warp(ctx, g.W, g.H, p->shifts[2 * k], p->shifts[2 * k + 1], &p->fwd_warps[k], &ytab);
+      if (rc == SRMAP_OK) rc = upload_ytab(ytab, &p->fwd_warps[k]);
       // the transpose warps an image of size (w*s, h*s)
       if (rc == SRMAP_OK)
-        rc = make_warp(ctx, g.w * g.s, g.h * g.s, -p->shifts[2 * k], -p->shifts[2 * k + 1], &p->bwd_warps[k]);
+        rc = make_warp(ctx, g.w * g.s, g.h * g.s, -p->shifts[2 * k], -p->shifts[2 * k + 1], &p->bwd_warps[k], &ytab);
+      if (rc == SRMAP_OK) rc = upload_ytab(ytab, &p->bwd_warps[k]);
     }
   }
   std::vector<int> cmap, rmap;
@@ -455,6 +478,7 @@ void srmap_problem_destroy(srmap_problem* p) {
                   p->d_obs, p->d_resid, p->d_regvals, p->d_x, p->d_g, p->d_tmp, p->d_partials, p->d_cost};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) (void)hipFree(p->reg[r].weights);
+  for (int* t : p->d_ytabs) (void)hipFree(t);
   delete p;
 }
 

@@ -23,8 +23,12 @@ template <typename T>
 struct WarpTaps {
   int ox, oy;
   int ntaps;  // 1 = integer shift (weights 1,0,0,0), 4 = bilinear
-  int pad;
+  int fx;     // x fraction index 0..31 (1/32 px) -- used with ytab
   T w[4];     // (0,0) (1,0) (0,1) (1,1) as (dx,dy) tap offsets
+  // warpAffine evaluates the y coordinate of every row in floating point before quantising it to 1/32 px; for a dy
+  // within rounding distance of a quantisation tie the fraction index differs from row to row.  Then ytab (device,
+  // one int per destination row: source row << 5 | fraction index) replaces oy and the y half of w.
+  const int* ytab;
 };
 
 struct Geometry {
@@ -73,6 +77,7 @@ struct srmap_problem {
   std::vector<double> blur2d_t;
   std::vector<double> blur1d;     // b (the separable factor: blur2d = blur1d * blur1d^T)
   // device constants
+  std::vector<int*> d_ytabs;      // per-row y tables of frames whose warpAffine y table is not uniform (owned)
   void* d_fwd_warps = nullptr;    // WarpTaps<T>[K]
   void* d_bwd_warps = nullptr;    // WarpTaps<T>[K]
   void* d_blur = nullptr;         // T[b*b]

@@ -469,3 +469,30 @@ def test_channel_map_matches_numpy(sr, ctx):
         ref = np.tensordot(M, x - oi.reshape((-1,) + (1,) * len(shape)), axes=1) + oo.reshape((-1,) + (1,) * len(shape))
         assert relerr(ctx.channel_map(M, x, oi, oo), ref) <= 1e-12
         assert relerr(ctx.channel_map(M, x), np.tensordot(M, x, axes=1)) <= 1e-12
+
+
+def test_rounding_tie_shift_runs_like_the_reference(sr, ctx):
+    """A dy within floating-point rounding of a 1/32-px quantisation tie: cv::warpAffine's per-row y coordinate
+    falls on either side of the tie depending on the row (non-uniform table).  The library evaluates it with a per-row
+    table instead of rejecting the shift."""
+    W, H, s = 48, 64, 2
+    shifts = [[0.25, -0.0151367187499999], [-1.5, 0.0161132812500001], [0.0, 0.0]]
+    X, Y = orc.warp_tables(W, H, 0.0, shifts[0][1])
+    assert not np.all(np.diff(Y) == 32)  # the case really is non-uniform
+    rng = np.random.default_rng(31)
+    model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=3, blur_sigma=1.0)
+    p = sr.Problem(ctx, W, H, 1, 3, s, shifts, 3, 1.0, sr.F64)
+    x = rng.standard_normal((1, H, W))
+    y = rng.standard_normal((1, H // s, W // s))
+    for k in range(3):
+        assert relerr(p.apply(x, k), model.apply(x, k)) <= 1e-12
+        assert relerr(p.apply_transpose(y, k), model.apply_transpose(y, k)) <= 1e-12
+    lr = np.stack([model.apply(x, k) for k in range(3)]) + 0.01 * rng.standard_normal((3, 1, H // s, W // s))
+    p.set_observations(lr)
+    ref = orc.Problem(model, lr)
+    p.add_regularizer(sr.REG_TV, 0.05)
+    ref.add_regularizer(0, 0.05)
+    x2 = rng.random((1, H, W))
+    f_ref, g_ref = ref.objective(x2)
+    f, g = p.eval(x2)
+    assert abs(f - f_ref) <= 1e-12 * max(1.0, abs(f_ref)) and relerr(g, g_ref) <= 4e-12
