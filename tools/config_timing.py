@@ -2,6 +2,7 @@
    python tools/config_timing.py [cfg ...]      e.g. 1 2 3 4 5"""
 import os, sys, time
 import numpy as np, torch
+torch.cuda.init(); torch.zeros(1, device='cuda')  # torch's HIP runtime before libsrmap.so
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd", "python"))
 import srmap
@@ -9,14 +10,19 @@ import srmap
 CFG = {
     1: dict(name="cfg1 4 frames, 2x -> 256^2, TV", W=256, C=1, K=4, s=2, blur=(0, 0.0), regs=[(srmap.REG_TV, 0, 0.0)]),
     2: dict(name="cfg2 16 frames, 4x -> 2048^2, blur + BTV", W=2048, C=1, K=16, s=4, blur=(3, 1.0), regs=[(srmap.REG_BTV, 3, 0.5)]),
-    3: dict(name="cfg3 16 frames RGB, 4x -> 4096^2, BTV", W=4096, C=3, K=16, s=4, blur=(3, 1.0), regs=[(srmap.REG_BTV, 3, 0.5)]),
-    4: dict(name="cfg4 9 frames x 128 ch, 3x -> 1023^2, TV", W=1023, C=128, K=9, s=3, blur=(3, 1.0), regs=[(srmap.REG_TV, 0, 0.0)]),
-    5: dict(name="cfg5 64 frames x 256 ch, 4x -> 2048^2, BTV + 3-D TV", W=2048, C=256, K=64, s=4, blur=(3, 1.0),
+    3: dict(name="cfg3 16 frames RGB, 4x -> 4096^2, BTV", W=4096, C=3, K=16, s=4, blur=(0, 0.0), regs=[(srmap.REG_BTV, 3, 0.5)]),
+    4: dict(name="cfg4 9 frames x 128 ch, 3x -> 1023^2, TV", W=1023, C=128, K=9, s=3, blur=(0, 0.0), regs=[(srmap.REG_TV, 0, 0.0)]),
+    5: dict(name="cfg5 64 frames x 256 ch, 4x -> 2048^2, BTV + 3-D TV", W=2048, C=256, K=64, s=4, blur=(0, 0.0),
             regs=[(srmap.REG_BTV, 3, 0.5), (srmap.REG_TV3D, 0, 0.0)]),
 }
 
 
 def main():
+    blurred = "--blur" in sys.argv  # also time cfg3-5 with the Gaussian blur (3, 1.0) cfg2 states
+    sys.argv = [a for a in sys.argv if a != "--blur"]
+    if blurred:
+        for c in (3, 4, 5):
+            CFG[c]["blur"] = (3, 1.0); CFG[c]["name"] += " + blur"
     which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
     dev = torch.device("cuda", 0)
     ctx = srmap.Context(0)
