@@ -120,6 +120,8 @@ struct ZArgs {
   const T* w;        // IRLS weights or nullptr
   T* g;              // nullptr = cost only
   double* partials;
+  const T* dvec;         // WD instances: search direction d; the kernel also produces partials of g.d
+  double* partials_gd;   //   (same indexing as partials)
   const int* cnt;        // [S][8]  residuals per (row phase, column phase); [pr][S] = max over the column phases
   const long long* off;  // [S][MS][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
   const ZEntry* aux;     // [S][MS][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
@@ -539,7 +541,7 @@ __device__ __forceinline__ T border_residual(const T* __restrict__ blur, int S, 
 }
 
 // One border block of NT threads; smem: scratch of at least 16 int2 + kBorderTabEntries ZEntry + 8 doubles.
-template <typename T, int NT, typename ArgsT>
+template <typename T, int NT, bool WD, typename ArgsT>
 __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>& Bd, int bidx, int ch, void* smem) {
   const int obs_C = Bd.obs_C;
   int2* s_hdr = reinterpret_cast<int2*>(smem);
@@ -552,7 +554,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
   if (tid < Bd.S * Bd.S) s_hdr[tid] = Bd.hdr[tid];
   for (int i = tid; i < Bd.n_ent; i += NT) s_ent[i] = Bd.ent[i];
   __syncthreads();
-  double cost = 0.0;
+  double cost = 0.0, gdc = 0.0;
   if (t < Bd.n_ring) {
     int qr, qc;
     ring_pixel(t, A.W, A.H, A.E, qr, qc);
@@ -597,6 +599,8 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
         }
       }
       corr *= (T)(2 * S * S);
+      // g.d of the corrected gradient: the correction's share, over the rows whose terms this problem counts
+      if (WD && qr >= A.cr0 && qr < A.cr1) gdc = -(double)corr * (double)A.dvec[(size_t)ch * N + (size_t)qr * A.W + qc];
     }
     if (A.g != nullptr) Bd.corr[(size_t)ch * Bd.n_ring + t] = corr;
   }
@@ -614,10 +618,24 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
       const int nbb = A.nby * gridDim.x;
       A.partials[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(Bd.S * Bd.S) * sum;
     }
+    if (WD) {
+      double w2 = gdc;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) w2 += __shfl_down(w2, o, 64);
+      __syncthreads();
+      if (lane == 0) red[wid] = w2;
+      __syncthreads();
+      if (tid == 0) {
+        double sum = 0.0;
+        for (int i = 0; i < NT / 64; ++i) sum += red[i];
+        const int nbb = A.nby * gridDim.x;
+        A.partials_gd[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = sum;
+      }
+    }
   }
 }
 
-template <typename T, int S, int B, int REGK, int R>
+template <typename T, int S, int B, int REGK, int R, bool WD>
 __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_z(
     ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
   using C = ZCfg<T, S, B, REGK, R>;
@@ -638,10 +656,11 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   if ((int)blockIdx.y < A.nby) {  // border blocks come first in dispatch order (uniform branch)
     const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
     const BorderArgs<T>& Bd = *A.bd;
-    if (bidx * C::NT < Bd.n_ring) border_block<T, C::NT>(A, Bd, bidx, blockIdx.z, xs);
+    if (bidx * C::NT < Bd.n_ring) border_block<T, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);
     else if (threadIdx.x == 0) {
       const int nbb = A.nby * gridDim.x;
       A.partials[(size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
+      if (WD) A.partials_gd[(size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
     }
     return;
   }
@@ -787,6 +806,14 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   __syncthreads();
 
   // ---------------- phase 2 ----------------
+  T dreg[S];  // WD: the search direction at this thread's pixels (g.d is produced with g)
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) dreg[pc] = T(0);
+  if (WD && gr < A.H && gc0 < A.W && gr >= A.cr0 && gr < A.cr1) {
+    const T* dp = A.dvec + (size_t)ch * N + (size_t)gr * A.W + gc0;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) dreg[pc] = dp[pc];
+  }
   if (want_data && A.g != nullptr) {
     const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
 #pragma unroll
@@ -811,6 +838,21 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   }
 
   // ---------------- cost partial of this workgroup ----------------
+  if (WD) {
+    double gd = 0.0;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) gd += (double)acc[pc] * (double)dreg[pc];
+    gd = wave_sum_d(gd);
+    if (lane == 0) red[0][wv] = gd;
+    __syncthreads();
+    if (tid == 0) {
+      double d = 0.0;
+#pragma unroll
+      for (int i = 0; i < C::NW; ++i) d += red[0][i];
+      A.partials_gd[((size_t)blockIdx.z * nby_t + by) * gridDim.x + blockIdx.x] = d;
+    }
+    __syncthreads();
+  }
   {
     const double sd = wave_sum_d(cost_data);
     const double sr = wave_sum_d(cost_reg);
@@ -831,11 +873,15 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 template <typename T>
 __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T* __restrict__ corr, int n_ring, int W,
                                                      int H, int E, int C, const double* __restrict__ partials,
-                                                     int n_partials, double* __restrict__ cost_out) {
+                                                     int n_partials, double* __restrict__ cost_out,
+                                                     const double* __restrict__ partials_gd) {
   __shared__ double red[4];
-  double v = 0.0;
+  double v = 0.0, v2 = 0.0;
   if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n_partials; i += 256) v += partials[i];
+    for (int i = threadIdx.x; i < n_partials; i += 256) {
+      v += partials[i];
+      if (partials_gd != nullptr) v2 += partials_gd[i];
+    }
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (g != nullptr && t < n_ring) {
     int qr, qc;
@@ -854,6 +900,14 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
     if (lane == 0) red[wid] = v;
     __syncthreads();
     if (threadIdx.x == 0) cost_out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (partials_gd != nullptr) {  // g.d of the same evaluation (solver line search)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v2 += __shfl_down(v2, o, 64);
+      __syncthreads();
+      if (lane == 0) red[wid] = v2;
+      __syncthreads();
+      if (threadIdx.x == 0) cost_out[1] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
   }
 }
 
@@ -1013,10 +1067,12 @@ size_t ztile_partials_needed(const srmap_problem* p) {
 
 template <typename T, int S, int B, int REGK, int R>
 static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
-                    const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st) {
+                    const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st, const T* dvec,
+                    double* partials_gd) {
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
   A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
+  A.dvec = dvec; A.partials_gd = partials_gd;
   A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
   A.obs_C = p->geo.C;
@@ -1049,7 +1105,8 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     nbb = A.nby * (int)grid.x;
     grid.y += A.nby;
   }
-  hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R>), grid, dim3(C::NT), 0, st, A);
+  if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true>), grid, dim3(C::NT), 0, st, A);
+  else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false>), grid, dim3(C::NT), 0, st, A);
   *nblocks = n_tile_partials + nbb * (int)grid.z;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
@@ -1060,7 +1117,8 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
 template <typename T, int S, int B, int REGK, int R>
 static void preload_z() {
   hipFuncAttributes attr;
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, true>));
 }
 template <typename T, int S, int B>
 static void preload_reg(int regk, int regr) {
@@ -1090,12 +1148,13 @@ void ztile_preload(const srmap_problem* p) {
 
 template <typename T, int S, int B>
 static int dispatch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
-                      const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, hipStream_t st) {
-  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
-  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
-  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
-  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
-  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st);
+                      const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, hipStream_t st,
+                      const T* dv, double* pgd) {
+  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
+  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
+  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
+  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
+  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
 }
 
 template <typename T>
@@ -1117,12 +1176,23 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (regk) zterms |= SRMAP_TERM_REG;
   int rc = SRMAP_OK, nb = 0;
   const int S = geo.s, B = geo.b;
-  if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
-  else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
-  else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
-  else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
-  else if (S == 4 && B == 1) rc = dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
-  else if (S == 4 && B == 3) rc = dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st);
+  // g.d with the gradient (solver line search): only when this launch produces the WHOLE gradient and the single
+  // finish launch reduces it -- no further regulariser kernels, few enough partials
+  bool more_regs = false;
+  if (want_reg)
+    for (int r = 0; r < p->nreg; ++r)
+      if (!(regk && r == z.reg_index) && p->reg[r].lambda > 0.0) more_regs = true;
+  const size_t est_parts = (size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8) * geo.C + (size_t)((z.n_ring + 511) / 512 + (geo.H + 7) / 8) * geo.C;
+  const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= 16384;
+  const T* dv = with_d ? (const T*)p->eval_dvec : nullptr;
+  double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
+  p->gd_valid = false;
+  if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
+  else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
+  else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
+  else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
+  else if (S == 4 && B == 1) rc = dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
+  else if (S == 4 && B == 3) rc = dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
   else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
   if (rc) return rc;
   int total = nb;
@@ -1152,15 +1222,16 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     const int nring = corr_on ? z.n_ring : 0;
     const unsigned nb_f = (unsigned)std::max(1, (nring + 255) / 256);
     hipLaunchKernelGGL(k_finish_eval<T>, dim3(nb_f), dim3(256), 0, st, corr_on ? g : (T*)nullptr, (const T*)z.d_corr,
-                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, total, p->d_cost);
+                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, total, p->d_cost, (const double*)pgd);
     SRMAP_HIP(p->ctx, hipGetLastError());
+    p->gd_valid = with_d;  // d_cost[1] = g.d
     *nblocks = 0;  // total already in d_cost[0]
     return SRMAP_OK;
   }
   // many partials (multi-channel problems): corrections here, two-stage reduction by the caller
   if (corr_on) {
     hipLaunchKernelGGL(k_finish_eval<T>, dim3((unsigned)((z.n_ring + 255) / 256)), dim3(256), 0, st, g, (const T*)z.d_corr,
-                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, 0, p->d_cost + 1);
+                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, 0, p->d_cost + 1, (const double*)nullptr);
     SRMAP_HIP(p->ctx, hipGetLastError());
   }
   *nblocks = total;

@@ -376,10 +376,39 @@ struct DeviceCG {
     for (int i = 0; i < cnt; ++i) out[i] = hs[i];
     return SRMAP_OK;
   }
-  // objective at x: g <- gradient; the cost stays on the device (finish(with_cost) fetches it)
-  int evaluate() {
+  // objective at x: g <- gradient; the cost stays on the device (finish(with_cost) fetches it).  With a direction
+  // the tile kernel may produce g.d in the same pass (p->gd_valid; not under frame sharding, where the local
+  // gradient is only a partial sum).
+  int evaluate(const T* dir = nullptr) {
     evaluations++;
-    return shard_eval(p, comm, shard, SRMAP_TERM_ALL, x, g, st);
+    const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
+    p->eval_dvec = (mode == SRMAP_SHARD_FRAMES || mode == SRMAP_SHARD_CHANNELS) ? nullptr : dir;
+    p->gd_valid = false;
+    const int rc = shard_eval(p, comm, shard, SRMAP_TERM_ALL, x, g, st);
+    p->eval_dvec = nullptr;
+    return rc;
+  }
+  // f and g.d of the evaluation just made, with one wait: out[0] = g.d, out[1] = f
+  int fetch_f_gd(double* out) {
+    if (!p->gd_valid) {
+      hipLaunchKernelGGL(k_dot<T>, dim3(nb()), dim3(256), 0, st, (const T*)g, (const T*)d, n, ow, part);
+      return finish(1, false, true, out);
+    }
+    tag += 1.0;
+    if (!reduce_scalars) {
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, hs, (const double*)p->d_cost, 2, hs + 15, tag);
+    } else {
+      SRMAP_HIP(p->ctx, hipMemcpyAsync(dscal, p->d_cost, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+      int rc = comm_allreduce(comm, dscal, 2, SRMAP_F64, 0, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, hs, (const double*)dscal, 2, hs + 15, tag);
+    }
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    int rc = wait_tag();
+    if (rc) return rc;
+    out[0] = hs[1];
+    out[1] = hs[0];
+    return SRMAP_OK;
   }
   // dn = -g + beta dk (dk may be null), yk = -g; direction norms -> dscal[4..5] (device, all-reduced)
   int direction(const T* dk_or_null, double beta) {
@@ -512,11 +541,10 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
       *stp = b.stx;
     hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
                        (const T*)cg.d, (T)*stp, cg.n);
-    rc = cg.evaluate();
+    rc = cg.evaluate(cg.d);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dot<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.d, cg.n, cg.ow, cg.part);
     double h[2];
-    rc = cg.finish(1, false, true, h);  // h[0] = g.d, h[1] = f
+    rc = cg.fetch_f_gd(h);  // h[0] = g.d, h[1] = f
     if (rc) return rc;
     double dg = h[0];
     *f = h[1];

@@ -214,6 +214,7 @@ static int ensure(srmap_problem* p, void** buf, size_t bytes) {
 }
 
 static int ensure_partials(srmap_problem* p, size_t n) {
+  n *= 2;  // second half: partials of g.d (eval_dvec)
   if (p->partials_cap >= n) return SRMAP_OK;
   if (p->d_partials) (void)hipFree(p->d_partials);
   p->d_partials = nullptr;

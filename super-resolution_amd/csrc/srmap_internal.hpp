@@ -96,7 +96,10 @@ struct srmap_problem {
   void* d_tmp = nullptr;          // [C][H][W] staging (gradient constants, values)
   double* d_partials = nullptr;   // per-block cost partials
   size_t partials_cap = 0;
-  double* d_cost = nullptr;       // [4] reduced scalars
+  double* d_cost = nullptr;       // [8] reduced scalars: [0] cost, [1] g.d when gd_valid
+  const void* eval_dvec = nullptr;  // set by the solver around an evaluation: direction d (device, dtype); the tile
+                                    // kernel then produces g.d with the gradient (one pass and two launches fewer)
+  bool gd_valid = false;            // the last evaluation left g.d in d_cost[1]
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
   void* zplan = nullptr;          // srmap::ZPlan of the z-tile kernels (kernels_ztile.hip), owned; nullptr = not covered
