@@ -27,8 +27,8 @@ int main(int argc, char** argv) {
   parameters.motion_sequence_path = flags.Str("motion_sequence_path");
   parameters.blur_radius = flags.Int("blur_radius", 0);
   parameters.blur_sigma = flags.Double("blur_sigma", 0.0);
-  const double noise_sigma = flags.Double("noise_sigma", 0.0);
-  const int noise_seed = flags.Int("noise_seed", 1);
+  parameters.noise_sigma = flags.Double("noise_sigma", 0.0);  // 0..255 units (additive_noise_module.cpp:25-26)
+  parameters.noise_seed = static_cast<uint64_t>(flags.Int("noise_seed", 1));
   parameters.scale = flags.Int("downsampling_scale", 2);
   const int number_of_frames = flags.Int("number_of_frames", 4);
   flags.RejectUnknown();
@@ -42,15 +42,8 @@ int main(int argc, char** argv) {
   flags.Require("output_image_dir");
   const ImageModel image_model = ImageModel::CreateImageModel(parameters);
   if (!extension.empty() && extension[0] != '.') extension = "." + extension;
-  std::mt19937_64 rng(static_cast<uint64_t>(noise_seed));
-  std::normal_distribution<double> gauss(0.0, noise_sigma > 0 ? noise_sigma : 1.0);
   for (int i = 0; i < number_of_frames; ++i) {
-    ImageData frame = image_model.ApplyToImage(image_data, i);
-    if (noise_sigma > 0)
-      for (int c = 0; c < frame.GetNumChannels(); ++c) {
-        double* px = frame.GetMutableChannelData(c);
-        for (int p = 0; p < frame.GetNumPixels(); ++p) px[p] += gauss(rng);
-      }
+    const ImageData frame = image_model.ApplyToImage(image_data, i);  // incl. the AdditiveNoiseModule, if any
     const std::string path = output_dir + "/low_res_" + std::to_string(i) + extension;
     util::SaveImage(frame, path);
     std::printf("Generated output image %s\n", path.c_str());

@@ -15,6 +15,7 @@
 
 #include "apps/app_flags.h"
 #include "evaluation/peak_signal_to_noise_ratio.h"
+#include "evaluation/structural_similarity.h"
 #include "hyperspectral/spectral_pca.h"
 #include "image/image_io.h"
 #include "image_model/image_model.h"
@@ -32,7 +33,7 @@ int main(int argc, char** argv) {
       "  [--regularizer=tv|3dtv|btv] [--btv_scale_range=3] [--btv_spatial_decay=0.5]\n"
       "  [--regularization_parameter=0.01] [--solver=cg] [--solver_iterations=50]\n"
       "  [--interpolate_color] [--solve_in_pca_space] [--num_pca_components=0] [--pca_retained_variance=0]\n"
-      "  [--evaluators=psnr] [--result_path=<path>] [--verbose]");
+      "  [--evaluators=psnr,ssim] [--result_path=<path>] [--verbose]");
   const std::string data_path = flags.Str("data_path");
   const bool generate_lr_images = flags.Bool("generate_lr_images", false);
   const double noise_sigma = flags.Double("noise_sigma", 0.0);
@@ -71,17 +72,12 @@ int main(int argc, char** argv) {
   std::vector<ImageData> low_res_images;
   if (generate_lr_images) {  // data_path is the ground truth (super_resolution.cpp:285-299)
     high_res_image = util::LoadImage(data_path);
-    std::mt19937_64 rng(static_cast<uint64_t>(noise_seed));
-    std::normal_distribution<double> gauss(0.0, noise_sigma > 0 ? noise_sigma : 1.0);
-    for (int i = 0; i < number_of_frames; ++i) {
-      ImageData frame = image_model.ApplyToImage(high_res_image, i);
-      if (noise_sigma > 0)
-        for (int c = 0; c < frame.GetNumChannels(); ++c) {
-          double* px = frame.GetMutableChannelData(c);
-          for (int p = 0; p < frame.GetNumPixels(); ++p) px[p] += gauss(rng);
-        }
-      low_res_images.push_back(frame);
-    }
+    // the generating model carries the AdditiveNoiseModule (sigma in 0..255 units), the solver's does not
+    ImageModelParameters with_noise = model_parameters;
+    with_noise.noise_sigma = noise_sigma;
+    with_noise.noise_seed = static_cast<uint64_t>(noise_seed);
+    const ImageModel image_model_with_noise = ImageModel::CreateImageModel(with_noise);
+    for (int i = 0; i < number_of_frames; ++i) low_res_images.push_back(image_model_with_noise.ApplyToImage(high_res_image, i));
   } else {
     low_res_images = util::LoadImages(data_path);
     if (!ground_truth_image.empty()) high_res_image = util::LoadImage(ground_truth_image);
@@ -154,6 +150,10 @@ int main(int argc, char** argv) {
         const PeakSignalToNoiseRatioEvaluator psnr_evaluator(high_res_image);
         std::cout << "PSNR score on upsampled: " << psnr_evaluator.Evaluate(upsampled_image) << std::endl;
         std::cout << "PSNR score on result:    " << psnr_evaluator.Evaluate(result) << std::endl;
+      } else if (evaluator == "ssim") {
+        const StructuralSimilarityEvaluator ssim_evaluator(high_res_image);
+        std::cout << "SSIM score on upsampled: " << ssim_evaluator.Evaluate(upsampled_image) << std::endl;
+        std::cout << "SSIM score on result:    " << ssim_evaluator.Evaluate(result) << std::endl;
       } else if (!evaluator.empty()) {
         std::fprintf(stderr, "ERROR: Unknown/unsupported evaluator '%s'.\n", evaluator.c_str());
       }

@@ -6,11 +6,14 @@
 //   DownsamplingModule   src/image_model/downsampling_module.{h,cpp}
 //   ImageModel, ImageModelParameters, CreateImageModel
 //                        src/image_model/image_model.{h,cpp}
-// Dense operator matrices (GetOperatorMatrix / GetModelMatrix) and
-// AdditiveNoiseModule (cv::randn) are test/data-generation helpers outside the
-// gradient path and are not provided.
+//   AdditiveNoiseModule  src/image_model/additive_noise_module.{h,cpp} (data generation: host-side N(0, sigma/255)
+//                        per pixel; cv::randn's global stream cannot be reproduced, the generator is seedable)
+// Dense operator matrices (GetOperatorMatrix / GetModelMatrix) are test helpers of
+// the reference and are not provided.
 #pragma once
+#include <cstdint>
 #include <memory>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -110,6 +113,32 @@ class DownsamplingModule : public DegradationOperator {
   const int scale_;
 };
 
+// additive_noise_module.cpp:19-36: zero-mean Gaussian noise of standard deviation sigma / 255 (the pixels are scaled
+// to [0, 1]) on every channel; the transpose is a no-op (:38-44).  Last operator of a data-generation chain only.
+class AdditiveNoiseModule : public DegradationOperator {
+ public:
+  explicit AdditiveNoiseModule(const double sigma, const uint64_t seed = 0x5eedULL) : sigma_(sigma), rng_(seed) {
+    if (!(sigma > 0.0)) srmap_host::Fail("Check failed: sigma_ > 0.0");
+  }
+  void ApplyToImage(ImageData* image_data, const int /*index*/) const override {
+    if (!image_data) srmap_host::Fail("CHECK_NOTNULL(image_data)");
+    std::normal_distribution<double> gauss(0.0, sigma_ / 255.0);
+    for (int c = 0; c < image_data->GetNumChannels(); ++c) {
+      double* px = image_data->GetMutableChannelData(c);
+      for (int i = 0; i < image_data->GetNumPixels(); ++i) px[i] += gauss(rng_);
+    }
+  }
+  void ApplyTransposeToImage(ImageData* image_data, const int /*index*/) const override {
+    if (!image_data) srmap_host::Fail("CHECK_NOTNULL(image_data)");
+  }
+  void Describe(srmap_host::ChainParams*) const override {}
+  void SetSeed(const uint64_t seed) const { rng_.seed(seed); }
+
+ private:
+  const double sigma_;
+  mutable std::mt19937_64 rng_;
+};
+
 struct ImageModelParameters {
   int scale = 2;
   int blur_radius = 0;
@@ -117,6 +146,7 @@ struct ImageModelParameters {
   std::string motion_sequence_path = "";
   MotionShiftSequence motion_sequence;
   double noise_sigma = 0.0;
+  uint64_t noise_seed = 0x5eedULL;  // not in the reference (cv::randn draws from OpenCV's global generator)
 };
 
 class ImageModel {
@@ -135,8 +165,8 @@ class ImageModel {
     if (parameters.blur_radius > 0 && parameters.blur_sigma > 0.0)
       model.AddDegradationOperator(std::make_shared<BlurModule>(parameters.blur_radius, parameters.blur_sigma));
     model.AddDegradationOperator(std::make_shared<DownsamplingModule>(parameters.scale));
-    if (parameters.noise_sigma > 0.0)
-      srmap_host::Fail("AdditiveNoiseModule (cv::randn) is data generation, outside the gradient path");
+    if (parameters.noise_sigma > 0.0)  // image_model.cpp:53-58
+      model.AddDegradationOperator(std::make_shared<AdditiveNoiseModule>(parameters.noise_sigma, parameters.noise_seed));
     return model;
   }
   void AddDegradationOperator(std::shared_ptr<DegradationOperator> op) { operators_.push_back(op); }
@@ -151,20 +181,32 @@ class ImageModel {
     srmap_host::ChainParams chain;
     // Blur and downsampling ignore the index (blur_module.cpp:25-28, downsampling_module.cpp:19-27): without a
     // MotionModule the fused problem has ONE frame, whatever index the caller passes
-    if (Canonical(&chain)) { srmap_host::RunChain(chain, image_data, chain.shifts_xy.empty() ? 0 : index, false); return; }
+    const AdditiveNoiseModule* noise = nullptr;
+    if (Canonical(&chain, &noise)) {
+      srmap_host::RunChain(chain, image_data, chain.shifts_xy.empty() ? 0 : index, false);
+      if (noise) noise->ApplyToImage(image_data, index);
+      return;
+    }
     for (const auto& op : operators_) op->ApplyToImage(image_data, index);
   }
   // image_model.cpp:93-101: transposes in reverse order.
   void ApplyTransposeToImage(ImageData* image_data, const int index) const {
     srmap_host::ChainParams chain;
-    if (Canonical(&chain)) { srmap_host::RunChain(chain, image_data, chain.shifts_xy.empty() ? 0 : index, true); return; }
+    if (Canonical(&chain)) { srmap_host::RunChain(chain, image_data, chain.shifts_xy.empty() ? 0 : index, true); return; }  // a trailing noise module's transpose is a no-op
     for (int i = static_cast<int>(operators_.size()) - 1; i >= 0; --i) operators_[i]->ApplyTransposeToImage(image_data, index);
   }
   int GetDownsamplingScale() const { return downsampling_scale_; }
-  // The fused chain description (valid when the operator list is canonical).
-  bool Canonical(srmap_host::ChainParams* chain) const {
-    int stage = 0;  // 0: expect motion/blur/down, 1: after motion, 2: after blur, 3: after down
+  // The fused chain description (valid when the operator list is canonical: [Motion][Blur]Downsampling, optionally
+  // followed by an AdditiveNoiseModule, which is returned separately and applied on the host).
+  bool Canonical(srmap_host::ChainParams* chain, const AdditiveNoiseModule** noise = nullptr) const {
+    int stage = 0;  // 0: expect motion/blur/down, 1: after motion, 2: after blur, 3: after down, 5: after noise
     for (const auto& op : operators_) {
+      if (const auto* nm = dynamic_cast<const AdditiveNoiseModule*>(op.get())) {
+        if (stage != 3) return false;
+        stage = 5;
+        if (noise) *noise = nm;
+        continue;
+      }
       const int kind = dynamic_cast<const MotionModule*>(op.get()) ? 1
                        : dynamic_cast<const BlurModule*>(op.get()) ? 2
                        : dynamic_cast<const DownsamplingModule*>(op.get()) ? 3 : 4;
@@ -172,7 +214,7 @@ class ImageModel {
       stage = kind;
       op->Describe(chain);
     }
-    return stage == 3;
+    return stage == 3 || stage == 5;
   }
 
  private:

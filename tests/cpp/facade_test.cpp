@@ -6,7 +6,8 @@
 //   test/test_tv_regularizer.cpp:61-198, test_btv_regularizer.cpp:21-95
 //   test/test_map_solver.cpp:79-199    SmallDataTest (1 / 10 channels / split)
 //   test/test_map_solver.cpp:369-469   RegularizationTest (PSNR ordering)
-//   test/test_evaluation.cpp:12-47     PSNR literal
+//   test/test_evaluation.cpp:12-47     PSNR literal;  :99-163 SSIM literal
+//   src/image_model/additive_noise_module.cpp:19-44  noise statistics, no-op transpose, place in the chain
 //   test/test_spectral_pca.cpp:19-137  SpectralPCA literal + reconstruction bounds
 //   src/optimization/irls_map_solver.cpp:200-262  the objective assembled term by term (ObjectiveFunction,
 //       ObjectiveDataTerm, ObjectiveIRLSRegularizationTerm) equals MapSolver::ComputeAllTerms
@@ -16,6 +17,7 @@
 #include <vector>
 
 #include "evaluation/peak_signal_to_noise_ratio.h"
+#include "evaluation/structural_similarity.h"
 #include "hyperspectral/spectral_pca.h"
 #include "image/image_data.h"
 #include "image_model/image_model.h"
@@ -283,6 +285,59 @@ static double MaxAbsDiff(const ImageData& a, const ImageData& b) {
     for (int i = 0; i < a.GetNumPixels(); ++i) m = std::max(m, std::fabs(a.GetChannelData(c)[i] - b.GetChannelData(c)[i]));
   return m;
 }
+static void TestSsimAndNoise() {
+  // test/test_evaluation.cpp:99-140
+  const double gt[4] = {0.5, 0.25, 0.75, 1.0}, im[4] = {0.55, 0.25, 0.7, 1.0};
+  ImageData ground_truth(gt, cv::Size(2, 2), 1);
+  const StructuralSimilarityEvaluator ssim(ground_truth);
+  ImageData test_image(im, cv::Size(2, 2), 1);
+  const double expected = 0.991784423266513;
+  EXPECT(std::fabs(ssim.Evaluate(test_image) - expected) <= 4e-16 * expected * 4);
+  ImageData gt_multi = ground_truth;
+  gt_multi.AddChannel(gt, cv::Size(2, 2));
+  const StructuralSimilarityEvaluator ssim_multi(gt_multi);
+  test_image.AddChannel(im, cv::Size(2, 2));
+  EXPECT(std::fabs(ssim_multi.Evaluate(test_image) - expected) <= 4e-16 * expected * 4);
+  EXPECT(std::fabs(ssim.Evaluate(ground_truth) - 1.0) <= 1e-15);
+
+  // AdditiveNoiseModule: N(0, sigma / 255) per pixel, reproducible per seed, transpose = no-op, last in the chain
+  const int S = 64;
+  std::vector<double> flat(static_cast<size_t>(S) * S * 2, 0.5);
+  ImageData img(flat.data(), cv::Size(S, S), 2);
+  AdditiveNoiseModule noise(10.0, 42);
+  ImageData a = img, b = img;
+  noise.ApplyToImage(&a, 0);
+  noise.SetSeed(42);
+  noise.ApplyToImage(&b, 3);
+  double sum = 0, sq = 0;
+  bool same = true;
+  for (int c = 0; c < 2; ++c)
+    for (int i = 0; i < S * S; ++i) {
+      const double d = a.GetChannelData(c)[i] - 0.5;
+      sum += d; sq += d * d;
+      if (a.GetChannelData(c)[i] != b.GetChannelData(c)[i]) same = false;
+    }
+  const double n = 2.0 * S * S, mean = sum / n, sd = std::sqrt(sq / n - mean * mean);
+  EXPECT(same);
+  EXPECT(std::fabs(mean) < 4 * (10.0 / 255.0) / std::sqrt(n));
+  EXPECT(std::fabs(sd - 10.0 / 255.0) < 0.05 * 10.0 / 255.0);
+  ImageData t = img;
+  noise.ApplyTransposeToImage(&t, 0);
+  EXPECT(t.GetChannelData(0)[5] == 0.5);
+  ImageModelParameters params;
+  params.scale = 2;
+  params.noise_sigma = 5.0;
+  params.noise_seed = 7;
+  const ImageModel noisy = ImageModel::CreateImageModel(params);
+  params.noise_sigma = 0.0;
+  const ImageModel clean = ImageModel::CreateImageModel(params);
+  const ImageData lr_noisy = noisy.ApplyToImage(img, 2), lr_clean = clean.ApplyToImage(img, 2);
+  EXPECT(lr_noisy.GetImageSize() == cv::Size(S / 2, S / 2));
+  double dev = 0;
+  for (int i = 0; i < lr_clean.GetNumPixels(); ++i) dev = std::fmax(dev, std::fabs(lr_noisy.GetChannelData(0)[i] - lr_clean.GetChannelData(0)[i]));
+  EXPECT(dev > 0.0 && dev < 6 * 5.0 / 255.0);
+}
+
 static void TestSpectralPca() {
   const double ch1[10] = {1.85, 2.05, -0.95, -1.55, -2.55, 2.85, 1.95, 2.75, -2.75, -3.65};
   const double ch2[10] = {2.2175, 2.5425, -1.2075, -1.9575, -3.3825, 3.6425, 2.5925, 3.3175, -3.4825, -4.2825};
@@ -332,6 +387,7 @@ int main() {
   TestRegularizationOrdering();
   TestObjectiveTerms();
   TestPsnr();
+  TestSsimAndNoise();
   TestSpectralPca();
   std::printf(g_fail ? "FACADE TESTS FAILED (%d)\n" : "FACADE TESTS PASSED\n", g_fail);
   return g_fail ? 1 : 0;

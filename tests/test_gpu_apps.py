@@ -194,3 +194,38 @@ def test_generate_without_motion_file(tmp_path):
     ref = prob.apply(gt.astype(np.float32).astype(np.float64), 0)
     for k in range(K):
         assert np.allclose(frames[k], ref, atol=2e-7)
+
+
+def test_noise_module_and_ssim_flag(tmp_path):
+    """--noise_sigma runs the AdditiveNoiseModule at the end of the generating chain (sigma / 255 per pixel, seeded);
+    --evaluators=psnr,ssim prints both metrics (super_resolution.cpp:405-430)."""
+    import __graft_entry__ as ge
+    ge.build_lib()
+    gen, sr = ge.build_apps()
+    C, H, W, s, K = 1, 64, 64, 2, 4
+    gt = _ground_truth(C, H, W)
+    gt_cfg = _write_envi(str(tmp_path / "gt"), gt)
+    motion = tmp_path / "motion.txt"
+    motion.write_text("0 0\n1 1\n0 1\n1 0\n")
+    frames = {}
+    for tag, sigma in (("clean", 0), ("noisy", 8)):
+        d = tmp_path / tag
+        d.mkdir()
+        out = subprocess.run([gen, "--input_image=" + gt_cfg, "--output_image_dir=" + str(d),
+                              "--motion_sequence_path=" + str(motion), "--downsampling_scale=%d" % s,
+                              "--number_of_frames=%d" % K, "--noise_sigma=%g" % sigma, "--noise_seed=3"],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        frames[tag] = np.stack([_read_envi(str(d / ("low_res_%d" % i)), (C, H // s, W // s)) for i in range(K)])
+    diff = frames["noisy"] - frames["clean"]
+    assert abs(diff.std() - 8 / 255) < 0.1 * 8 / 255 and abs(diff.mean()) < 4 * (8 / 255) / np.sqrt(diff.size)
+    out = subprocess.run([sr, "--data_path=" + str(tmp_path / "noisy"), "--ground_truth_image=" + gt_cfg,
+                          "--upsampling_scale=%d" % s, "--blur_radius=0", "--motion_sequence_path=" + str(motion),
+                          "--regularizer=tv", "--regularization_parameter=0.002", "--optimization_iterations=3",
+                          "--solver_iterations=20", "--evaluators=psnr,ssim"],
+                         capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0
+    vals = {l.split(":")[0].strip(): float(l.split(":")[1]) for l in out.stdout.splitlines() if "score on" in l}
+    assert set(vals) == {"PSNR score on upsampled", "PSNR score on result", "SSIM score on upsampled", "SSIM score on result"}
+    assert 0.0 < vals["SSIM score on result"] <= 1.0 and vals["SSIM score on result"] >= vals["SSIM score on upsampled"] - 0.02
