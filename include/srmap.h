@@ -176,6 +176,25 @@ int srmap_channel_map(srmap_ctx* ctx, int rows_out, int rows_in, size_t n,
                       const double* offset_out, const double* in_host,
                       double* out_host);
 
+/* The same on device-resident planar f64 cubes (in_dev [rows_in][n], out_dev [rows_out][n]); M and the offsets
+ * are host arrays.  Enqueued on hip_stream (NULL = the context's stream); returns when the result is complete. */
+int srmap_channel_map_device(srmap_ctx* ctx, int rows_out, int rows_in, size_t n,
+                             const double* M, const double* offset_in,
+                             const double* offset_out, const double* in_dev,
+                             double* out_dev, void* hip_stream);
+/* SpectralPCA training (spectral_pca.cpp:30-88 over cv::PCA): mean, covariance / count and its
+ * eigen-decomposition of `count` spectral samples, on the GPU (row means, centred samples, the covariance as one
+ * DGEMM, rocSOLVER dsyevd).  samples_host is planar [rows][count].  Outputs (host): mean[rows],
+ * eigenvalues[rows] in descending order, basis[rows][rows] with row k = k-th eigenvector, its
+ * largest-magnitude component positive. */
+int srmap_channel_pca(srmap_ctx* ctx, int rows, size_t count, const double* samples_host,
+                      double* mean_out, double* eigenvalues_out, double* basis_out);
+/* The same on a device-resident planar f64 cube in_dev [rows][n]: the samples are the pixels
+ * first + j * stride, j < count. */
+int srmap_channel_pca_device(srmap_ctx* ctx, int rows, size_t n, const double* in_dev,
+                             size_t first, size_t stride, size_t count, double* mean_out,
+                             double* eigenvalues_out, double* basis_out);
+
 /* ------------------------------------------------------------- solver */
 /* IRLSMapSolverOptions (irls_map_solver.h:14-36) + MapSolverOptions
  * (map_solver.h:28-79); srmap_irls_options_default() fills the reference

@@ -346,6 +346,7 @@ void srmap_ctx_destroy(srmap_ctx* ctx) {
     if (ctx->h_event[i]) (void)hipEventDestroy(ctx->h_event[i]);
   }
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+  blas_release(ctx);
   delete ctx;
 }
 

@@ -63,6 +63,7 @@ struct srmap_ctx {
   void* h_stage[2] = {nullptr, nullptr};
   hipEvent_t h_event[2] = {nullptr, nullptr};
   double* h_scal = nullptr;  // [16], host-mapped
+  void* blas = nullptr;      // rocblas_handle of this context (channel_map.hip), created on first use
 };
 
 struct srmap_problem {
@@ -115,6 +116,7 @@ struct srmap_problem {
 namespace srmap {
 
 int set_error(srmap_ctx* ctx, int status, const char* fmt, ...);
+void blas_release(srmap_ctx* ctx);
 
 #define SRMAP_HIP(ctx, call)                                                     \
   do {                                                                           \

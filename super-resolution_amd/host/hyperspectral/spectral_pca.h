@@ -10,12 +10,13 @@
 //     whose cumulative eigenvalue share exceeds it, at least 2 -- cv::PCA's
 //     computeCumulativeEnergy) components are kept;
 //   * GetPCAImage = E (x - mean), ReconstructImage = E^T y + mean, per pixel.
-// OpenCV is absent: the eigen-decomposition is a cyclic Jacobi here, eigenvector
-// signs are fixed by "largest-magnitude component positive", which reproduces the
-// one literal the reference pins (test_spectral_pca.cpp:19-60); beyond that the
-// signs are parity-unpinned (reconstruction and TV/BTV solves are sign-invariant).
-// Training runs on the host (C x C, C <= a few hundred); the per-pixel maps run
-// on the GPU as one dense contraction (srmap_channel_map).
+// OpenCV is absent: training runs on the GPU (srmap_channel_pca: row means, centred
+// samples, covariance as one DGEMM, rocSOLVER dsyevd); eigenvector signs are fixed
+// by "largest-magnitude component positive", which reproduces the one literal the
+// reference pins (test_spectral_pca.cpp:19-60); beyond that the signs are
+// parity-unpinned (reconstruction and TV/BTV solves are sign-invariant).  The
+// per-pixel maps run on the GPU as one dense contraction (srmap_channel_map; on
+// device-resident cubes srmap_channel_map_device).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -104,73 +105,17 @@ class SpectralPCA {
       }
     }
     num_spectral_bands_ = C;
-    mean_.assign(C, 0.0);
+    // cv::PCA(data, noArray(), DATA_AS_ROW): mean, covariance / ns, eigenvectors by descending eigenvalue -- on the
+    // GPU (srmap_channel_pca: row means, centred samples, covariance as one DGEMM, rocSOLVER dsyevd).  The
+    // library wants the samples planar [C][ns]; signs are fixed by "largest-magnitude component positive".
+    std::vector<double> planar(static_cast<size_t>(C) * ns);
     for (int i = 0; i < ns; ++i)
-      for (int c = 0; c < C; ++c) mean_[c] += data[static_cast<size_t>(i) * C + c];
-    for (int c = 0; c < C; ++c) mean_[c] /= ns;
-    std::vector<double> cov(static_cast<size_t>(C) * C, 0.0);
-    for (int i = 0; i < ns; ++i) {
-      const double* row = &data[static_cast<size_t>(i) * C];
-      for (int a = 0; a < C; ++a) {
-        const double da = row[a] - mean_[a];
-        double* cr = &cov[static_cast<size_t>(a) * C];
-        for (int b = a; b < C; ++b) cr[b] += da * (row[b] - mean_[b]);
-      }
-    }
-    for (int a = 0; a < C; ++a)
-      for (int b = a; b < C; ++b) {
-        cov[static_cast<size_t>(a) * C + b] /= ns;
-        cov[static_cast<size_t>(b) * C + a] = cov[static_cast<size_t>(a) * C + b];
-      }
-    // cyclic Jacobi: cov = V diag(w) V^T, V's columns = eigenvectors
-    std::vector<double> V(static_cast<size_t>(C) * C, 0.0);
-    for (int i = 0; i < C; ++i) V[static_cast<size_t>(i) * C + i] = 1.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-      double off = 0.0, diag = 0.0;
-      for (int a = 0; a < C; ++a)
-        for (int b = 0; b < C; ++b) (a == b ? diag : off) += cov[static_cast<size_t>(a) * C + b] * cov[static_cast<size_t>(a) * C + b];
-      if (off <= 1e-30 * (diag + 1e-300)) break;
-      for (int p = 0; p < C - 1; ++p)
-        for (int q = p + 1; q < C; ++q) {
-          const double apq = cov[static_cast<size_t>(p) * C + q];
-          if (apq == 0.0) continue;
-          const double app = cov[static_cast<size_t>(p) * C + p], aqq = cov[static_cast<size_t>(q) * C + q];
-          const double theta = (aqq - app) / (2.0 * apq);
-          const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-          const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-          for (int k = 0; k < C; ++k) {  // rotate columns p, q
-            const double akp = cov[static_cast<size_t>(k) * C + p], akq = cov[static_cast<size_t>(k) * C + q];
-            cov[static_cast<size_t>(k) * C + p] = c * akp - s * akq;
-            cov[static_cast<size_t>(k) * C + q] = s * akp + c * akq;
-          }
-          for (int k = 0; k < C; ++k) {  // rotate rows p, q
-            const double apk = cov[static_cast<size_t>(p) * C + k], aqk = cov[static_cast<size_t>(q) * C + k];
-            cov[static_cast<size_t>(p) * C + k] = c * apk - s * aqk;
-            cov[static_cast<size_t>(q) * C + k] = s * apk + c * aqk;
-          }
-          for (int k = 0; k < C; ++k) {
-            const double vkp = V[static_cast<size_t>(k) * C + p], vkq = V[static_cast<size_t>(k) * C + q];
-            V[static_cast<size_t>(k) * C + p] = c * vkp - s * vkq;
-            V[static_cast<size_t>(k) * C + q] = s * vkp + c * vkq;
-          }
-        }
-    }
-    std::vector<int> order(C);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      return cov[static_cast<size_t>(a) * C + a] > cov[static_cast<size_t>(b) * C + b];
-    });
-    eigenvalues_.resize(C);
+      for (int c = 0; c < C; ++c) planar[static_cast<size_t>(c) * ns + i] = data[static_cast<size_t>(i) * C + c];
+    mean_.assign(C, 0.0);
+    eigenvalues_.assign(C, 0.0);
     basis_.assign(static_cast<size_t>(C) * C, 0.0);
-    for (int k = 0; k < C; ++k) {
-      const int src = order[k];
-      eigenvalues_[k] = cov[static_cast<size_t>(src) * C + src];
-      int big = 0;
-      for (int c = 1; c < C; ++c)
-        if (std::fabs(V[static_cast<size_t>(c) * C + src]) > std::fabs(V[static_cast<size_t>(big) * C + src])) big = c;
-      const double sign = V[static_cast<size_t>(big) * C + src] < 0 ? -1.0 : 1.0;
-      for (int c = 0; c < C; ++c) basis_[static_cast<size_t>(k) * C + c] = sign * V[static_cast<size_t>(c) * C + src];
-    }
+    srmap_host::Check(srmap_channel_pca(srmap_host::Context(), C, static_cast<size_t>(ns), planar.data(), mean_.data(),
+                                        eigenvalues_.data(), basis_.data()), "srmap_channel_pca");
     num_pca_bands_ = C;
   }
 

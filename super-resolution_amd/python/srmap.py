@@ -88,6 +88,9 @@ _SIGNATURES = [
     ("srmap_upload", C.c_int, [C.c_void_p, c_double_p, C.c_void_p, C.c_size_t]),
     ("srmap_download", C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_size_t]),
     ("srmap_channel_map", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    ("srmap_channel_map_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("srmap_channel_pca", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p]),
+    ("srmap_channel_pca_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, c_double_p, c_double_p, c_double_p]),
     ("srmap_synchronize", C.c_int, [C.c_void_p]),
     ("srmap_irls_options_default", None, [C.POINTER(IrlsOptions)]),
     ("srmap_solve", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
@@ -153,6 +156,31 @@ class Context:
         oo = _d(offset_out) if offset_out is not None else (None, None)
         self.check(load().srmap_channel_map(self._h, ro, ri, n, pM, oi[1], oo[1], pa, out.ctypes.data_as(c_double_p)))
         return out
+
+    def channel_map_device(self, M, in_ptr, out_ptr, n, offset_in=None, offset_out=None, stream=None):
+        """The same on device-resident planar f64 cubes (raw device pointers, n pixels per channel)."""
+        Mm, pM = _d(M)
+        ro, ri = Mm.shape
+        oi = _d(offset_in) if offset_in is not None else (None, None)
+        oo = _d(offset_out) if offset_out is not None else (None, None)
+        self.check(load().srmap_channel_map_device(self._h, ro, ri, n, pM, oi[1], oo[1], C.c_void_p(in_ptr),
+                                                   C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
+
+    def pca(self, samples):
+        """PCA of planar samples [rows][count] on the GPU: (mean, eigenvalues descending, basis rows = eigenvectors)."""
+        a, pa = _d(samples)
+        rows, count = a.shape
+        mean, ev, basis = np.empty(rows), np.empty(rows), np.empty((rows, rows))
+        self.check(load().srmap_channel_pca(self._h, rows, count, pa, mean.ctypes.data_as(c_double_p),
+                                            ev.ctypes.data_as(c_double_p), basis.ctypes.data_as(c_double_p)))
+        return mean, ev, basis
+
+    def pca_device(self, in_ptr, rows, n, first, stride, count):
+        mean, ev, basis = np.empty(rows), np.empty(rows), np.empty((rows, rows))
+        self.check(load().srmap_channel_pca_device(self._h, rows, n, C.c_void_p(in_ptr), first, stride, count,
+                                                   mean.ctypes.data_as(c_double_p), ev.ctypes.data_as(c_double_p),
+                                                   basis.ctypes.data_as(c_double_p)))
+        return mean, ev, basis
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -496,3 +496,50 @@ def test_rounding_tie_shift_runs_like_the_reference(sr, ctx):
     f_ref, g_ref = ref.objective(x2)
     f, g = p.eval(x2)
     assert abs(f - f_ref) <= 1e-12 * max(1.0, abs(f_ref)) and relerr(g, g_ref) <= 4e-12
+
+
+def test_device_pca_and_resident_projection(sr, ctx):
+    """SpectralPCA on the device: training (mean, covariance / n as one DGEMM, rocSOLVER
+    eigen-decomposition) against numpy, from host samples and from a device-resident cube with a pixel stride; the
+    projection / back-projection on device-resident cubes without a PCIe round trip."""
+    import torch
+    rng = np.random.default_rng(5)
+    C, n = 24, 5000
+    mix = rng.standard_normal((C, C))
+    cube = mix @ rng.standard_normal((C, n)) * np.linspace(2.0, 0.2, C)[:, None] + rng.standard_normal((C, 1))
+
+    def ref_pca(s):
+        mean = s.mean(axis=1)
+        cov = (s - mean[:, None]) @ (s - mean[:, None]).T / s.shape[1]
+        w, V = np.linalg.eigh(cov)
+        w, V = w[::-1], V[:, ::-1].T
+        for k in range(len(w)):
+            big = np.argmax(np.abs(V[k]))
+            if V[k, big] < 0:
+                V[k] = -V[k]
+        return mean, w, V
+
+    mean, ev, basis = ctx.pca(cube)
+    m_ref, w_ref, V_ref = ref_pca(cube)
+    assert np.max(np.abs(mean - m_ref)) <= 1e-12
+    assert np.max(np.abs(ev - w_ref)) <= 1e-10 * w_ref[0]
+    assert np.max(np.abs(basis - V_ref)) <= 1e-8  # well separated spectrum
+    assert np.max(np.abs(basis @ basis.T - np.eye(C))) <= 1e-12
+    # strided samples of a resident cube
+    d = torch.from_numpy(cube).cuda()
+    first, stride, count = 3, 7, 600
+    mean2, ev2, basis2 = ctx.pca_device(d.data_ptr(), C, n, first, stride, count)
+    m2, w2, V2 = ref_pca(cube[:, first:first + stride * count:stride])
+    assert np.max(np.abs(mean2 - m2)) <= 1e-12 and np.max(np.abs(ev2 - w2)) <= 1e-10 * w2[0]
+    assert np.max(np.abs(basis2 - V2)) <= 1e-8
+    # resident projection onto the leading components and back
+    L = 6
+    out = torch.empty((L, n), dtype=torch.float64, device="cuda")
+    ctx.channel_map_device(basis[:L], d.data_ptr(), out.data_ptr(), n, offset_in=mean)
+    torch.cuda.synchronize()
+    proj_ref = basis[:L] @ (cube - mean[:, None])
+    assert relerr(out.cpu().numpy(), proj_ref) <= 1e-12
+    back = torch.empty((C, n), dtype=torch.float64, device="cuda")
+    ctx.channel_map_device(basis[:L].T, out.data_ptr(), back.data_ptr(), n, offset_out=mean)
+    torch.cuda.synchronize()
+    assert relerr(back.cpu().numpy(), basis[:L].T @ proj_ref + mean[:, None]) <= 1e-12
