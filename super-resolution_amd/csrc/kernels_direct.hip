@@ -133,10 +133,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_gather_direct(
     const T* __restrict__ resid, T* __restrict__ gout, Geometry g,
     const WarpTaps<T>* __restrict__ warps, const T* __restrict__ blur_t, int k0,
-    int nk, T out_scale, int accumulate) {
-  const int hp = blockIdx.x * 256 + threadIdx.x;
+    int nk, T out_scale, int accumulate, int ring) {
+  int hp = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
   const int N = g.W * g.H, n = g.w * g.h;
+  if (ring > 0) {
+    // thread index -> pixel of the border ring of width `ring`: top band, bottom band, then the left / right strips
+    const int band = ring * g.W, mid = g.H - 2 * ring, t = hp;
+    if (t >= 2 * band + 2 * ring * mid) return;
+    int rr, cc;
+    if (t < band) { rr = t / g.W; cc = t % g.W; }
+    else if (t < 2 * band) { rr = g.H - ring + (t - band) / g.W; cc = (t - band) % g.W; }
+    else { const int u = t - 2 * band, m = u % (2 * ring); rr = ring + u / (2 * ring); cc = m < ring ? m : g.W - 2 * ring + m; }
+    hp = rr * g.W + cc;
+  }
   if (hp >= N) return;
   const int r = hp / g.W, col = hp - r * g.W;
   T acc = T(0);
@@ -157,14 +167,18 @@ __global__ __launch_bounds__(256) void k_gather_direct(
       const int pr = r + oy + (t >> 1), pc = col + wt.ox + (t & 1);
       if (pr < 0 || pr >= g.H || pc < 0 || pc >= g.W) continue;
       T v = T(0);
-      for (int a = 0; a < g.b; ++a) {
+      // only the taps that land on the LR grid (every s-th), visited in the same increasing (a, e) order
+      int a0 = (g.hb - pr) % g.s, e0 = (g.hb - pc) % g.s;
+      if (a0 < 0) a0 += g.s;
+      if (e0 < 0) e0 += g.s;
+      for (int a = a0; a < g.b; a += g.s) {
         const int R = pr + a - g.hb;
-        if (R < 0 || R >= g.H || (R % g.s) != 0) continue;
+        if (R < 0 || R >= g.H) continue;
         const int li = R / g.s;
         if (li >= g.h) continue;
-        for (int e = 0; e < g.b; ++e) {
+        for (int e = e0; e < g.b; e += g.s) {
           const int Cc = pc + e - g.hb;
-          if (Cc < 0 || Cc >= g.W || (Cc % g.s) != 0) continue;
+          if (Cc < 0 || Cc >= g.W) continue;
           const int lj = Cc / g.s;
           if (lj >= g.w) continue;
           v += blur_t[a * g.b + e] * rk[(size_t)li * g.w + lj];
@@ -182,11 +196,17 @@ __global__ __launch_bounds__(256) void k_gather_direct(
 template <typename T>
 int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, T* g,
                          int k0, int nk, double out_scale, bool accumulate,
-                         hipStream_t st) {
-  dim3 grid((geo.W * geo.H + 255) / 256, geo.C);
+                         hipStream_t st, int ring) {
+  // ring > 0: only the pixels within `ring` of the image edge (the exact border of the sub-pixel tile path)
+  size_t npix = (size_t)geo.W * geo.H;
+  if (ring > 0) {
+    if (2 * ring >= geo.H || 2 * ring >= geo.W) ring = 0;
+    else npix = 2 * (size_t)ring * geo.W + 2 * (size_t)ring * (geo.H - 2 * ring);
+  }
+  dim3 grid((unsigned)((npix + 255) / 256), geo.C);
   hipLaunchKernelGGL(k_gather_direct<T>, grid, dim3(256), 0, st, resid, g, geo,
                      p->has_motion ? (const WarpTaps<T>*)p->d_bwd_warps : nullptr,
-                     (const T*)p->d_blur_t, k0, nk, (T)out_scale, accumulate ? 1 : 0);
+                     (const T*)p->d_blur_t, k0, nk, (T)out_scale, accumulate ? 1 : 0, ring);
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
 }
@@ -535,7 +555,7 @@ int launch_reduce_partials(srmap_problem* p, const double* partials, int n, doub
                                         const T*, int, int, T*, int, int, double*, int*,   \
                                         hipStream_t);                                       \
   template int launch_gather_direct<T>(srmap_problem*, const Geometry&, const T*, T*, int, \
-                                       int, double, bool, hipStream_t);                     \
+                                       int, double, bool, hipStream_t, int);                \
   template int launch_reg_values<T>(srmap_problem*, const Geometry&, const RegSpec&,       \
                                     const T*, T*, hipStream_t);                             \
   template int launch_reg_gradient_direct<T>(srmap_problem*, const Geometry&,              \

@@ -122,6 +122,9 @@ struct ZArgs {
   double* partials;
   const T* dvec;         // WD instances: search direction d; the kernel also produces partials of g.d
   double* partials_gd;   //   (same indexing as partials)
+  const T* rbuf;         // SP instances (sub-pixel shifts): residuals r_k = A_k x - y_k, [K][C][h][w], from k_forward_direct
+  const double* spw;     //   bilinear tap weight of every table entry, [S][MS][S]
+  int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
   const int* cnt;        // [S][8]  residuals per (row phase, column phase); [pr][S] = max over the column phases
   const long long* off;  // [S][MS][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
   const ZEntry* aux;     // [S][MS][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
@@ -305,6 +308,64 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
           }
         }
       }
+    }
+  }
+  if (B == 1) {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) zout[pc] = z[pc];
+  } else {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      T zh = T(0);
+#pragma unroll
+      for (int e = 0; e < B; ++e) zh += k1_tap<B>(A, e) * z[pc + e];
+      zs[(rowrel + HB) * C::ZROW + pc * C::CW + lane] = zh;
+    }
+  }
+}
+
+// ---- data term, phase 1, SUB-PIXEL shifts ----
+// The transpose warp of a sub-pixel shift is a 4-tap bilinear gather (motion_module.cpp:40-51: warpAffine with the
+// negated shift); in the interior it commutes with B^T like the integer shift does, so
+//     z(p) = sum_k sum_b w'_{k,b} [ (p + o'_k + tap_b) on the LR grid ] r_k((p + o'_k + tap_b) / S),   g_data = 2 S^2 B^T z.
+// The residuals come from k_forward_direct (exact 4-tap forward warp, every clip); which (frame, tap) pairs hit a
+// pixel depends only on its phase: host-built table (frame, LR row / column offset, weight).  No cost here (the
+// forward kernel counts it); the pixels within Dr of the edge are evaluated by the exact ring pass instead.
+template <typename T, int S, int B, typename C, typename ArgsT>
+__device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int rowrel, int R0, int cell0, int lane, int ch,
+                                         T (&zout)[S]) {
+  constexpr int HB = C::HB, NV = C::NV;
+  int rc, pr;
+  row_phase<S>(R0 + rowrel, rc, pr);
+  const size_t nl = (size_t)A.wl * A.hl;
+  int cn[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
+  const int mmax = A.cnt[pr * 8 + S];
+  T z[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) z[v] = T(0);
+  for (int t = 0; t < mmax; ++t) {
+    const size_t slot = (size_t)(pr * A.MS + t) * S;
+    T rv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {  // all loads of this round first
+      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+      rv[v] = T(0);
+      if (t < cn[pc]) {  // uniform
+        const ZEntry e = A.aux[slot + pc];
+        const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
+        if ((unsigned)i < (unsigned)A.hl) {  // uniform
+          const int jc = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
+          const T val = A.rbuf[((size_t)e.k * A.obs_C + ch) * nl + (size_t)i * A.wl + jc];
+          rv[v] = ((unsigned)j < (unsigned)A.wl) ? val : T(0);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int pc = posmod(v - HB, S);
+      if (t < cn[pc]) z[v] += (T)A.spw[slot + pc] * rv[v];
     }
   }
   if (B == 1) {
@@ -635,7 +696,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
   }
 }
 
-template <typename T, int S, int B, int REGK, int R, bool WD>
+template <typename T, int S, int B, int REGK, int R, bool WD, bool SP>
 __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_z(
     ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
   using C = ZCfg<T, S, B, REGK, R>;
@@ -720,8 +781,8 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   T ypre2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) ypre2[v] = T(0);
-  if (want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, CJ0, lane, edge, ybase, ypre);
-  if (has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
+  if (!SP && want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, CJ0, lane, edge, ybase, ypre);
+  if (!SP && has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
   const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
   T wreg[S];
 #pragma unroll
@@ -768,7 +829,12 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   double cost_data = 0.0, cost_reg = 0.0;
 
   // ---------------- phase 1: data term ----------------
-  if (want_data) {
+  if (SP && want_data) {
+    T dummy[S];
+    z_row_sp<T, S, B, C>(A, zs, wv, R0, CJ0, lane, ch, zown);
+    if (has_z_halo) z_row_sp<T, S, B, C>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+  }
+  if (!SP && want_data) {
     T dummy[S];
     double dcost = 0.0;
     if (edge) {
@@ -826,6 +892,8 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 #pragma unroll
         for (int a = 0; a < B; ++a) zz += k1_tap<B>(A, a) * zs[(wv + a) * C::ZROW + pc * C::CW + lane];  // rows wv-HB+a
       }
+      if (SP)  // the ring pass owns the pixels within Dr of the image edge
+        zz = ((unsigned)(gr - A.Dr) < (unsigned)(A.H - 2 * A.Dr) && (unsigned)(gc0 + pc - A.Dr) < (unsigned)(A.W - 2 * A.Dr)) ? zz : T(0);
       acc[pc] += sc * zz;
     }
   }
@@ -918,6 +986,9 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
 struct ZPlan {
   int S = 0, B = 1;
   int regk = 0, regr = 0, reg_index = -1;
+  bool subpix = false;  // sub-pixel shifts: residuals from k_forward_direct, z by 4-tap tables, exact ring by k_gather_direct
+  int Dr = 0;           //   ring width
+  double* d_spw = nullptr;
   int E = 0;   // max |shift|
   int MS = 1;  // table slots per (row phase, column phase)
   int n_ent = 0;
@@ -939,6 +1010,7 @@ void ztile_release(srmap_problem* p) {
   if (z->d_cnt) (void)hipFree(z->d_cnt);
   if (z->d_off) (void)hipFree(z->d_off);
   if (z->d_aux) (void)hipFree(z->d_aux);
+  if (z->d_spw) (void)hipFree(z->d_spw);
   if (z->d_corr) (void)hipFree(z->d_corr);
   if (z->d_bd) (void)hipFree(z->d_bd);
   delete z;
@@ -961,20 +1033,81 @@ bool ztile_plan(srmap_problem* p) {
   }
   std::vector<int> ox(K, 0), oy(K, 0);
   int amax = 0;
+  bool subpix = false;
   if (p->has_motion) {
     for (int k = 0; k < K; ++k) {
       const WarpTaps<double>& f = p->fwd_warps[k];
       const WarpTaps<double>& b = p->bwd_warps[k];
-      if (f.ntaps != 1 || b.ntaps != 1) return false;          // integer shifts only
-      if (b.ox != -f.ox || b.oy != -f.oy) return false;
+      if (f.ytab != nullptr || b.ytab != nullptr) return false;  // rounding-tie shifts: per-row tables, direct kernels
+      if (f.ntaps != 1 || b.ntaps != 1) subpix = true;
+      else if (b.ox != -f.ox || b.oy != -f.oy) return false;
       ox[k] = f.ox; oy[k] = f.oy;
       amax = std::max(amax, std::max(std::abs(f.ox), std::abs(f.oy)));
+      amax = std::max(amax, std::max(std::abs(b.ox), std::abs(b.oy)));
     }
   }
   if (amax > 4096) return false;
   ZPlan* z = new ZPlan();
   z->S = S; z->B = B;
   z->E = amax;
+  if (subpix) {
+    // ---- sub-pixel plan: z(p) = sum over (frame, bilinear tap of the TRANSPOSE warp) pairs that land on the LR grid ----
+    z->subpix = true;
+    z->E = 0;  // no border blocks: the forward kernel counts the cost, the ring pass evaluates the border exactly
+    z->Dr = amax + 2 + g.hb;
+    if (g.W <= 4 * z->Dr + 2 * S || g.H <= 4 * z->Dr + 2 * S) { delete z; return false; }
+    for (int r = 0; r < p->nreg && z->regk == 0; ++r) {
+      const RegSpec& rs = p->reg[r];
+      if (rs.lambda <= 0) continue;
+      if (rs.kind == SRMAP_REG_TV) { z->regk = 1; z->reg_index = r; }
+      else if (rs.kind == SRMAP_REG_BTV && rs.range >= 1 && rs.range <= 3) { z->regk = 2; z->regr = rs.range; z->reg_index = r; }
+      break;
+    }
+    struct SpE { ZEntry e; double w; };
+    std::vector<std::vector<SpE>> lists((size_t)S * S);
+    for (int pr = 0; pr < S; ++pr)
+      for (int pc = 0; pc < S; ++pc)
+        for (int k = 0; k < K; ++k) {
+          const WarpTaps<double>& b = p->bwd_warps[k];
+          for (int t = 0; t < b.ntaps; ++t) {  // t & 1 = dx tap, t >> 1 = dy tap (motion_module.cpp:40-51, gather form)
+            if (b.w[t] == 0.0) continue;
+            const int rr = pr + b.oy + (t >> 1), cc = pc + b.ox + (t & 1);
+            if (pmod(rr, S) != 0 || pmod(cc, S) != 0) continue;
+            SpE q; q.e.k = k; q.e.io = fdiv(rr, S); q.e.jo = fdiv(cc, S); q.e.oyx = 0; q.w = b.w[t];
+            lists[(size_t)pr * S + pc].push_back(q);
+          }
+        }
+    int MS = 1;
+    for (const auto& l : lists) MS = std::max(MS, (int)l.size());
+    z->MS = MS;
+    std::vector<int> cnt((size_t)S * 8, 0);
+    std::vector<ZEntry> aux((size_t)S * MS * S, ZEntry{0, 0, 0, 0});
+    std::vector<double> spw((size_t)S * MS * S, 0.0);
+    for (int pr = 0; pr < S; ++pr) {
+      int mx = 0;
+      for (int pc = 0; pc < S; ++pc) {
+        const auto& l = lists[(size_t)pr * S + pc];
+        cnt[(size_t)pr * 8 + pc] = (int)l.size();
+        mx = std::max(mx, (int)l.size());
+        for (size_t t = 0; t < l.size(); ++t) {
+          const size_t slot = ((size_t)pr * MS + t) * S + pc;
+          aux[slot] = l[t].e;
+          spw[slot] = l[t].w;
+        }
+      }
+      cnt[(size_t)pr * 8 + S] = mx;
+    }
+    bool ok = hipMalloc((void**)&z->d_cnt, sizeof(int) * cnt.size()) == hipSuccess &&
+              hipMemcpy(z->d_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void**)&z->d_aux, sizeof(ZEntry) * aux.size()) == hipSuccess &&
+              hipMemcpy(z->d_aux, aux.data(), sizeof(ZEntry) * aux.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void**)&z->d_spw, sizeof(double) * spw.size()) == hipSuccess &&
+              hipMemcpy(z->d_spw, spw.data(), sizeof(double) * spw.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void**)&z->d_off, 64) == hipSuccess;
+    p->zplan = z;
+    if (!ok) { ztile_release(p); return false; }
+    return true;
+  }
   // the border frame (k_border, width 2E) must stay a small part of the image
   if (g.W <= 4 * z->E + 2 * S || g.H <= 4 * z->E + 2 * S) { delete z; return false; }
   // the one regulariser handled in-kernel (first TV / BTV with lambda > 0)
@@ -1105,8 +1238,13 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     nbb = A.nby * (int)grid.x;
     grid.y += A.nby;
   }
-  if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true>), grid, dim3(C::NT), 0, st, A);
-  else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false>), grid, dim3(C::NT), 0, st, A);
+  A.rbuf = nullptr; A.spw = z.d_spw; A.Dr = z.Dr;
+  if (z.subpix && (terms & SRMAP_TERM_DATA)) {
+    A.rbuf = (const T*)p->d_resid;
+    A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
+    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), 0, st, A);
+  } else if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), 0, st, A);
+  else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
   *nblocks = n_tile_partials + nbb * (int)grid.z;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
@@ -1117,8 +1255,9 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
 template <typename T, int S, int B, int REGK, int R>
 static void preload_z() {
   hipFuncAttributes attr;
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false>));
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, true>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, true, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false, true>));
 }
 template <typename T, int S, int B>
 static void preload_reg(int regk, int regr) {
@@ -1183,7 +1322,17 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     for (int r = 0; r < p->nreg; ++r)
       if (!(regk && r == z.reg_index) && p->reg[r].lambda > 0.0) more_regs = true;
   const size_t est_parts = (size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8) * geo.C + (size_t)((z.n_ring + 511) / 512 + (geo.H + 7) / 8) * geo.C;
-  const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= 16384;
+  const bool sp_data = z.subpix && (terms & SRMAP_TERM_DATA);
+  const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= 16384 && !z.subpix;
+  int nfwd = 0;
+  if (sp_data) {
+    // sub-pixel shifts: exact residuals (and the data cost) from the direct forward kernel, then the tile kernel
+    // gathers them with the 4-tap tables; the pixels within Dr of the edge are redone exactly afterwards
+    if (!p->d_resid) SRMAP_HIP(p->ctx, hipMalloc(&p->d_resid, p->lr_count() * sizeof(T)));
+    rc = launch_forward_direct<T>(p, geo, x, (const T*)p->d_obs, p->geo.C, obs_c0, (T*)p->d_resid, 0, geo.K, partials, &nfwd, st);
+    if (rc) return rc;
+    partials += nfwd;
+  }
   const T* dv = with_d ? (const T*)p->eval_dvec : nullptr;
   double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
   p->gd_valid = false;
@@ -1195,6 +1344,14 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   else if (S == 4 && B == 3) rc = dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
   else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
   if (rc) return rc;
+  if (sp_data) {
+    partials -= nfwd;
+    nb += nfwd;
+    if (g != nullptr) {
+      rc = launch_gather_direct<T>(p, geo, (const T*)p->d_resid, g, 0, geo.K, 2.0 * geo.s * geo.s, true, st, z.Dr);
+      if (rc) return rc;
+    }
+  }
   int total = nb;
   // remaining regularisers (3-D TV, a second regulariser, BTV range > 3): direct kernels, accumulating into g
   if (want_reg) {

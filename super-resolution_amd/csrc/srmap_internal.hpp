@@ -139,7 +139,7 @@ int launch_forward_direct(srmap_problem* p, const Geometry& g, const T* x, const
 template <typename T>
 int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, T* g,
                          int k0, int nk, double out_scale, bool accumulate,
-                         hipStream_t st);
+                         hipStream_t st, int ring = 0);
 template <typename T>
 int launch_reg_values(srmap_problem* p, const Geometry& geo, const RegSpec& rs,
                       const T* x, T* values, hipStream_t st);

@@ -215,6 +215,52 @@ def test_objective_matches_oracle(sr, ctx, case, regs, dtype):
     assert abs((fd + fr) - f) <= 1e-9 * max(1.0, abs(f))
 
 
+SUBPIX_CASES = [
+    # W, H, C, s, shifts, blur, sigma -- large enough for the tile kernel's sub-pixel form (interior + exact ring)
+    (96, 80, 1, 4, [[0.5, 0.25], [-1.3, 2.71], [0.01, -0.99], [3.0, -2.5], [2.0, 1.0], [-0.03125, 0.96875]], 3, 1.0),
+    (90, 72, 2, 3, [[0.75, -0.5], [1, 1], [-2.25, 0.125]], 0, 0.0),
+    (70, 66, 1, 2, [[0.5, 0.5], [-0.5, 1.5], [1.25, -1.75], [0, 0]], 3, 0.7),
+    (84, 64, 1, 4, [[0.4, -0.6], [1.9, 0.2]], 3, 1.2),
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", range(len(SUBPIX_CASES)))
+@pytest.mark.parametrize("regs", [[], [(0, 0.05, 0, 0.0)], [(2, 0.01, 3, 0.5)], [(2, 0.02, 2, 0.6), (1, 0.03, 0, 0.0)]])
+def test_subpixel_tile_path_matches_oracle(sr, ctx, case, regs, dtype):
+    """Sub-pixel shifts through the tile kernel (forward residuals -> 4-tap phase tables -> exact border ring,
+    DESIGN.md 3.6) against the oracle AND against the direct kernels; IMPL_TILED must accept the geometry."""
+    W, H, C, s, shifts, b, sigma = SUBPIX_CASES[case]
+    rng = np.random.default_rng(4000 + case)
+    exact_geo = W % s == 0 and H % s == 0  # the oracle's solver geometry needs HR = LR * scale; otherwise tile vs direct
+    model, p, ref, lr = make_pair(sr, ctx, rng, W, H, C, s, shifts, b, sigma, dtype, with_obs=exact_geo)
+    if not exact_geo:
+        p.set_observations(rng.random((len(shifts), C, H // s, W // s)))
+    for kind, lam, rg, dc in regs:
+        i = p.add_regularizer(kind, lam, rg, dc)
+        wts = 0.5 + 2 * rng.random((C, H, W))
+        p.set_irls_weights(i, wts)
+        if ref is not None:
+            ref.add_regularizer(kind, lam, rg, dc)
+            ref.set_irls_weights(i, wts)
+    x = rng.random((C, H, W))
+    tol = TOL[dtype]
+    p.set_impl(sr.IMPL_TILED)  # fails with EUNSUPPORTED if the tile plan rejected the sub-pixel geometry
+    f, g = p.eval(x)
+    if ref is not None:
+        f_ref, g_ref = ref.objective(x)
+        assert abs(f - f_ref) / max(1.0, abs(f_ref)) <= (tol if dtype == 0 else 1e-5)
+        assert relerr(g, g_ref) <= 4 * tol
+    fd, gd = p.eval(x, sr.TERM_DATA)
+    f1, _ = p.eval(x, sr.TERM_ALL, want_grad=False)
+    assert f1 == f
+    p.set_impl(sr.IMPL_DIRECT)
+    f2, g2 = p.eval(x)
+    fd2, gd2 = p.eval(x, sr.TERM_DATA)
+    assert abs(f - f2) <= (1e-12 if dtype == 0 else 1e-5) * max(1.0, abs(f2))
+    assert relerr(g, g2) <= 4 * tol and relerr(gd, gd2) <= 4 * tol and fd == fd2
+
+
 def test_lambda_zero_term_is_skipped(sr, ctx):
     rng = np.random.default_rng(5)
     model, p, ref, lr = make_pair(sr, ctx, rng, 16, 16, 1, 2, [[0, 0], [1, 0]], 0, 0.0, 0)
