@@ -76,23 +76,47 @@ __global__ __launch_bounds__(256) void k_forward_direct(
     const int* __restrict__ col_map, const int* __restrict__ row_map, int k0,
     double cost_scale, int obs_C, int obs_c0) {
   __shared__ double red[4];
+  __shared__ T comb[36];  // blur (x) bilinear taps of this block's frame, (b+1) x (b+1), b <= 5
   const int lp = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y, kk = blockIdx.z, k = k0 + kk;
   const int n = g.w * g.h;
+  const WarpTaps<T> wt = warps ? warps[k] : identity_warp<T>();
+  // interior fast path for bilinear warps: one (b+1)^2 stencil on x instead of b^2 four-tap samples
+  const bool use_comb = wt.ntaps == 4 && wt.ytab == nullptr && g.b <= 5;
+  const int nb1 = g.b + 1;
+  if (use_comb) {
+    if ((int)threadIdx.x < nb1 * nb1) {
+      const int a1 = threadIdx.x / nb1, e1 = threadIdx.x - a1 * nb1;
+      T s = T(0);
+      for (int t = 0; t < 4; ++t) {
+        const int a = a1 - (t >> 1), e = e1 - (t & 1);
+        if (a >= 0 && a < g.b && e >= 0 && e < g.b) s += blur[a * g.b + e] * wt.w[t];
+      }
+      comb[threadIdx.x] = s;
+    }
+    __syncthreads();
+  }
   double sq = 0.0;
   if (lp < n) {
     const int i = lp / g.w, j = lp - i * g.w;
     const int R0 = row_map[i], C0 = col_map[j];
     const T* plane = x + (size_t)c * g.W * g.H;
-    const WarpTaps<T> wt = warps ? warps[k] : identity_warp<T>();
     T acc = T(0);
-    for (int a = 0; a < g.b; ++a) {
-      const int rr = R0 + a - g.hb;
-      if (rr < 0 || rr >= g.H) continue;  // filter2D BORDER_CONSTANT on the warped image
-      for (int e = 0; e < g.b; ++e) {
-        const int cc = C0 + e - g.hb;
-        if (cc < 0 || cc >= g.W) continue;
-        acc += blur[a * g.b + e] * warp_sample(plane, g.W, g.H, wt, rr, cc);
+    const int sr0 = R0 - g.hb + wt.oy, sc0 = C0 - g.hb + wt.ox;
+    if (use_comb && R0 - g.hb >= 0 && R0 + g.hb < g.H && C0 - g.hb >= 0 && C0 + g.hb < g.W && sr0 >= 0 &&
+        sr0 + g.b < g.H && sc0 >= 0 && sc0 + g.b < g.W) {
+      const T* src = plane + (size_t)sr0 * g.W + sc0;
+      for (int a1 = 0; a1 < nb1; ++a1)
+        for (int e1 = 0; e1 < nb1; ++e1) acc += comb[a1 * nb1 + e1] * src[(size_t)a1 * g.W + e1];
+    } else {
+      for (int a = 0; a < g.b; ++a) {
+        const int rr = R0 + a - g.hb;
+        if (rr < 0 || rr >= g.H) continue;  // filter2D BORDER_CONSTANT on the warped image
+        for (int e = 0; e < g.b; ++e) {
+          const int cc = C0 + e - g.hb;
+          if (cc < 0 || cc >= g.W) continue;
+          acc += blur[a * g.b + e] * warp_sample(plane, g.W, g.H, wt, rr, cc);
+        }
       }
     }
     T res = acc;
@@ -134,23 +158,29 @@ __global__ __launch_bounds__(256) void k_gather_direct(
     const T* __restrict__ resid, T* __restrict__ gout, Geometry g,
     const WarpTaps<T>* __restrict__ warps, const T* __restrict__ blur_t, int k0,
     int nk, T out_scale, int accumulate, int ring) {
-  int hp = blockIdx.x * 256 + threadIdx.x;
+  // ring mode: 64 pixels per block, the frames split over 4 thread groups (short dependent-load chains), combined
+  // through LDS in fixed order; full mode: one pixel per thread, all frames
+  __shared__ T part[256];
+  int hp = ring > 0 ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * 256 + threadIdx.x;
+  const int fg = ring > 0 ? (int)(threadIdx.x >> 6) : 0, nfg = ring > 0 ? 4 : 1;
   const int c = blockIdx.y;
   const int N = g.W * g.H, n = g.w * g.h;
+  bool live = true;
   if (ring > 0) {
     // thread index -> pixel of the border ring of width `ring`: top band, bottom band, then the left / right strips
     const int band = ring * g.W, mid = g.H - 2 * ring, t = hp;
-    if (t >= 2 * band + 2 * ring * mid) return;
-    int rr, cc;
+    live = t < 2 * band + 2 * ring * mid;
+    int rr = 0, cc = 0;
     if (t < band) { rr = t / g.W; cc = t % g.W; }
     else if (t < 2 * band) { rr = g.H - ring + (t - band) / g.W; cc = (t - band) % g.W; }
-    else { const int u = t - 2 * band, m = u % (2 * ring); rr = ring + u / (2 * ring); cc = m < ring ? m : g.W - 2 * ring + m; }
+    else if (live) { const int u = t - 2 * band, m = u % (2 * ring); rr = ring + u / (2 * ring); cc = m < ring ? m : g.W - 2 * ring + m; }
     hp = rr * g.W + cc;
+  } else if (hp >= N) {
+    return;
   }
-  if (hp >= N) return;
   const int r = hp / g.W, col = hp - r * g.W;
   T acc = T(0);
-  for (int kk = 0; kk < nk; ++kk) {
+  for (int kk = fg; kk < nk && live; kk += nfg) {
     const WarpTaps<T> wt = warps ? warps[k0 + kk] : identity_warp<T>();
     const T* rk = resid + ((size_t)kk * g.C + c) * n;
     T tk = T(0);
@@ -188,6 +218,12 @@ __global__ __launch_bounds__(256) void k_gather_direct(
     }
     acc += tk;
   }
+  if (ring > 0) {
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (fg != 0 || !live) return;
+    acc = ((part[threadIdx.x] + part[threadIdx.x + 64]) + part[threadIdx.x + 128]) + part[threadIdx.x + 192];
+  }
   const size_t o = (size_t)c * N + hp;
   const T base = accumulate ? gout[o] : T(0);
   gout[o] = base + out_scale * acc;
@@ -203,7 +239,7 @@ int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, 
     if (2 * ring >= geo.H || 2 * ring >= geo.W) ring = 0;
     else npix = 2 * (size_t)ring * geo.W + 2 * (size_t)ring * (geo.H - 2 * ring);
   }
-  dim3 grid((unsigned)((npix + 255) / 256), geo.C);
+  dim3 grid((unsigned)(ring > 0 ? (npix + 63) / 64 : (npix + 255) / 256), geo.C);
   hipLaunchKernelGGL(k_gather_direct<T>, grid, dim3(256), 0, st, resid, g, geo,
                      p->has_motion ? (const WarpTaps<T>*)p->d_bwd_warps : nullptr,
                      (const T*)p->d_blur_t, k0, nk, (T)out_scale, accumulate ? 1 : 0, ring);

@@ -331,13 +331,40 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
 // The residuals come from k_forward_direct (exact 4-tap forward warp, every clip); which (frame, tap) pairs hit a
 // pixel depends only on its phase: host-built table (frame, LR row / column offset, weight).  No cost here (the
 // forward kernel counts it); the pixels within Dr of the edge are evaluated by the exact ring pass instead.
-template <typename T, int S, int B, typename C, typename ArgsT>
+// EDGE = false: tiles whose table rows all stay inside the LR image -- no uniform branches, one table row per round
+// (padding entries carry weight 0 and a harmless in-range offset).  Columns: the address is clamped and the WEIGHT
+// masked per lane (nothing is done to the loaded value before the multiply-add, so a round's loads stay in flight
+// together).
+template <typename T, int S, typename C, bool EDGE, typename ArgsT>
+__device__ __forceinline__ void sp_load_round(const ArgsT& A, int pr, int rc, int t, int cell0, int lane, int ch,
+                                              const int (&cn)[S], T (&rv)[C::NV], T (&wm)[C::NV]) {
+  constexpr int HB = C::HB, NV = C::NV;
+  const size_t nl = (size_t)A.wl * A.hl;
+  const int slot = (pr * A.MS + t) * S;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+    rv[v] = T(0);
+    wm[v] = T(0);
+    if (!EDGE || t < cn[pc]) {  // uniform
+      const ZEntry e = A.aux[slot + pc];
+      const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
+      if (!EDGE || (unsigned)i < (unsigned)A.hl) {  // uniform
+        const int jc = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
+        const T* plane = A.rbuf + (size_t)(e.k * A.obs_C + ch) * nl;
+        rv[v] = plane[i * A.wl + jc];
+        wm[v] = ((unsigned)j < (unsigned)A.wl) ? (T)A.spw[slot + pc] : T(0);
+      }
+    }
+  }
+}
+
+template <typename T, int S, int B, typename C, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int rowrel, int R0, int cell0, int lane, int ch,
                                          T (&zout)[S]) {
   constexpr int HB = C::HB, NV = C::NV;
   int rc, pr;
   row_phase<S>(R0 + rowrel, rc, pr);
-  const size_t nl = (size_t)A.wl * A.hl;
   int cn[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
@@ -346,27 +373,10 @@ __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int
 #pragma unroll
   for (int v = 0; v < NV; ++v) z[v] = T(0);
   for (int t = 0; t < mmax; ++t) {
-    const size_t slot = (size_t)(pr * A.MS + t) * S;
-    T rv[NV];
+    T rv[NV], wm[NV];
+    sp_load_round<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ch, cn, rv, wm);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {  // all loads of this round first
-      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-      rv[v] = T(0);
-      if (t < cn[pc]) {  // uniform
-        const ZEntry e = A.aux[slot + pc];
-        const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
-        if ((unsigned)i < (unsigned)A.hl) {  // uniform
-          const int jc = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
-          const T val = A.rbuf[((size_t)e.k * A.obs_C + ch) * nl + (size_t)i * A.wl + jc];
-          rv[v] = ((unsigned)j < (unsigned)A.wl) ? val : T(0);
-        }
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int pc = posmod(v - HB, S);
-      if (t < cn[pc]) z[v] += (T)A.spw[slot + pc] * rv[v];
-    }
+    for (int v = 0; v < NV; ++v) z[v] += wm[v] * rv[v];
   }
   if (B == 1) {
 #pragma unroll
@@ -747,7 +757,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // ---------------- global loads whose addresses are known now: x tile, observations, IRLS weights ----------------
   constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // x rows per wave
   constexpr int EXTRA = C::XC - C::CW;              // halo cells, staged by the first lanes
-  T va[ARI][S], vb[ARI][S];
+  T va[ARI][S], vb[ARI][S], ma[ARI], mb[ARI];
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
     const int row = wv + it * C::NW;
@@ -762,11 +772,10 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      va[it][pc] = ina ? Pre<T>::up(va[it][pc]) : T(0);
-      vb[it][pc] = inb ? Pre<T>::up(vb[it][pc]) : T(0);
-    }
+    // scale 2^Q inside the image, 0 outside: applied as ONE multiply when the tile goes to LDS -- a select on the
+    // loaded value makes the compiler wait for this row group before it requests the next one
+    ma[it] = ina ? Pre<T>::up(T(1)) : T(0);
+    mb[it] = inb ? Pre<T>::up(T(1)) : T(0);
   }
   T ypre[NV];
 #pragma unroll
@@ -809,10 +818,10 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     const int row = wv + it * C::NW;
     if (row < C::XR) {  // uniform
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + lane] = va[it][pc];
+      for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + lane] = va[it][pc] * ma[it];
       if (lane < EXTRA) {
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + lane] = vb[it][pc];
+        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + lane] = vb[it][pc] * mb[it];
       }
     }
   }
@@ -831,8 +840,15 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // ---------------- phase 1: data term ----------------
   if (SP && want_data) {
     T dummy[S];
-    z_row_sp<T, S, B, C>(A, zs, wv, R0, CJ0, lane, ch, zown);
-    if (has_z_halo) z_row_sp<T, S, B, C>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+    // table rows reach (Dr + S) / S LR rows around the tile's own: only the top / bottom tile rows can leave the image
+    const bool row_edge = (R0 - A.Dr - 2 * S < 0) || (R0 + C::TH + A.Dr + 2 * S > A.H);
+    if (row_edge) {
+      z_row_sp<T, S, B, C, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) z_row_sp<T, S, B, C, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+    } else {
+      z_row_sp<T, S, B, C, false>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) z_row_sp<T, S, B, C, false>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+    }
   }
   if (!SP && want_data) {
     T dummy[S];
@@ -989,6 +1005,7 @@ struct ZPlan {
   bool subpix = false;  // sub-pixel shifts: residuals from k_forward_direct, z by 4-tap tables, exact ring by k_gather_direct
   int Dr = 0;           //   ring width
   double* d_spw = nullptr;
+  SpForwardPlan spf;    //   forward tile kernel (kernels_spfwd.hip); the direct forward kernel when it does not apply
   int E = 0;   // max |shift|
   int MS = 1;  // table slots per (row phase, column phase)
   int n_ent = 0;
@@ -1011,6 +1028,7 @@ void ztile_release(srmap_problem* p) {
   if (z->d_off) (void)hipFree(z->d_off);
   if (z->d_aux) (void)hipFree(z->d_aux);
   if (z->d_spw) (void)hipFree(z->d_spw);
+  spfwd_release(&z->spf);
   if (z->d_corr) (void)hipFree(z->d_corr);
   if (z->d_bd) (void)hipFree(z->d_bd);
   delete z;
@@ -1106,6 +1124,7 @@ bool ztile_plan(srmap_problem* p) {
               hipMalloc((void**)&z->d_off, 64) == hipSuccess;
     p->zplan = z;
     if (!ok) { ztile_release(p); return false; }
+    (void)spfwd_plan(p, &z->spf);
     return true;
   }
   // the border frame (k_border, width 2E) must stay a small part of the image
@@ -1329,7 +1348,10 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     // sub-pixel shifts: exact residuals (and the data cost) from the direct forward kernel, then the tile kernel
     // gathers them with the 4-tap tables; the pixels within Dr of the edge are redone exactly afterwards
     if (!p->d_resid) SRMAP_HIP(p->ctx, hipMalloc(&p->d_resid, p->lr_count() * sizeof(T)));
-    rc = launch_forward_direct<T>(p, geo, x, (const T*)p->d_obs, p->geo.C, obs_c0, (T*)p->d_resid, 0, geo.K, partials, &nfwd, st);
+    if (z.spf.ok)
+      rc = launch_forward_sp<T>(p, geo, z.spf, x, (const T*)p->d_obs, p->geo.C, obs_c0, (T*)p->d_resid, partials, &nfwd, st);
+    else
+      rc = launch_forward_direct<T>(p, geo, x, (const T*)p->d_obs, p->geo.C, obs_c0, (T*)p->d_resid, 0, geo.K, partials, &nfwd, st);
     if (rc) return rc;
     partials += nfwd;
   }

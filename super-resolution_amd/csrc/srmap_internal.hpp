@@ -166,6 +166,19 @@ template <typename T>
 int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,
                       const T* x, T* g, double* partials, int* nblocks, hipStream_t st);
 
+// ---- forward tile kernel for sub-pixel shifts (kernels_spfwd.hip) ----
+struct SpForwardPlan {
+  void* d_frames = nullptr;  // per frame: integer offsets + blur (x) bilinear stencil
+  int RLO = 0, CLO = 0, XR = 0, XC = 0;  // LDS window of a workgroup relative to its first LR row / cell
+  bool ok = false;
+};
+bool spfwd_plan(srmap_problem* p, SpForwardPlan* sp);
+void spfwd_release(SpForwardPlan* sp);
+// out[k][c][h][w] = A_k x - y_k for all frames + cost partials (one per workgroup)
+template <typename T>
+int launch_forward_sp(srmap_problem* p, const Geometry& geo, const SpForwardPlan& sp, const T* x, const T* y,
+                      int obs_C, int obs_c0, T* out, double* partials, int* nblocks, hipStream_t st);
+
 // ---- vector kernels for the solver (solver.hip) ----
 int solve_impl(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard,
                const srmap_irls_options* o, const double* x0, double* x_out,

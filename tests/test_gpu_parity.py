@@ -258,7 +258,8 @@ def test_subpixel_tile_path_matches_oracle(sr, ctx, case, regs, dtype):
     f2, g2 = p.eval(x)
     fd2, gd2 = p.eval(x, sr.TERM_DATA)
     assert abs(f - f2) <= (1e-12 if dtype == 0 else 1e-5) * max(1.0, abs(f2))
-    assert relerr(g, g2) <= 4 * tol and relerr(gd, gd2) <= 4 * tol and fd == fd2
+    assert relerr(g, g2) <= 4 * tol and relerr(gd, gd2) <= 4 * tol
+    assert abs(fd - fd2) <= (1e-12 if dtype == 0 else 1e-5) * max(1.0, abs(fd2))
 
 
 def test_lambda_zero_term_is_skipped(sr, ctx):
