@@ -8,6 +8,8 @@
 //       (kernels_tiled.hip) do not cover the geometry, and their cross-check.
 //
 // Math: SURVEY.md section 8(a'); reference lines are cited per kernel.
+#include <cstdint>
+
 #include "srmap_internal.hpp"
 
 namespace srmap {
@@ -431,19 +433,50 @@ __global__ __launch_bounds__(256) void k_tv_onepass(const T* __restrict__ x, con
         if (k < n) { const int cc = cs + k; dst[k] = (rin && (unsigned)cc < (unsigned)W) ? src[cc] : fill; }
     };
     T xc[P + 2], xd[P + 2], xu[P + 2], xn[P + 2], xnu[P + 2], xp[P + 2], xpd[P + 2], wc[P + 2], wu[P + 2], wp[P + 2];
-    row(plane, r, c0 - 1, P + 2, xc, T(0));      // columns c0-1 .. c0+4
-    row(plane, r + 1, c0 - 1, P + 1, xd, T(0));  // c0-1 .. c0+3
-    row(plane, r - 1, c0, P + 1, xu, T(0));      // c0 .. c0+4
+    T gold[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) gold[i] = T(0);
     const bool has_next = D3 && (c + 1 < C || zhi), has_prev = D3 && (c > 0 || zlo);
-    if (has_next) { row(plane + N, r, c0 - 1, P + 1, xn, T(0)); row(plane + N, r - 1, c0, P, xnu, T(0)); }
-    if (has_prev) { row(plane - N, r, c0, P + 1, xp, T(0)); row(plane - N, r + 1, c0, P, xpd, T(0)); }
-    if (gcp) {
-      row(gcp, r, c0 - 1, P + 1, wc, T(1));
-      row(gcp, r - 1, c0, P, wu, T(1));
-      if (has_prev) row(gcp - N, r, c0, P, wp, T(1));
+    T* gdst = gout ? gout + (size_t)c * N + (size_t)r * W + c0 : nullptr;
+    // rows r-1 .. r+1 inside the image and whole 4-pixel cells: every segment is one unconditional 4-vector plus
+    // at most one clamped neighbour element, all requested before the first use (wave-uniform branch; the masked
+    // element-wise form below made every load wait for the one before it)
+    const bool fast = (W & 3) == 0 && r >= 1 && r + 1 < H;
+    if (fast) {
+      const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + P < W ? c0 + P : W - 1;
+      const size_t o0 = (size_t)r * W, od = o0 + W, ou = o0 - W;
+      auto vec = [&](const T* src, T* dst) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) dst[k] = src[k];
+      };
+      vec(plane + o0 + c0, xc + 1); xc[0] = plane[o0 + cl]; xc[P + 1] = plane[o0 + cr];
+      vec(plane + od + c0, xd + 1); xd[0] = plane[od + cl];
+      vec(plane + ou + c0, xu); xu[P] = plane[ou + cr];
+      if (has_next) { vec(plane + N + o0 + c0, xn + 1); xn[0] = plane[N + o0 + cl]; vec(plane + N + ou + c0, xnu); }
+      if (has_prev) { vec(plane - N + o0 + c0, xp); xp[P] = plane[o0 + cr - N]; vec(plane - N + od + c0, xpd); }
+      if (gcp) {
+        vec(gcp + o0 + c0, wc + 1); wc[0] = gcp[o0 + cl];
+        vec(gcp + ou + c0, wu);
+        if (has_prev) vec(gcp - N + o0 + c0, wp);
+      }
+      if (gdst && accumulate) vec(gdst, gold);
+    } else {
+      row(plane, r, c0 - 1, P + 2, xc, T(0));      // columns c0-1 .. c0+4
+      row(plane, r + 1, c0 - 1, P + 1, xd, T(0));  // c0-1 .. c0+3
+      row(plane, r - 1, c0, P + 1, xu, T(0));      // c0 .. c0+4
+      if (has_next) { row(plane + N, r, c0 - 1, P + 1, xn, T(0)); row(plane + N, r - 1, c0, P, xnu, T(0)); }
+      if (has_prev) { row(plane - N, r, c0, P + 1, xp, T(0)); row(plane - N, r + 1, c0, P, xpd, T(0)); }
+      if (gcp) {
+        row(gcp, r, c0 - 1, P + 1, wc, T(1));
+        row(gcp, r - 1, c0, P, wu, T(1));
+        if (has_prev) row(gcp - N, r, c0, P, wp, T(1));
+      }
+      if (gdst && accumulate) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) if (c0 + i < W) gold[i] = gdst[i];
+      }
     }
     const bool down = r + 1 < H;
-    T* gdst = gout ? gout + (size_t)c * N + (size_t)r * W + c0 : nullptr;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int col = c0 + i;
@@ -491,9 +524,148 @@ __global__ __launch_bounds__(256) void k_tv_onepass(const T* __restrict__ x, con
           const T cq = gc_scale * (gcp ? wp[i] : T(1));
           grad += T(2) * cq * rq * sgn(x0 - v0);
         }
-        if (gdst) gdst[i] = (accumulate ? gdst[i] : T(0)) + grad;
+        if (gdst) gdst[i] = gold[i] + grad;
         // lambda * w * r^2  (objective_irls_regularization_term.cpp:45-50)
         cost += (r >= cr0 && r < cr1) ? (double)cc0 * (double)r0 * (double)r0 : 0.0;
+      }
+    }
+  }
+  if (partials) {  // (64, 4) block: wave = threadIdx.y
+    const double ws = wave_sum(cost);
+    if (threadIdx.x == 0) red[threadIdx.y] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+      partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// 3-D TV marching along the CHANNEL axis (tv_regularizer.cpp:110-227, the z terms :154-170 and :205-222).
+// k_tv_onepass gives every (pixel, channel) its own thread, so each plane is fetched three times (as the current,
+// the next and the previous channel) one whole plane of blocks apart -- from the Infinity Cache at best.  Here a
+// thread keeps its 4 pixels and walks a chunk of channels with the planes c-1, c, c+1 (rows r-1, r, r+1 of each)
+// in registers: per step it requests plane c+1, the weights and the old gradient of c -- all unconditional
+// (out-of-range planes are clamped to a valid one and never used), one wait, then the arithmetic; other waves
+// cover the wait.  Every plane, weight and gradient element crosses the fabric once per chunk.  The three plane
+// sets rotate with compile-time indices (loop unrolled by 3).  Same expressions, same order as k_tv_onepass.
+template <typename T> struct TvPlane { T m[6], d[5], u[5]; };  // row r: c0-1..c0+4, row r+1: c0-1..c0+3, row r-1: c0..c0+4
+
+template <typename T>
+__device__ __forceinline__ void tv_load4(const T* __restrict__ src, T* dst) {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  const V4 v = *reinterpret_cast<const V4*>(src);
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+}
+
+template <typename T>
+__device__ __forceinline__ void tv_load_plane(const T* __restrict__ pl, size_t o0, size_t od, size_t ou, int c0, int cl,
+                                              int cr, TvPlane<T>& R) {
+  tv_load4(pl + o0 + c0, R.m + 1); R.m[0] = pl[o0 + cl]; R.m[5] = pl[o0 + cr];
+  tv_load4(pl + od + c0, R.d + 1); R.d[0] = pl[od + cl];
+  tv_load4(pl + ou + c0, R.u); R.u[4] = pl[ou + cr];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tv3d_march(const T* __restrict__ x, const T* __restrict__ gc, T gc_scale,
+                                                    T* __restrict__ gout, int accumulate,
+                                                    double* __restrict__ partials, int W, int H, int C, int cr0,
+                                                    int cr1, int zlo, int zhi, int chunk) {
+  __shared__ double red[4];
+  constexpr int P = 4;
+  const int c0 = (blockIdx.x * 64 + threadIdx.x) * P, r = blockIdx.y * 4 + threadIdx.y;
+  const int cbeg = blockIdx.z * chunk, cend = (cbeg + chunk < C) ? cbeg + chunk : C;
+  const ptrdiff_t N = (ptrdiff_t)W * H;
+  double cost = 0.0;
+  if (c0 < W && r < H) {  // W % 4 == 0: whole cells
+    const bool up = r >= 1, down = r + 1 < H;
+    const int cl = c0 >= 1 ? c0 - 1 : 0, cr = c0 + P < W ? c0 + P : W - 1;
+    const size_t o0 = (size_t)r * W, od = o0 + (down ? W : 0), ou = o0 - (up ? W : 0);
+    const bool cost_row = r >= cr0 && r < cr1;
+    const int plo = zlo ? -1 : 0, phi = zhi ? C : C - 1;  // planes that exist
+    auto clampc = [&](int c) { return c < plo ? plo : (c > phi ? phi : c); };
+    TvPlane<T> R[3];
+    T wprev[P];
+    tv_load_plane(x + clampc(cbeg - 1) * N, o0, od, ou, c0, cl, cr, R[2]);
+    tv_load_plane(x + cbeg * N, o0, od, ou, c0, cl, cr, R[0]);
+#pragma unroll
+    for (int i = 0; i < P; ++i) wprev[i] = T(1);
+    if (gc) tv_load4(gc + clampc(cbeg - 1) * N + o0 + c0, wprev);
+    for (int cb = cbeg; cb < cend; cb += 3) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = cb + k;
+        if (c < cend) {  // uniform
+          const TvPlane<T>& Rc = R[k];
+          TvPlane<T>& Rn = R[(k + 1) % 3];
+          const TvPlane<T>& Rp = R[(k + 2) % 3];
+          tv_load_plane(x + clampc(c + 1) * N, o0, od, ou, c0, cl, cr, Rn);
+          T wc[P + 1], wu[P], gold[P];
+#pragma unroll
+          for (int i = 0; i < P; ++i) { wc[i] = T(1); wu[i] = T(1); gold[i] = T(0); }
+          wc[P] = T(1);
+          if (gc) {
+            const T* g0 = gc + c * N;
+            tv_load4(g0 + o0 + c0, wc + 1); wc[0] = g0[o0 + cl];
+            tv_load4(g0 + ou + c0, wu);
+          }
+          if (gout && accumulate) tv_load4(gout + c * N + o0 + c0, gold);
+          const bool has_next = (c + 1 < C || zhi), has_prev = (c > 0 || zlo);
+          T gnew[P];
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            const int col = c0 + i;
+            const bool right = col + 1 < W;
+            const T x0 = Rc.m[i + 1];
+            const T cc0 = gc_scale * wc[i + 1];
+            T r0;
+            {
+              const T yv = down ? absval(Rc.d[i + 1] - x0) : T(0);
+              const T xv = right ? absval(Rc.m[i + 2] - x0) : T(0);
+              r0 = yv + xv;
+              if (has_next) r0 += absval(Rn.m[i + 1] - x0);
+            }
+            T grad = T(0);
+            T didi = T(0);
+            if (right) didi -= sgn(Rc.m[i + 2] - x0);
+            if (down) didi -= sgn(Rc.d[i + 1] - x0);
+            grad += T(2) * cc0 * r0 * didi;  // 3-D TV has no z self term (tv_regularizer.cpp:154-170)
+            if (col - 1 >= 0) {
+              const T v0 = Rc.m[i];
+              const T yv = down ? absval(Rc.d[i] - v0) : T(0);
+              const T xv = absval(x0 - v0);
+              T rq = yv + xv;
+              if (has_next) rq += absval(Rn.m[i] - v0);
+              const T cq = gc_scale * wc[i];
+              grad += T(2) * cq * rq * sgn(x0 - v0);
+            }
+            if (up) {
+              const T v0 = Rc.u[i];
+              const T yv = absval(x0 - v0);
+              const T xv = right ? absval(Rc.u[i + 1] - v0) : T(0);
+              T rq = yv + xv;
+              if (has_next) rq += absval(Rn.u[i] - v0);
+              const T cq = gc_scale * wu[i];
+              grad += T(2) * cq * rq * sgn(x0 - v0);
+            }
+            if (has_prev) {
+              const T v0 = Rp.m[i + 1];
+              const T yv = down ? absval(Rp.d[i + 1] - v0) : T(0);
+              const T xv = right ? absval(Rp.m[i + 2] - v0) : T(0);
+              T rq = yv + xv;
+              rq += absval(x0 - v0);
+              const T cq = gc_scale * wprev[i];
+              grad += T(2) * cq * rq * sgn(x0 - v0);
+            }
+            gnew[i] = gold[i] + grad;
+            cost += cost_row ? (double)cc0 * (double)r0 * (double)r0 : 0.0;
+          }
+          if (gout) {
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            V4 v; v.x = gnew[0]; v.y = gnew[1]; v.z = gnew[2]; v.w = gnew[3];
+            *reinterpret_cast<V4*>(gout + c * N + o0 + c0) = v;
+          }
+#pragma unroll
+          for (int i = 0; i < P; ++i) wprev[i] = wc[i + 1];
+        }
       }
     }
   }
@@ -513,6 +685,20 @@ int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegS
                                hipStream_t st) {
   if (values == nullptr && rs.kind != SRMAP_REG_BTV) {  // TV kinds, one pass
     dim3 grid2((geo.W + 255) / 256, (geo.H + 3) / 4, geo.C);
+    const size_t valign = 4 * sizeof(T);
+    if (rs.kind == SRMAP_REG_TV3D && geo.C >= 2 && (geo.W & 3) == 0 && ((uintptr_t)x % valign) == 0 &&
+        (!gc || ((uintptr_t)gc % valign) == 0) && (!g || ((uintptr_t)g % valign) == 0)) {
+      // channel march: chunks of channels per thread; enough chunks to fill the GPU at a few planes of overlap each
+      const long long per_plane = (long long)grid2.x * grid2.y;
+      int chunk = geo.C;
+      while (chunk > 16 && per_plane * ((geo.C + chunk - 1) / chunk) < 4096) chunk = (chunk + 1) / 2;
+      dim3 grid3(grid2.x, grid2.y, (geo.C + chunk - 1) / chunk);
+      hipLaunchKernelGGL(k_tv3d_march<T>, grid3, dim3(64, 4), 0, st, x, gc, (T)gc_scale, g, accumulate ? 1 : 0, partials,
+                         geo.W, geo.H, geo.C, geo.cr0, geo.cr1, geo.zlo, geo.zhi, chunk);
+      if (nblocks) *nblocks = (int)(grid3.x * grid3.y * grid3.z);
+      SRMAP_HIP(p->ctx, hipGetLastError());
+      return SRMAP_OK;
+    }
     if (rs.kind == SRMAP_REG_TV3D)
       hipLaunchKernelGGL((k_tv_onepass<T, true>), grid2, dim3(64, 4), 0, st, x, gc, (T)gc_scale, g, accumulate ? 1 : 0,
                          partials, geo.W, geo.H, geo.C, geo.cr0, geo.cr1, geo.zlo, geo.zhi);

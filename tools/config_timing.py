@@ -23,12 +23,15 @@ def main():
     if blurred:
         for c in (3, 4, 5):
             CFG[c]["blur"] = (3, 1.0); CFG[c]["name"] += " + blur"
+    chan = None
+    if "--channels" in sys.argv:  # override the channel count (per-kernel profiles of cfg4 / cfg5 at a few channels)
+        i = sys.argv.index("--channels"); chan = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
     which = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
     dev = torch.device("cuda", 0)
     ctx = srmap.Context(0)
     for c in which:
         cf = CFG[c]
-        W, C, K, s = cf["W"], cf["C"], cf["K"], cf["s"]
+        W, C, K, s = cf["W"], chan or cf["C"], cf["K"], cf["s"]
         w = W // s
         shifts = [[k % s, (k // s) % s] for k in range(K)]
         g = torch.Generator(device=dev); g.manual_seed(c)
@@ -38,7 +41,8 @@ def main():
         p = srmap.Problem(ctx, W, W, C, K, s, shifts, cf["blur"][0], cf["blur"][1], srmap.F64)
         p.set_observations_device(y.data_ptr())
         for kind, r, d in cf["regs"]:
-            p.add_regularizer(kind, 0.01, r, d)
+            ri = p.add_regularizer(kind, 0.01, r, d)
+            p.update_irls_weights_device(ri, x.data_ptr())  # IRLS weights resident, as in the solver loop
         n = 3 if C >= 128 else 30
         for _ in range(2):
             p.eval_device(x.data_ptr(), gr.data_ptr(), srmap.TERM_ALL)
