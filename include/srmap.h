@@ -195,6 +195,18 @@ int srmap_channel_pca_device(srmap_ctx* ctx, int rows, size_t n, const double* i
                              size_t first, size_t stride, size_t count, double* mean_out,
                              double* eigenvalues_out, double* basis_out);
 
+/* ------------------------------------------------------- registration */
+/* registration::TranslationalRegistration (src/motion/registration.h:19-22, registration.cpp:161-201): the
+ * shift (dx, dy) of every image relative to the first one -- content at p in image 0 sits at p + (dx, dy) in
+ * image i, the convention of MotionModule / MotionShift -- estimated on the GPU (box pyramid, exhaustive
+ * integer search coarse to fine, Gauss-Newton sub-pixel refinement; see csrc/registration.hip for why this is
+ * not the reference's OpenCV feature pipeline).  images_host: num_images planes [height][width] (the reference
+ * registers on channel 0, registration.cpp:41-46).  shifts_xy_out: 2 * num_images doubles, image 0 -> (0, 0).
+ * num_images == 0 returns SRMAP_OK and writes nothing (registration.cpp:165-168).  SRMAP_EINVAL when no shift
+ * can be determined (the reference CHECK-fails, registration.cpp:193-194). */
+int srmap_register_translational(srmap_ctx* ctx, int num_images, int width, int height,
+                                 const double* images_host, double* shifts_xy_out);
+
 /* ------------------------------------------------------------- solver */
 /* IRLSMapSolverOptions (irls_map_solver.h:14-36) + MapSolverOptions
  * (map_solver.h:28-79); srmap_irls_options_default() fills the reference

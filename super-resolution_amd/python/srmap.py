@@ -89,6 +89,7 @@ _SIGNATURES = [
     ("srmap_download", C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_size_t]),
     ("srmap_channel_map", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("srmap_channel_map_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("srmap_register_translational", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
     ("srmap_channel_pca", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("srmap_channel_pca_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, c_double_p, c_double_p, c_double_p]),
     ("srmap_synchronize", C.c_int, [C.c_void_p]),
@@ -165,6 +166,14 @@ class Context:
         oo = _d(offset_out) if offset_out is not None else (None, None)
         self.check(load().srmap_channel_map_device(self._h, ro, ri, n, pM, oi[1], oo[1], C.c_void_p(in_ptr),
                                                    C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
+
+    def register_translational(self, images):
+        """registration::TranslationalRegistration: images [n][H][W] -> shifts [n][2] (dx, dy) relative to image 0."""
+        a, pa = _d(images)
+        n, H, W = a.shape
+        out = np.zeros((n, 2))
+        self.check(load().srmap_register_translational(self._h, n, W, H, pa, out.ctypes.data_as(c_double_p)))
+        return out
 
     def pca(self, samples):
         """PCA of planar samples [rows][count] on the GPU: (mean, eigenvalues descending, basis rows = eigenvectors)."""

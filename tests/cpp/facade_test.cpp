@@ -11,6 +11,7 @@
 //   test/test_spectral_pca.cpp:19-137  SpectralPCA literal + reconstruction bounds
 //   src/optimization/irls_map_solver.cpp:200-262  the objective assembled term by term (ObjectiveFunction,
 //       ObjectiveDataTerm, ObjectiveIRLSRegularizationTerm) equals MapSolver::ComputeAllTerms
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -22,6 +23,7 @@
 #include "image/image_data.h"
 #include "image_model/image_model.h"
 #include "motion/motion_shift.h"
+#include "motion/registration.h"
 #include "optimization/irls_map_solver.h"
 #include "optimization/regularizer.h"
 
@@ -377,6 +379,47 @@ static void TestSpectralPca() {
   EXPECT(MaxAbsDiff(pca_var.ReconstructImage(pca_var_image), cube) <= 0.05);
 }
 
+// test/test_registration.cpp:27-68: shifts applied with MotionModule are recovered to 0.01 px.  The reference's
+// test image is a JPEG (no decoder here): a deterministic textured image stands in for it.
+static void TestRegistration() {
+  const int W = 320, H = 240;
+  std::vector<double> px(static_cast<size_t>(W) * H);
+  std::mt19937_64 rng(7);
+  std::uniform_real_distribution<double> uni(0.0, 1.0);
+  std::vector<double> coarse(40 * 30);
+  for (auto& v : coarse) v = uni(rng);
+  for (int r = 0; r < H; ++r)
+    for (int c = 0; c < W; ++c) {
+      const double u = c / 8.0, v = r / 8.0;  // bilinear blow-up of a random 40 x 30 grid + two sinusoids
+      const int u0 = std::min(38, (int)u), v0 = std::min(28, (int)v);
+      const double a = u - u0, b = v - v0;
+      const double g = (1 - b) * ((1 - a) * coarse[v0 * 40 + u0] + a * coarse[v0 * 40 + u0 + 1]) +
+                       b * ((1 - a) * coarse[(v0 + 1) * 40 + u0] + a * coarse[(v0 + 1) * 40 + u0 + 1]);
+      px[static_cast<size_t>(r) * W + c] = 0.6 * g + 0.2 + 0.1 * std::sin(0.21 * c) * std::cos(0.17 * r);
+    }
+  const ImageData original(px.data(), cv::Size(W, H));
+  for (int sub = 0; sub < 2; ++sub) {
+    std::vector<MotionShift> truth = sub ? std::vector<MotionShift>{MotionShift(0, 0), MotionShift(0.5, -0.25), MotionShift(1.75, 2.5), MotionShift(-3.125, 0.875)}
+                                         : std::vector<MotionShift>{MotionShift(0, 0), MotionShift(0, 1), MotionShift(2, 0), MotionShift(5, 5), MotionShift(-5, -1)};
+    const MotionShiftSequence truth_seq(truth);
+    const MotionModule motion(truth_seq);
+    std::vector<ImageData> shifted;
+    for (int i = 0; i < truth_seq.GetNumMotionShifts(); ++i) {
+      ImageData im = original;
+      motion.ApplyToImage(&im, i);
+      shifted.push_back(im);
+    }
+    const MotionShiftSequence got = registration::TranslationalRegistration(shifted);
+    EXPECT(got.GetNumMotionShifts() == truth_seq.GetNumMotionShifts());
+    const double tol = sub ? 0.05 : 0.01;  // kTranslationEstimateErrorTolerance = 0.01 for the reference's (integer) shifts
+    for (int i = 0; i < got.GetNumMotionShifts(); ++i) {
+      EXPECT(std::fabs(got[i].dx - truth[i].dx) <= tol);
+      EXPECT(std::fabs(got[i].dy - truth[i].dy) <= tol);
+    }
+  }
+  EXPECT(registration::TranslationalRegistration({}).GetNumMotionShifts() == 0);
+}
+
 int main() {
   TestDownsamplingModule();
   TestBlurModule();
@@ -389,6 +432,7 @@ int main() {
   TestPsnr();
   TestSsimAndNoise();
   TestSpectralPca();
+  TestRegistration();
   std::printf(g_fail ? "FACADE TESTS FAILED (%d)\n" : "FACADE TESTS PASSED\n", g_fail);
   return g_fail ? 1 : 0;
 }
