@@ -160,7 +160,7 @@ REGS = [("tv", 0, 0, 0.0), ("tv3d", 1, 0, 0.0), ("btv", 2, 1, 0.25), ("btv", 2, 
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("reg", range(len(REGS)))
-@pytest.mark.parametrize("shape", [(1, 5, 5), (3, 13, 17), (2, 1, 9), (2, 8, 1)])
+@pytest.mark.parametrize("shape", [(1, 5, 5), (3, 13, 17), (2, 1, 9), (2, 8, 1), (5, 7, 12), (40, 9, 16)])  # last two: W % 4 == 0 -> the channel-marching 3-D TV kernel, one chunk / four chunks of channels
 def test_regularizer_values_and_gradient(sr, ctx, reg, shape, dtype):
     """Regularizer::ApplyToImage / ApplyToImageWithDifferentiation incl. the
     reference's quirks: exclusive BTV gradient window, absolute-(0,0) skip,
