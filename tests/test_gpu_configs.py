@@ -309,3 +309,39 @@ def test_cfg4_full_size(sr, ctx):
 def test_cfg5_full_size(sr, ctx):
     """64 frames x 256 channels, 4x -> 2048 x 2048, BTV(3) + 3-D TV (previous / next channel coupling)."""
     _full_size_case(sr, ctx, "cfg5", 2048, 2048, 256, [0, 1, 128, 255])
+
+
+def test_indexing_beyond_2_31_elements(sr):
+    """a15 (GetPixelIndex, 64-bit offsets): K * C * n = 2.28 G observation elements (> 2^31) at cfg5-like extents;
+    the gradient of the first / middle / LAST channel of the many-channel problem must be bit-identical to that of a
+    single-channel problem built from the same slices.  Device-generated data (no multi-GB host arrays), f32."""
+    import torch
+    C, K, s, W = 136, 64, 4, 2048
+    H, w, h = W, W // s, W // s
+    dev = torch.device("cuda", 0)
+    shifts = [[k % s, (k // s) % s] for k in range(K)]
+    ctx = sr.Context(0)
+    big = sr.Problem(ctx, W, H, C, K, s, shifts, 3, 1.0, sr.F32)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    y = torch.rand((K, C, h, w), generator=g, device=dev, dtype=torch.float32)
+    assert y.numel() > 2 ** 31
+    big.set_observations_device(y.data_ptr())
+    big.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
+    x = torch.rand((C, H, W), generator=g, device=dev, dtype=torch.float32)
+    gbig = torch.empty_like(x)
+    cost_big = big.eval_device(x.data_ptr(), gbig.data_ptr(), sr.TERM_ALL, want_cost=True)
+    torch.cuda.synchronize()
+    assert np.isfinite(cost_big) and cost_big > 0
+    for c in (0, C // 2, C - 1):
+        one = sr.Problem(ctx, W, H, 1, K, s, shifts, 3, 1.0, sr.F32)
+        yc = y[:, c:c + 1].contiguous()
+        one.set_observations_device(yc.data_ptr())
+        one.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
+        xc = x[c:c + 1].contiguous()
+        gc = torch.empty_like(xc)
+        one.eval_device(xc.data_ptr(), gc.data_ptr(), sr.TERM_ALL, want_cost=True)
+        torch.cuda.synchronize()
+        assert torch.equal(gc[0], gbig[c]), "channel %d differs" % c
+        del one
+    del big, x, y, gbig
+    torch.cuda.empty_cache()
