@@ -958,7 +958,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T* __restrict__ corr, int n_ring, int W,
                                                      int H, int E, int C, const double* __restrict__ partials,
                                                      int n_partials, double* __restrict__ cost_out,
-                                                     const double* __restrict__ partials_gd) {
+                                                     const double* __restrict__ partials_gd, double* pub,
+                                                     double* tag_slot, double tag) {
   __shared__ double red[4];
   double v = 0.0, v2 = 0.0;
   if (blockIdx.x == 0)
@@ -990,7 +991,16 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
       __syncthreads();
       if (lane == 0) red[wid] = v2;
       __syncthreads();
-      if (threadIdx.x == 0) cost_out[1] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (threadIdx.x == 0) {
+        const double gd = (red[0] + red[1]) + (red[2] + red[3]);
+        cost_out[1] = gd;
+        if (pub != nullptr) {  // solver line search: {cost, g.d} straight to the host-mapped words, then the arrival tag
+          pub[0] = cost_out[0];
+          pub[1] = gd;
+          __threadfence_system();
+          *(volatile double*)tag_slot = tag;
+        }
+      }
     }
   }
 }
@@ -1358,6 +1368,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   const T* dv = with_d ? (const T*)p->eval_dvec : nullptr;
   double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
   p->gd_valid = false;
+  p->eval_published = false;
   if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
   else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
   else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
@@ -1401,16 +1412,19 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     const int nring = corr_on ? z.n_ring : 0;
     const unsigned nb_f = (unsigned)std::max(1, (nring + 255) / 256);
     hipLaunchKernelGGL(k_finish_eval<T>, dim3(nb_f), dim3(256), 0, st, corr_on ? g : (T*)nullptr, (const T*)z.d_corr,
-                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, total, p->d_cost, (const double*)pgd);
+                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, total, p->d_cost, (const double*)pgd,
+                       with_d ? p->eval_pub : (double*)nullptr, p->eval_pub_tag_slot, p->eval_pub_tag);
     SRMAP_HIP(p->ctx, hipGetLastError());
     p->gd_valid = with_d;  // d_cost[1] = g.d
+    p->eval_published = with_d && p->eval_pub != nullptr;
     *nblocks = 0;  // total already in d_cost[0]
     return SRMAP_OK;
   }
   // many partials (multi-channel problems): corrections here, two-stage reduction by the caller
   if (corr_on) {
     hipLaunchKernelGGL(k_finish_eval<T>, dim3((unsigned)((z.n_ring + 255) / 256)), dim3(256), 0, st, g, (const T*)z.d_corr,
-                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, 0, p->d_cost + 1, (const double*)nullptr);
+                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, 0, p->d_cost + 1, (const double*)nullptr,
+                       (double*)nullptr, (double*)nullptr, 0.0);
     SRMAP_HIP(p->ctx, hipGetLastError());
   }
   *nblocks = total;

@@ -284,6 +284,7 @@ struct DeviceCG {
   const srmap_shard_desc* shard = nullptr;
   Owned ow{};
   bool reduce_scalars = false;  // row / channel shards: the owned-element sums are all-reduced
+  bool published = false;       // the last evaluation's finish kernel published {f, g.d} + tag (fetch_f_gd just waits)
   // x, g: current point and gradient; xk/dk: accepted point and direction; dn: next direction;
   // d: normalised direction; yk = -g (then g_{k+1} - g_k).  The line-search base is xk itself.
   T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr, *yk = nullptr;
@@ -384,8 +385,16 @@ struct DeviceCG {
     const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
     p->eval_dvec = (mode == SRMAP_SHARD_FRAMES || mode == SRMAP_SHARD_CHANNELS) ? nullptr : dir;
     p->gd_valid = false;
+    p->eval_published = false;
+    // without a scalar all-reduce the evaluation's finish kernel can publish {f, g.d} and the arrival tag itself
+    p->eval_pub = (!reduce_scalars && p->eval_dvec != nullptr) ? hs : nullptr;
+    p->eval_pub_tag_slot = hs + 15;
+    p->eval_pub_tag = tag + 1.0;
     const int rc = shard_eval(p, comm, shard, SRMAP_TERM_ALL, x, g, st);
     p->eval_dvec = nullptr;
+    p->eval_pub = nullptr;
+    published = p->eval_published;
+    if (published) tag += 1.0;
     return rc;
   }
   // f and g.d of the evaluation just made, with one wait: out[0] = g.d, out[1] = f
@@ -393,6 +402,14 @@ struct DeviceCG {
     if (!p->gd_valid) {
       hipLaunchKernelGGL(k_dot<T>, dim3(nb()), dim3(256), 0, st, (const T*)g, (const T*)d, n, ow, part);
       return finish(1, false, true, out);
+    }
+    if (published) {  // the evaluation's own finish kernel carries the tag
+      published = false;
+      const int rcw = wait_tag();
+      if (rcw) return rcw;
+      out[0] = hs[1];
+      out[1] = hs[0];
+      return SRMAP_OK;
     }
     tag += 1.0;
     if (!reduce_scalars) {

@@ -101,6 +101,12 @@ struct srmap_problem {
   const void* eval_dvec = nullptr;  // set by the solver around an evaluation: direction d (device, dtype); the tile
                                     // kernel then produces g.d with the gradient (one pass and two launches fewer)
   bool gd_valid = false;            // the last evaluation left g.d in d_cost[1]
+  // set by the solver around an evaluation: host-mapped words the evaluation's finish kernel publishes
+  // {cost, g.d} to, followed by the arrival tag (saves the separate publish launch); eval_published reports it did
+  double* eval_pub = nullptr;
+  double* eval_pub_tag_slot = nullptr;
+  double eval_pub_tag = 0.0;
+  bool eval_published = false;
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
   void* zplan = nullptr;          // srmap::ZPlan of the z-tile kernels (kernels_ztile.hip), owned; nullptr = not covered
