@@ -192,8 +192,8 @@ class Context:
         return mean, ev, basis
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            load().srmap_ctx_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # at interpreter exit the module globals may be gone
+            _lib.srmap_ctx_destroy(self._h)
             self._h = None
 
 
@@ -225,8 +225,8 @@ class Problem:
         self.nreg = 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            load().srmap_problem_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # at interpreter exit the module globals may be gone
+            _lib.srmap_problem_destroy(self._h)
             self._h = None
 
     @property
@@ -414,6 +414,6 @@ class Comm:
         return buf.raw
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            load().srmap_comm_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # at interpreter exit the module globals may be gone
+            _lib.srmap_comm_destroy(self._h)
             self._h = None
