@@ -147,7 +147,10 @@ int srmap_reg_values_and_gradient(srmap_problem* p, int reg, const double* x,
 int srmap_eval(srmap_problem* p, unsigned terms, const double* x, double* cost,
                double* grad);
 /* Device-resident form: x_dev / g_dev hold the problem dtype ([C][H][W]).
- * Work is enqueued on `hip_stream` (NULL = the context's stream).  When
+ * Work is enqueued on `hip_stream` (NULL = the context's stream, which is a
+ * NON-BLOCKING stream: it does not order itself against the legacy default
+ * stream, so buffers produced by other streams must be complete -- or pass the
+ * producing stream here).  When
  * cost != NULL the call synchronises the stream and returns the cost; when
  * cost == NULL it returns right after enqueueing (the cost stays on device
  * until srmap_last_cost()). */

@@ -209,18 +209,28 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
   constexpr int HB = C::HB, NV = C::NV;
   const size_t slot = (size_t)(pr * A.MS + t) * S;  // uniform
   const T* yrow = ybase + ((long long)rc * A.wl + cell0);  // uniform: LR cell row rc, first cell of the tile
+  if (!EDGE) {
+    // branch-free: the S offsets of this table row come as ONE scalar load and every pixel's observation is
+    // requested (unused slots hold offset 0 = a valid element of this LR row; their values are never consumed).
+    // A uniform branch per pixel made each request wait for its own scalar load: six serialised round trips per row.
+    long long offs[S];
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) offs[pc] = A.off[slot + pc];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+      const T* yp = yrow + (offs[pc] + dc);  // uniform pointer; the lane adds its (non-negative) cell index
+      yv[v] = yp[(unsigned)lane];
+    }
+    return;
+  }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
     yv[v] = T(0);
     if (t < cn[pc]) {  // uniform
-      if (!EDGE) {
-        const T* yp = yrow + (A.off[slot + pc] + dc);  // uniform pointer; the lane adds its (non-negative) cell index
-        yv[v] = yp[(unsigned)lane];
-      } else {
-        const ZEntry e = A.aux[slot + pc];
-        yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
-      }
+      const ZEntry e = A.aux[slot + pc];
+      yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
     }
   }
 }

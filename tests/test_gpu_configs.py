@@ -238,6 +238,7 @@ def _full_size_case(sr, ctx, name, W, H, C, check_channels, blurred=False):
     y = torch.rand((K, C, h, w), generator=gen, device=dev, dtype=torch.float64)
     x = torch.rand((C, H, W), generator=gen, device=dev, dtype=torch.float64)
     x = torch.round(x * 1024) / 1024  # ties
+    torch.cuda.synchronize()  # the library enqueues on its own stream
     p = sr.Problem(ctx, W, H, C, K, s, shifts, b, sigma, sr.F64)
     p.set_observations_device(y.data_ptr())
     for kind, lam, rg, dc in cf["regs"]:
@@ -329,6 +330,7 @@ def test_indexing_beyond_2_31_elements(sr):
     big.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
     x = torch.rand((C, H, W), generator=g, device=dev, dtype=torch.float32)
     gbig = torch.empty_like(x)
+    torch.cuda.synchronize()  # the library enqueues on its own (non-blocking) stream: torch's generators must be done
     cost_big = big.eval_device(x.data_ptr(), gbig.data_ptr(), sr.TERM_ALL, want_cost=True)
     torch.cuda.synchronize()
     assert np.isfinite(cost_big) and cost_big > 0
@@ -339,6 +341,7 @@ def test_indexing_beyond_2_31_elements(sr):
         one.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
         xc = x[c:c + 1].contiguous()
         gc = torch.empty_like(xc)
+        torch.cuda.synchronize()
         one.eval_device(xc.data_ptr(), gc.data_ptr(), sr.TERM_ALL, want_cost=True)
         torch.cuda.synchronize()
         assert torch.equal(gc[0], gbig[c]), "channel %d differs" % c
