@@ -123,12 +123,12 @@ struct ZArgs {
   const T* dvec;         // WD instances: search direction d; the kernel also produces partials of g.d
   double* partials_gd;   //   (same indexing as partials)
   const T* rbuf;         // SP instances (sub-pixel shifts): residuals r_k = A_k x - y_k, [K][C][h][w], from k_forward_direct
-  const double* spw;     //   bilinear tap weight of every table entry, [S][MS][S]
+  const double* spw;     //   bilinear tap weight of every table entry, [MS][S][S]
   int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
   const int* cnt;        // [S][8]  residuals per (row phase, column phase); [pr][S] = max over the column phases
-  const long long* off;  // [S][MS][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
-  const ZEntry* aux;     // [S][MS][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
-  int MS;                // slots per (row phase, column phase)
+  const long long* off;  // [MS][S][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
+  const ZEntry* aux;     // [MS][S][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
+  int MS;                // slots per (row phase, column phase); tables are [MS][S][S] (round, row phase, column phase)
   const BorderArgs<T>* bd;  // device-resident constants of the border blocks
   int W, H, wl, hl;
   int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
@@ -207,7 +207,7 @@ template <typename T, int S, typename C, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int t, int cell0, int lane,
                                              const T* __restrict__ ybase, const int (&cn)[S], T (&yv)[C::NV]) {
   constexpr int HB = C::HB, NV = C::NV;
-  const size_t slot = (size_t)(pr * A.MS + t) * S;  // uniform
+  const size_t slot = (size_t)(t * S + pr) * S;  // uniform; round-major: round 0 (the prefetch) needs no table size
   const T* yrow = ybase + ((long long)rc * A.wl + cell0);  // uniform: LR cell row rc, first cell of the tile
   if (!EDGE) {
     // branch-free: the S offsets of this table row come as ONE scalar load and every pixel's observation is
@@ -224,15 +224,18 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
     }
     return;
   }
+  // EDGE: the same without branches -- (frame, LR row, LR column) entries of the table row in one scalar load, every
+  // address clamped into the image (unused slots are frame 0, offset 0); validity is the consumer's business
+  ZEntry ent[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) ent[pc] = A.aux[slot + pc];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-    yv[v] = T(0);
-    if (t < cn[pc]) {  // uniform
-      const ZEntry e = A.aux[slot + pc];
-      yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
-    }
+    const ZEntry e = ent[pc];
+    yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
   }
+  (void)cn;
 }
 
 // ---- data term, phase 1, for the S pixels of one cell in tile row `rowrel` (wave-uniform) ----
@@ -287,7 +290,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
     } else {
       load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ybase, cn, yv);
     }
-    const size_t slot = (size_t)(pr * A.MS + t) * S;
+    const size_t slot = (size_t)(t * S + pr) * S;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
@@ -350,7 +353,7 @@ __device__ __forceinline__ void sp_load_round(const ArgsT& A, int pr, int rc, in
                                               const int (&cn)[S], T (&rv)[C::NV], T (&wm)[C::NV]) {
   constexpr int HB = C::HB, NV = C::NV;
   const size_t nl = (size_t)A.wl * A.hl;
-  const int slot = (pr * A.MS + t) * S;
+  const int slot = (t * S + pr) * S;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
@@ -888,11 +891,13 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
       else
         reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, false);
     }
-    if (reg_halo_on && wv == C::NW - 1 && lane < C::TH + RU) {  // left halo columns -1 .. -RU, one row per lane
+    // left halo columns -1 .. -RU, one row per lane, one column per wave (a few-lane task with a
+    // long dependent chain -- both columns on one wave made the whole workgroup wait for it at the barrier)
+    if (reg_halo_on && (wv == 4 || wv == 5) && lane < C::TH + RU) {  // waves 4 / 5: their SIMDs carry the z halo rows only
       const int rowrel = lane - RU;
       const int lo = rowrel * C::XROW, lc = rowrel * C::CROW;  // per-lane row offsets
-      if (RU >= 1) reg_halo_col<T, S, REGK, R, C, -1>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-      if (RU >= 2) reg_halo_col<T, S, REGK, R, C, -2>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+      if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+      if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
     }
   }
   __syncthreads();
@@ -1032,8 +1037,8 @@ struct ZPlan {
   int2* d_hdr = nullptr;       // flat table of k_border: (count, first entry) per phase
   ZEntry* d_ent = nullptr;
   int* d_cnt = nullptr;        // tile kernel: [S][8]
-  long long* d_off = nullptr;  //              [S][MS][S]
-  ZEntry* d_aux = nullptr;     //              [S][MS][S]
+  long long* d_off = nullptr;  //              [MS][S][S]
+  ZEntry* d_aux = nullptr;     //              [MS][S][S]
   int n_ring = 0;              // pixels of the border frame (0 without motion)
   void* d_corr = nullptr;      // [C][n_ring] border corrections of the gradient
   void* d_bd = nullptr;        // BorderArgs<T> (device)
@@ -1128,7 +1133,7 @@ bool ztile_plan(srmap_problem* p) {
         cnt[(size_t)pr * 8 + pc] = (int)l.size();
         mx = std::max(mx, (int)l.size());
         for (size_t t = 0; t < l.size(); ++t) {
-          const size_t slot = ((size_t)pr * MS + t) * S + pc;
+          const size_t slot = ((size_t)t * S + pr) * S + pc;
           aux[slot] = l[t].e;
           spw[slot] = l[t].w;
         }
@@ -1192,7 +1197,7 @@ bool ztile_plan(srmap_problem* p) {
       mx = std::max(mx, h.x);
       for (int t = 0; t < h.x; ++t) {
         const ZEntry& e = ent[(size_t)h.y + t];
-        const size_t slot = ((size_t)pr * MS + t) * S + pc;
+        const size_t slot = ((size_t)t * S + pr) * S + pc;
         aux[slot] = e;
         off[slot] = (long long)e.k * g.C * nl + (long long)e.io * g.w + e.jo;
       }
