@@ -1,0 +1,42 @@
+"""Instruments a COPY of csrc/kernels_ztile.hip (written to /tmp/spx/kz_time.hip) with per-wave s_memtime stamps at the
+phase boundaries of k_eval_z and a setter srmap_dbg_set_timing(buffer).  Timing-only: see build.sh / run.py."""
+import sys
+root = sys.argv[1] if len(sys.argv) > 1 else "/root/repo"
+src=open(root + '/super-resolution_amd/csrc/kernels_ztile.hip').read()
+s=src
+s=s.replace('namespace {\n\n__device__ __forceinline__ double wave_sum_d','namespace {\n\n__device__ unsigned long long* g_ztdbg = nullptr;\n#define ZT_STAMP(i) do { zts[i] = __builtin_readcyclecounter(); } while (0)\n\n__device__ __forceinline__ double wave_sum_d',1)
+def rep(old,new):
+    global s
+    assert old in s, old
+    s=s.replace(old,new,1)
+rep('''  const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;''','''  const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;
+  unsigned long long* dbg = g_ztdbg ? g_ztdbg + ((size_t)(by * gridDim.x + blockIdx.x) * 8 + wv) * 16 : nullptr;
+  unsigned long long zts[10];
+  ZT_STAMP(0);''')
+rep('''  T ypre[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) ypre[v] = T(0);''','''  ZT_STAMP(1);
+  T ypre[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) ypre[v] = T(0);''')
+rep('''  if (!SP && has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);''','''  ZT_STAMP(2);
+  if (!SP && has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
+  ZT_STAMP(3);''')
+rep('''  // ---------------- x tile -> LDS, polyphase ----------------''','''  ZT_STAMP(4);
+  // ---------------- x tile -> LDS, polyphase ----------------''')
+rep('''  // in-image mask of this thread's pixels (partial tiles at the right / bottom edge)''','''  ZT_STAMP(5);
+  // in-image mask of this thread's pixels (partial tiles at the right / bottom edge)''')
+rep('''  // ---------------- phase 1: regulariser ----------------''','''  ZT_STAMP(6);
+  // ---------------- phase 1: regulariser ----------------''')
+rep('''  __syncthreads();
+
+  // ---------------- phase 2 ----------------''','''  ZT_STAMP(7);
+  __syncthreads();
+  ZT_STAMP(8);
+
+  // ---------------- phase 2 ----------------''')
+rep('''  // ---------------- cost partial of this workgroup ----------------''','''  ZT_STAMP(9);
+  if (dbg && lane == 0) { for (int q = 0; q < 10; ++q) dbg[q] = zts[q]; }
+  // ---------------- cost partial of this workgroup ----------------''')
+rep('// ---------------------------------------------------------------------------------------------------------\n// host side: plan','extern "C" int srmap_dbg_set_timing(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ztdbg), &buf, sizeof(buf)); }\n// ---------------------------------------------------------------------------------------------------------\n// host side: plan')
+open('/tmp/spx/kz_time.hip','w').write(s)

@@ -1,10 +1,12 @@
+"""cfg2 evaluation through the timing-only library of build.sh: mean cycles per wave and phase of k_eval_z
+(s_memtime, deferred stores).  Cycle counters of different XCDs are not synchronised: only per-wave differences are used."""
 import os, sys, time, ctypes
 import numpy as np, torch
 torch.cuda.init(); torch.zeros(1, device="cuda")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd", "python"))
 import srmap
-srmap.LIB_PATH = os.path.join(ROOT, "tmp_exp", "libsrmap_time.so")
+srmap.LIB_PATH = os.path.join(ROOT, "tools", "phase_clock", "libsrmap_time.so")
 W = 2048; s, K = 4, 16
 shifts = [[k % s, (k // s) % s] for k in range(K)]
 ctx = srmap.Context(0)
