@@ -885,8 +885,9 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (has_reg_halo) {
       T dacc[S];
       double dc = 0.0;
-      // the rows above a tile are never at the bottom edge; the right-edge masks follow the tile's
-      if (C0 + C::TW + C::WIN > A.W)
+      // right-edge masks follow the tile's; the rows above a tile reach below the image only when the tile keeps
+      // fewer than WIN rows of it (a partial bottom tile: found by tests/test_gpu_fuzz.py, H - R0 = 2 with BTV(3))
+      if (C0 + C::TW + C::WIN > A.W || R0 + C::WIN > A.H)
         reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, false);
       else
         reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, false);

@@ -59,6 +59,8 @@ CASES = [
     (16, 16, 1, 2, None, 3, 1.0),               # no MotionModule in the chain
     (28, 20, 1, 4, [[0.5, 0.25], [-1.3, 2.71], [0.01, -0.99], [3.0, -2.5]], 3, 1.0),  # sub-pixel
     (36, 30, 2, 3, [[0.75, -0.5], [1, 1]], 7, 2.0),
+    (146, 66, 1, 2, [[0, -6], [3, -1], [-2, 5], [6, 6]], 3, 0.94),  # bottom tile keeps 2 rows < BTV range: its halo rows need the bottom masks (fuzz find)
+    (130, 65, 1, 5, None, 0, 0.0),
 ]
 
 
