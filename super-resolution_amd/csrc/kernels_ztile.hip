@@ -59,10 +59,25 @@ static inline int pmod(int a, int b) { return a - fdiv(a, b) * b; }
 
 namespace {
 
+// Sum over the 64 lanes of a wave, result in EVERY lane.  DPP lane permutations (register-to-register: the
+// __shfl_down tree went through ds_bpermute, twelve dependent LDS round trips at the end of every workgroup's life)
+// inside the rows of 16 lanes, then the four row sums through v_readlane.  Fixed order: deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v += dpp_perm_d<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_perm_d<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_perm_d<0x141>(v);  // row_half_mirror
+  v += dpp_perm_d<0x140>(v);  // row_mirror: every lane holds the sum of its row of 16
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -129,6 +144,9 @@ struct ZArgs {
   const long long* off;  // [MS][S][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
   const ZEntry* aux;     // [MS][S][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
   int MS;                // slots per (row phase, column phase); tables are [MS][S][S] (round, row phase, column phase)
+  // the same by value (kernel-argument segment: always scalar loads, no table round trip before the first request):
+  int cntk[4][8];        //   cnt; [pr][S + 1] = min over the column phases (rounds below it need no per-pixel test)
+  long long off0[4][4];  //   round 0 of off
   const BorderArgs<T>* bd;  // device-resident constants of the border blocks
   int W, H, wl, hl;
   int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
@@ -141,6 +159,7 @@ struct ZArgs {
   T k1s[2];          // the separable factor (B^T z is evaluated as two 1-D passes): outer tap, centre tap
   T lambda;
   T powtab[NP];      // BTV alpha^(i+j)
+  T pwsum;           // BTV: sum of alpha^(i+j) over the gradient's (exclusive) window
 };
 
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
@@ -164,6 +183,10 @@ template <typename T>
 __device__ __forceinline__ T sgn_pre(T dq, T pw) { return __builtin_fmin(__builtin_fmax(dq, -pw), pw); }
 template <>
 __device__ __forceinline__ float sgn_pre<float>(float dq, float pw) { return __builtin_amdgcn_fmed3f(dq, -pw, pw); }
+// (sgn(d) + 1) / 2 of a pre-scaled difference: dq + 0.5 clamped to [0, 1] -- ONE instruction (v_add_f64 ... clamp):
+// 0 / 0.5 / 1 for d < 0 / d == 0 / d > 0 (|dq| >= 1 whenever d != 0)
+template <typename T>
+__device__ __forceinline__ T step_pre(T dq) { return __builtin_fmin(__builtin_fmax(dq + T(0.5), T(0)), T(1)); }
 
 // ---- index helpers: `col` is a pixel column relative to the first pixel of the thread's cell ----
 template <typename C>
@@ -215,7 +238,7 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
     // A uniform branch per pixel made each request wait for its own scalar load: six serialised round trips per row.
     long long offs[S];
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) offs[pc] = A.off[slot + pc];
+    for (int pc = 0; pc < S; ++pc) offs[pc] = (t == 0) ? A.off0[pr][pc] : A.off[slot + pc];  // t: uniform
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
@@ -277,8 +300,9 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
   const T unscale = Pre<T>::down(T(1));
   int cn[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
-  const int mmax = A.cnt[pr * 8 + S];
+  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
+  const int mmax = A.cntk[pr][S];
+  const int mfull = EDGE ? 0 : A.cntk[pr][S + 1];  // rounds in which every column phase owns a residual
   T z[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) z[v] = T(0);
@@ -289,6 +313,16 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
       for (int v = 0; v < NV; ++v) yv[v] = ypre[v];
     } else {
       load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ybase, cn, yv);
+    }
+    if (!EDGE && t < mfull) {  // uniform; the common case (K a multiple of S*S distinct phases): no per-pixel selects
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int pcv = v - HB;
+        const T rr = bx[v] * unscale - yv[v];
+        z[v] += rr;
+        if (pcv >= 0 && pcv < S && count) cost += (double)rr * (double)rr;
+      }
+      continue;
     }
     const size_t slot = (size_t)(t * S + pr) * S;
 #pragma unroll
@@ -380,8 +414,8 @@ __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int
   row_phase<S>(R0 + rowrel, rc, pr);
   int cn[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
-  const int mmax = A.cnt[pr * 8 + S];
+  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
+  const int mmax = A.cntk[pr][S];
   T z[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) z[v] = T(0);
@@ -413,7 +447,7 @@ __device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R
   row_phase<S>(R0 + rowrel, rc, pr);
   int cn[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cnt[pr * 8 + pc];
+  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
   if (edge) load_obs_row<T, S, C, true>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
   else load_obs_row<T, S, C, false>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
 }
@@ -424,7 +458,7 @@ __device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R
 template <typename T, int S, int REGK, int R, typename C, bool BORDER, bool FULL>
 __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __restrict__ xs, T* __restrict__ cs,
                                         const T (&wv)[S], int rowrel, int lane, int gr, int gc0, int W, int H,
-                                        T lambda, const T (&pw)[C::NP], bool cost_row) {
+                                        T lambda, const T (&pw)[C::NP], T pwsum, bool cost_row) {
   constexpr int WIN = C::WIN;
   constexpr int NC = S + WIN;
   const int xrow = rowrel + C::HU;
@@ -450,7 +484,10 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
           T d = x0v[pc] - row[pc + j];
           if (BORDER) d = ((gr + i < H) && (gc0 + pc + j < W)) ? d : T(0);  // skipped tap == zero difference
           rv[pc] += pw[i + j] * absv(d);
-          if (FULL && i < R && j < R) dv[pc] += sgn_pre<T>(d, pw[i + j]);  // exclusive window in the gradient
+          if (FULL && i < R && j < R) {  // exclusive window in the gradient
+            if (sizeof(T) == 8) dv[pc] += pw[i + j] * step_pre<T>(d);  // (sgn + 1) / 2: add with clamp + FMA, two f64 issues
+            else dv[pc] += sgn_pre<T>(d, pw[i + j]);
+          }
         }
       } else if (i == 1) {
         T dyv = row[pc] - x0v[pc];
@@ -472,6 +509,7 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
     T cr2 = T(2) * c * r;
     const bool in_img = (unsigned)gr < (unsigned)H && (unsigned)(gc0 + pc) < (unsigned)W;
     if (FULL) {
+      if (REGK == 2 && sizeof(T) == 8) dv[pc] = T(2) * dv[pc] - pwsum;  // sum pw * sgn = 2 * sum pw * (sgn + 1) / 2 - sum pw
       acc[pc] += cr2 * dv[pc];
       const double cd = (in_img && cost_row) ? (double)c * (double)r * (double)r : 0.0;
       cost += cd;
@@ -879,18 +917,18 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     const bool reg_border = (R0 + C::TH + C::WIN > A.H) || (C0 + C::TW + C::WIN > A.W);
     const bool cost_row = gr >= A.cr0 && gr < A.cr1;
     if (reg_border)
-      reg_row<T, S, REGK, R, C, true, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, cost_row);
+      reg_row<T, S, REGK, R, C, true, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
     else
-      reg_row<T, S, REGK, R, C, false, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, cost_row);
+      reg_row<T, S, REGK, R, C, false, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
     if (has_reg_halo) {
       T dacc[S];
       double dc = 0.0;
       // right-edge masks follow the tile's; the rows above a tile reach below the image only when the tile keeps
       // fewer than WIN rows of it (a partial bottom tile: found by tests/test_gpu_fuzz.py, H - R0 = 2 with BTV(3))
       if (C0 + C::TW + C::WIN > A.W || R0 + C::WIN > A.H)
-        reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, false);
+        reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
       else
-        reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, false);
+        reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
     }
     // left halo columns -1 .. -RU, one row per lane, one column per wave (a few-lane task with a
     // long dependent chain -- both columns on one wave made the whole workgroup wait for it at the barrier)
@@ -938,32 +976,23 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   }
 
   // ---------------- cost partial of this workgroup ----------------
-  if (WD) {
-    double gd = 0.0;
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) gd += (double)acc[pc] * (double)dreg[pc];
-    gd = wave_sum_d(gd);
-    if (lane == 0) red[0][wv] = gd;
-    __syncthreads();
-    if (tid == 0) {
-      double d = 0.0;
-#pragma unroll
-      for (int i = 0; i < C::NW; ++i) d += red[0][i];
-      A.partials_gd[((size_t)blockIdx.z * nby_t + by) * gridDim.x + blockIdx.x] = d;
-    }
-    __syncthreads();
-  }
   {
-    const double sd = wave_sum_d(cost_data);
-    const double sr = wave_sum_d(cost_reg);
-    if (lane == 0) { red[0][wv] = sd; red[1][wv] = sr; }
+    double gd = 0.0;
+    if (WD) {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) gd += (double)acc[pc] * (double)dreg[pc];
+      gd = wave_sum_d(gd);
+    }
+    const double cw = wave_sum_d((double)(S * S) * cost_data + cost_reg);
+    if (lane == 0) { red[0][wv] = cw; if (WD) red[1][wv] = gd; }
     __syncthreads();
     if (tid == 0) {
-      double d = 0.0, r = 0.0;
+      double c = 0.0, d = 0.0;
 #pragma unroll
-      for (int i = 0; i < C::NW; ++i) { d += red[0][i]; r += red[1][i]; }
+      for (int i = 0; i < C::NW; ++i) { c += red[0][i]; if (WD) d += red[1][i]; }
       const size_t b = ((size_t)blockIdx.z * nby_t + by) * gridDim.x + blockIdx.x;
-      A.partials[b] = (double)(S * S) * d + r;
+      A.partials[b] = c;
+      if (WD) A.partials_gd[b] = d;
     }
   }
 }
@@ -1037,6 +1066,8 @@ struct ZPlan {
   int n_ent = 0;
   int2* d_hdr = nullptr;       // flat table of k_border: (count, first entry) per phase
   ZEntry* d_ent = nullptr;
+  int h_cnt[32] = {0};         // host copies handed to the kernel by value: [4][8] counts (+ max, min over the column phases)
+  long long h_off0[16] = {0};  //   [4][4] round-0 offsets
   int* d_cnt = nullptr;        // tile kernel: [S][8]
   long long* d_off = nullptr;  //              [MS][S][S]
   ZEntry* d_aux = nullptr;     //              [MS][S][S]
@@ -1141,6 +1172,7 @@ bool ztile_plan(srmap_problem* p) {
       }
       cnt[(size_t)pr * 8 + S] = mx;
     }
+    for (size_t i = 0; i < cnt.size(); ++i) z->h_cnt[i] = cnt[i];
     bool ok = hipMalloc((void**)&z->d_cnt, sizeof(int) * cnt.size()) == hipSuccess &&
               hipMemcpy(z->d_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&z->d_aux, sizeof(ZEntry) * aux.size()) == hipSuccess &&
@@ -1204,7 +1236,12 @@ bool ztile_plan(srmap_problem* p) {
       }
     }
     cnt[(size_t)pr * 8 + S] = mx;
+    int mn = INT_MAX;
+    for (int pc = 0; pc < S; ++pc) mn = std::min(mn, cnt[(size_t)pr * 8 + pc]);
+    cnt[(size_t)pr * 8 + S + 1] = mn;
+    for (int pc = 0; pc < S; ++pc) z->h_off0[pr * 4 + pc] = off[((size_t)0 * S + pr) * S + pc];
   }
+  for (size_t i = 0; i < cnt.size(); ++i) z->h_cnt[i] = cnt[i];
   bool ok = hipMalloc((void**)&z->d_hdr, sizeof(int2) * hdr.size()) == hipSuccess &&
             hipMemcpy(z->d_hdr, hdr.data(), sizeof(int2) * hdr.size(), hipMemcpyHostToDevice) == hipSuccess &&
             hipMalloc((void**)&z->d_ent, sizeof(ZEntry) * ent.size()) == hipSuccess &&
@@ -1252,6 +1289,10 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
   A.dvec = dvec; A.partials_gd = partials_gd;
   A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
+  for (int pr = 0; pr < 4; ++pr) {
+    for (int i = 0; i < 8; ++i) A.cntk[pr][i] = z.h_cnt[pr * 8 + i];
+    for (int pc = 0; pc < 4; ++pc) A.off0[pr][pc] = z.h_off0[pr * 4 + pc];
+  }
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
   A.obs_C = p->geo.C;
   A.E = z.E;
@@ -1270,6 +1311,11 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     A.lambda = (T)rs.lambda;
     if (REGK == 2) for (int i = 0; i < C::NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
   }
+  A.pwsum = T(0);
+  if (REGK == 2)
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < R; ++j)
+        if (i + j > 0) A.pwsum += A.powtab[i + j];
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
   const int n_tile_partials = (int)(grid.x * grid.y * grid.z);
