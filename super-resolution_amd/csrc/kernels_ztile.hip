@@ -521,7 +521,8 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
 
 // 2*lambda*w*r of ONE pixel at tile-relative (rowrel (per lane), col (compile time, < 0)): the left halo columns.
 // xs / cs arrive already offset by the lane's row (rowrel * XROW / rowrel * CROW): every index below is an immediate.
-template <typename T, int S, int REGK, int R, typename C, int COL>
+// BORDER = false: the window stays inside the image (no per-tap masks).
+template <typename T, int S, int REGK, int R, typename C, int COL, bool BORDER>
 __device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __restrict__ cs, const T* __restrict__ wplane,
                                              int rowrel, int R0, int C0, int W, int H, T lambda,
                                              const T (&pw)[C::NP]) {
@@ -540,13 +541,13 @@ __device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __rest
         for (int j = 0; j <= WIN; ++j) {
           if (i == 0 && j == 0) continue;
           const T v = xs[xi<C>(xrow + i, COL + j)];
-          const T d = (gr + i < H && gc + j < W) ? x0 - v : T(0);
+          const T d = (!BORDER || (gr + i < H && gc + j < W)) ? x0 - v : T(0);
           r += pw[i + j] * absv(d);
         }
       }
     } else {
-      const T yv = (gr + 1 < H) ? absv(xs[xi<C>(xrow + 1, COL)] - x0) : T(0);
-      const T xv = (gc + 1 < W) ? absv(xs[xi<C>(xrow, COL + 1)] - x0) : T(0);
+      const T yv = (!BORDER || gr + 1 < H) ? absv(xs[xi<C>(xrow + 1, COL)] - x0) : T(0);
+      const T xv = (!BORDER || gc + 1 < W) ? absv(xs[xi<C>(xrow, COL + 1)] - x0) : T(0);
       r = yv + xv;
     }
     cr2 = T(2) * (lambda * wt) * Pre<T>::down(r);
@@ -878,6 +879,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   }
   __syncthreads();
 
+  const T* wcol = wplane;
   // in-image mask of this thread's pixels (partial tiles at the right / bottom edge)
   T mk[S];
 #pragma unroll
@@ -935,8 +937,13 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (reg_halo_on && (wv == 4 || wv == 5) && lane < C::TH + RU) {  // waves 4 / 5: their SIMDs carry the z halo rows only
       const int rowrel = lane - RU;
       const int lo = rowrel * C::XROW, lc = rowrel * C::CROW;  // per-lane row offsets
-      if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-      if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2>(xs + lo, cs + lc, wplane, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+      if (reg_border) {
+        if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+        if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+      } else {
+        if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+        if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+      }
     }
   }
   __syncthreads();

@@ -4,7 +4,9 @@ import sys
 root = sys.argv[1] if len(sys.argv) > 1 else "/root/repo"
 src=open(root + '/super-resolution_amd/csrc/kernels_ztile.hip').read()
 s=src
-s=s.replace('namespace {\n\n__device__ __forceinline__ double wave_sum_d','namespace {\n\n__device__ unsigned long long* g_ztdbg = nullptr;\n#define ZT_STAMP(i) do { zts[i] = __builtin_readcyclecounter(); } while (0)\n\n__device__ __forceinline__ double wave_sum_d',1)
+anchor = 'constexpr int floordiv(int a, int b)'
+assert anchor in s
+s=s.replace(anchor,'__device__ unsigned long long* g_ztdbg = nullptr;\n#define ZT_STAMP(i) do { zts[i] = __builtin_readcyclecounter(); } while (0)\n\n' + anchor,1)
 def rep(old,new):
     global s
     assert old in s, old
