@@ -147,6 +147,7 @@ struct ZArgs {
   // the same by value (kernel-argument segment: always scalar loads, no table round trip before the first request):
   int cntk[4][8];        //   cnt; [pr][S + 1] = min over the column phases (rounds below it need no per-pixel test)
   long long off0[4][4];  //   round 0 of off
+  ZEntry aux0[4][4];     //   round 0 of aux (edge tiles)
   const BorderArgs<T>* bd;  // device-resident constants of the border blocks
   int W, H, wl, hl;
   int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
@@ -251,7 +252,7 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
   // address clamped into the image (unused slots are frame 0, offset 0); validity is the consumer's business
   ZEntry ent[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) ent[pc] = A.aux[slot + pc];
+  for (int pc = 0; pc < S; ++pc) ent[pc] = (t == 0) ? A.aux0[pr][pc] : A.aux[slot + pc];  // t: uniform
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
@@ -336,7 +337,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
           z[v] += rr;
           if (own && count) cost += (double)rr * (double)rr;
         } else {
-          const ZEntry e = A.aux[slot + pc];
+          const ZEntry e = (t == 0) ? A.aux0[pr][pc] : A.aux[slot + pc];
           const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
           T bxv = bx[v];
           if (B > 1) {
@@ -642,29 +643,39 @@ __device__ __forceinline__ void ring_pixel(int t, int W, int H, int E, int& qr, 
 }
 
 // r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
-template <typename T>
-__device__ __forceinline__ T border_residual(const T* __restrict__ blur, int S, int b, int hb, int W, int H, int wl,
-                                             const T* __restrict__ xplane, const T* __restrict__ yk, int ox, int oy,
-                                             int i, int j) {
-  T acc = T(0);
-  for (int a = 0; a < b; ++a) {
+// S, B at compile time and the taps from the kernel arguments: the B * B loads of a residual are requested together
+// (with run-time loop bounds and a tap table in memory every tap was its own round trip: ~9 us per border block).
+template <typename T, int S, int B, typename ArgsT>
+__device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int wl, const T* __restrict__ xplane,
+                                             const T* __restrict__ yk, int ox, int oy, int i, int j) {
+  constexpr int hb = (B - 1) / 2;
+  T xv[B * B];
+  const T yv = yk[(size_t)i * wl + j];
+#pragma unroll
+  for (int a = 0; a < B; ++a) {
     const int rr = S * i + a - hb;
     const int sr = rr + oy;
     // filter2D BORDER_CONSTANT on the warped image, warpAffine BORDER_CONSTANT on the source
     const bool rok = rr >= 0 && rr < H && sr >= 0 && sr < H;
-    for (int e = 0; e < b; ++e) {
+#pragma unroll
+    for (int e = 0; e < B; ++e) {
       const int cc = S * j + e - hb;
       const int sc = cc + ox;
       const bool ok = rok && cc >= 0 && cc < W && sc >= 0 && sc < W;
       const T v = xplane[ok ? (size_t)sr * W + sc : (size_t)0];
-      acc += ok ? blur[a * b + e] * v : T(0);
+      xv[a * B + e] = ok ? v : T(0);
     }
   }
-  return acc - yk[(size_t)i * wl + j];
+  T acc = T(0);
+#pragma unroll
+  for (int a = 0; a < B; ++a)
+#pragma unroll
+    for (int e = 0; e < B; ++e) acc += blur_tap<B>(A, a, e) * xv[a * B + e];
+  return acc - yv;
 }
 
 // One border block of NT threads; smem: scratch of at least 16 int2 + kBorderTabEntries ZEntry + 8 doubles.
-template <typename T, int NT, bool WD, typename ArgsT>
+template <typename T, int S, int B, int NT, bool WD, typename ArgsT>
 __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>& Bd, int bidx, int ch, void* smem) {
   const int obs_C = Bd.obs_C;
   int2* s_hdr = reinterpret_cast<int2*>(smem);
@@ -674,14 +685,13 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
   const int t = bidx * NT + tid;
   const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
   // the frame table -> LDS (one global latency for the whole block instead of one per lookup)
-  if (tid < Bd.S * Bd.S) s_hdr[tid] = Bd.hdr[tid];
+  if (tid < S * S) s_hdr[tid] = Bd.hdr[tid];
   for (int i = tid; i < Bd.n_ent; i += NT) s_ent[i] = Bd.ent[i];
   __syncthreads();
   double cost = 0.0, gdc = 0.0;
   if (t < Bd.n_ring) {
     int qr, qc;
     ring_pixel(t, A.W, A.H, A.E, qr, qc);
-    const int S = Bd.S;
     const T* xplane = A.x + (size_t)ch * N;
     const T* ybase = A.y + (size_t)ch * nl;
     const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
@@ -696,15 +706,18 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
           if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
           if (S * i < A.cr0 || S * i >= A.cr1) continue;
           const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-          const double r = (double)border_residual<T>(Bd.blur_d, S, Bd.b, Bd.hb, A.W, A.H, A.wl, xplane,
-                                                      ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
+          const double r = (double)border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane,
+                                                            ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
           cost += r * r;
         }
       }
     } else if (A.g != nullptr && (A.terms & SRMAP_TERM_DATA)) {
-      for (int a = 0; a < Bd.b; ++a) {
-        for (int b2 = 0; b2 < Bd.b; ++b2) {
-          const int pr = qr + a - Bd.hb, pc = qc + b2 - Bd.hb;
+      constexpr int hb = (B - 1) / 2;
+#pragma unroll
+      for (int a = 0; a < B; ++a) {
+#pragma unroll
+        for (int b2 = 0; b2 < B; ++b2) {
+          const int pr = qr + a - hb, pc = qc + b2 - hb;
           const int rc = dfdiv(pr, S), cc = dfdiv(pc, S);
           const int2 h = s_hdr[(pr - rc * S) * S + (pc - cc * S)];
           for (int n = 0; n < h.x; ++n) {
@@ -715,9 +728,8 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
             const int i = rc + e.io, j = cc + e.jo;
             if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
             // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
-            corr += Bd.blur_d[b2 * Bd.b + a] *
-                    border_residual<T>(Bd.blur_d, S, Bd.b, Bd.hb, A.W, A.H, A.wl, xplane,
-                                       ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
+            corr += blur_tap<B>(A, b2, a) *
+                    border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
           }
         }
       }
@@ -739,7 +751,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
       double sum = 0.0;
       for (int i = 0; i < NT / 64; ++i) sum += red[i];
       const int nbb = A.nby * gridDim.x;
-      A.partials[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(Bd.S * Bd.S) * sum;
+      A.partials[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(S * S) * sum;
     }
     if (WD) {
       double w2 = gdc;
@@ -779,7 +791,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   if ((int)blockIdx.y < A.nby) {  // border blocks come first in dispatch order (uniform branch)
     const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
     const BorderArgs<T>& Bd = *A.bd;
-    if (bidx * C::NT < Bd.n_ring) border_block<T, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);
+    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);
     else if (threadIdx.x == 0) {
       const int nbb = A.nby * gridDim.x;
       A.partials[(size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
@@ -1014,11 +1026,22 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
                                                      double* tag_slot, double tag) {
   __shared__ double red[4];
   double v = 0.0, v2 = 0.0;
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n_partials; i += 256) {
-      v += partials[i];
-      if (partials_gd != nullptr) v2 += partials_gd[i];
+  if (blockIdx.x == 0) {
+    // eight requests in flight per thread (one load per iteration was one memory round trip per 256 partials);
+    // the order of the additions is fixed
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < n_partials; base += 256 * U) {
+      double a[U], b2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256;
+        a[u] = i < n_partials ? partials[i] : 0.0;
+        b2[u] = (partials_gd != nullptr && i < n_partials) ? partials_gd[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { v += a[u]; v2 += b2[u]; }
     }
+  }
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (g != nullptr && t < n_ring) {
     int qr, qc;
@@ -1075,6 +1098,7 @@ struct ZPlan {
   ZEntry* d_ent = nullptr;
   int h_cnt[32] = {0};         // host copies handed to the kernel by value: [4][8] counts (+ max, min over the column phases)
   long long h_off0[16] = {0};  //   [4][4] round-0 offsets
+  ZEntry h_aux0[16] = {};      //   [4][4] round-0 (frame, LR row / column offset) entries
   int* d_cnt = nullptr;        // tile kernel: [S][8]
   long long* d_off = nullptr;  //              [MS][S][S]
   ZEntry* d_aux = nullptr;     //              [MS][S][S]
@@ -1246,7 +1270,10 @@ bool ztile_plan(srmap_problem* p) {
     int mn = INT_MAX;
     for (int pc = 0; pc < S; ++pc) mn = std::min(mn, cnt[(size_t)pr * 8 + pc]);
     cnt[(size_t)pr * 8 + S + 1] = mn;
-    for (int pc = 0; pc < S; ++pc) z->h_off0[pr * 4 + pc] = off[((size_t)0 * S + pr) * S + pc];
+    for (int pc = 0; pc < S; ++pc) {
+      z->h_off0[pr * 4 + pc] = off[((size_t)0 * S + pr) * S + pc];
+      z->h_aux0[pr * 4 + pc] = aux[((size_t)0 * S + pr) * S + pc];
+    }
   }
   for (size_t i = 0; i < cnt.size(); ++i) z->h_cnt[i] = cnt[i];
   bool ok = hipMalloc((void**)&z->d_hdr, sizeof(int2) * hdr.size()) == hipSuccess &&
@@ -1298,7 +1325,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
   for (int pr = 0; pr < 4; ++pr) {
     for (int i = 0; i < 8; ++i) A.cntk[pr][i] = z.h_cnt[pr * 8 + i];
-    for (int pc = 0; pc < 4; ++pc) A.off0[pr][pc] = z.h_off0[pr * 4 + pc];
+    for (int pc = 0; pc < 4; ++pc) { A.off0[pr][pc] = z.h_off0[pr * 4 + pc]; A.aux0[pr][pc] = z.h_aux0[pr * 4 + pc]; }
   }
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
   A.obs_C = p->geo.C;
