@@ -651,19 +651,28 @@ __device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int w
   constexpr int hb = (B - 1) / 2;
   T xv[B * B];
   const T yv = yk[(size_t)i * wl + j];
+  // 32-bit element offsets inside the plane (the plan admits planes below 2^31 elements), column terms hoisted out of
+  // the row loop, every request at a valid address (masked afterwards)
+  int cix[B];
+  bool cok[B];
+#pragma unroll
+  for (int e = 0; e < B; ++e) {
+    const int cc = S * j + e - hb;
+    const int sc = cc + ox;
+    cok[e] = cc >= 0 && cc < W && sc >= 0 && sc < W;
+    cix[e] = cok[e] ? sc : 0;
+  }
 #pragma unroll
   for (int a = 0; a < B; ++a) {
     const int rr = S * i + a - hb;
     const int sr = rr + oy;
     // filter2D BORDER_CONSTANT on the warped image, warpAffine BORDER_CONSTANT on the source
     const bool rok = rr >= 0 && rr < H && sr >= 0 && sr < H;
+    const int rix = rok ? sr * W : 0;
 #pragma unroll
     for (int e = 0; e < B; ++e) {
-      const int cc = S * j + e - hb;
-      const int sc = cc + ox;
-      const bool ok = rok && cc >= 0 && cc < W && sc >= 0 && sc < W;
-      const T v = xplane[ok ? (size_t)sr * W + sc : (size_t)0];
-      xv[a * B + e] = ok ? v : T(0);
+      // mask as a multiply: a select on the loaded value lets the compiler sink each load under its own branch
+      xv[a * B + e] = xplane[(unsigned)(rix + cix[e])] * ((rok && cok[e]) ? T(1) : T(0));
     }
   }
   T acc = T(0);
@@ -1024,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
                                                      int n_partials, double* __restrict__ cost_out,
                                                      const double* __restrict__ partials_gd, double* pub,
                                                      double* tag_slot, double tag) {
-  __shared__ double red[4];
+  __shared__ double red[4], red2[4];
   double v = 0.0, v2 = 0.0;
   if (blockIdx.x == 0) {
     // eight requests in flight per thread (one load per iteration was one memory round trip per 256 partials);
@@ -1042,8 +1051,9 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
       for (int u = 0; u < U; ++u) { v += a[u]; v2 += b2[u]; }
     }
   }
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (g != nullptr && t < n_ring) {
+  // block 0 only reduces (its chain of dependent steps is the kernel's duration); the corrections start at block 1
+  const int t = ((int)blockIdx.x - 1) * 256 + (int)threadIdx.x;
+  if (g != nullptr && blockIdx.x > 0 && t < n_ring) {
     int qr, qc;
     ring_pixel(t, W, H, E, qr, qc);
     if (qr >= 0 && qr < H && qc >= 0 && qc < W) {
@@ -1054,20 +1064,15 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
     }
   }
   if (blockIdx.x == 0) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    v = wave_sum_d(v);
+    if (partials_gd != nullptr) v2 = wave_sum_d(v2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) red[wid] = v;
+    if (lane == 0) { red[wid] = v; red2[wid] = v2; }
     __syncthreads();
     if (threadIdx.x == 0) cost_out[0] = (red[0] + red[1]) + (red[2] + red[3]);
     if (partials_gd != nullptr) {  // g.d of the same evaluation (solver line search)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v2 += __shfl_down(v2, o, 64);
-      __syncthreads();
-      if (lane == 0) red[wid] = v2;
-      __syncthreads();
       if (threadIdx.x == 0) {
-        const double gd = (red[0] + red[1]) + (red[2] + red[3]);
+        const double gd = (red2[0] + red2[1]) + (red2[2] + red2[3]);
         cost_out[1] = gd;
         if (pub != nullptr) {  // solver line search: {cost, g.d} straight to the host-mapped words, then the arrival tag
           pub[0] = cost_out[0];
@@ -1153,6 +1158,7 @@ bool ztile_plan(srmap_problem* p) {
     }
   }
   if (amax > 4096) return false;
+  if ((long long)g.W * g.H >= (long long)INT_MAX) return false;  // the border blocks index a plane with 32 bits
   ZPlan* z = new ZPlan();
   z->S = S; z->B = B;
   z->E = amax;
@@ -1506,7 +1512,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   const bool corr_on = (terms & SRMAP_TERM_DATA) && z.E > 0 && g != nullptr;
   if (total <= 16384) {
     const int nring = corr_on ? z.n_ring : 0;
-    const unsigned nb_f = (unsigned)std::max(1, (nring + 255) / 256);
+    const unsigned nb_f = 1u + (unsigned)((nring + 255) / 256);
     hipLaunchKernelGGL(k_finish_eval<T>, dim3(nb_f), dim3(256), 0, st, corr_on ? g : (T*)nullptr, (const T*)z.d_corr,
                        z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, total, p->d_cost, (const double*)pgd,
                        with_d ? p->eval_pub : (double*)nullptr, p->eval_pub_tag_slot, p->eval_pub_tag);
@@ -1518,7 +1524,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   }
   // many partials (multi-channel problems): corrections here, two-stage reduction by the caller
   if (corr_on) {
-    hipLaunchKernelGGL(k_finish_eval<T>, dim3((unsigned)((z.n_ring + 255) / 256)), dim3(256), 0, st, g, (const T*)z.d_corr,
+    hipLaunchKernelGGL(k_finish_eval<T>, dim3(1u + (unsigned)((z.n_ring + 255) / 256)), dim3(256), 0, st, g, (const T*)z.d_corr,
                        z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, 0, p->d_cost + 1, (const double*)nullptr,
                        (double*)nullptr, (double*)nullptr, 0.0);
     SRMAP_HIP(p->ctx, hipGetLastError());
