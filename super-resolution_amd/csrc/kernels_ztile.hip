@@ -130,37 +130,41 @@ template <typename T> struct BorderArgs;
 
 template <typename T, int B, int NP>
 struct ZArgs {
+  // Field order = order of first use: what a workgroup needs before its first request shares the first cache lines of
+  // the argument block (each separately fetched line was a scalar-load round trip at the head of every workgroup).
   const T* x;
   const T* y;
   const T* w;        // IRLS weights or nullptr
   T* g;              // nullptr = cost only
-  double* partials;
-  const T* dvec;         // WD instances: search direction d; the kernel also produces partials of g.d
-  double* partials_gd;   //   (same indexing as partials)
-  const T* rbuf;         // SP instances (sub-pixel shifts): residuals r_k = A_k x - y_k, [K][C][h][w], from k_forward_direct
-  const double* spw;     //   bilinear tap weight of every table entry, [MS][S][S]
-  int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
-  const int* cnt;        // [S][8]  residuals per (row phase, column phase); [pr][S] = max over the column phases
-  const long long* off;  // [MS][S][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
-  const ZEntry* aux;     // [MS][S][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
+  int W, H, wl, hl;
+  int nby;           // grid rows (blockIdx.y) taken by border blocks; 0 = none
+  int E;             // max |shift| (edge tiles take the masked code path)
+  int terms;         // SRMAP_TERM_*
+  int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
+  // ---- 64 bytes ----
+  int cr0, cr1;      // HR rows whose cost terms are counted (row-band sharding; default 0, H)
+  int n_tile_partials;  // border partials are stored behind the tile partials
   int MS;                // slots per (row phase, column phase); tables are [MS][S][S] (round, row phase, column phase)
-  // the same by value (kernel-argument segment: always scalar loads, no table round trip before the first request):
+  // the frame table by value (kernel-argument segment: always scalar loads, no table round trip before the first request):
   int cntk[4][8];        //   cnt; [pr][S + 1] = min over the column phases (rounds below it need no per-pixel test)
   long long off0[4][4];  //   round 0 of off
-  ZEntry aux0[4][4];     //   round 0 of aux (edge tiles)
-  const BorderArgs<T>* bd;  // device-resident constants of the border blocks
-  int W, H, wl, hl;
-  int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
-  int E;             // max |shift| (edge tiles take the masked code path)
-  int cr0, cr1;      // HR rows whose cost terms are counted (row-band sharding; default 0, H)
-  int terms;         // SRMAP_TERM_*
-  int nby;           // grid rows (blockIdx.y) taken by border blocks; 0 = none
-  int n_tile_partials;  // border partials are stored behind the tile partials
   T blur3[3];        // k * k^T (blur_module.cpp:20-22) of the symmetric kernel: corner, edge, centre (B == 1: 1, 1, 1)
   T k1s[2];          // the separable factor (B^T z is evaluated as two 1-D passes): outer tap, centre tap
   T lambda;
   T powtab[NP];      // BTV alpha^(i+j)
   T pwsum;           // BTV: sum of alpha^(i+j) over the gradient's (exclusive) window
+  double* partials;
+  const T* dvec;         // WD instances: search direction d; the kernel also produces partials of g.d
+  double* partials_gd;   //   (same indexing as partials)
+  const BorderArgs<T>* bd;  // device-resident constants of the border blocks
+  // ---- edge tiles, later rounds, sub-pixel instances ----
+  ZEntry aux0[4][4];     // round 0 of aux (edge tiles)
+  const int* cnt;        // [S][8]  residuals per (row phase, column phase); [pr][S] = max over the column phases
+  const long long* off;  // [MS][S][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
+  const ZEntry* aux;     // [MS][S][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
+  const T* rbuf;         // SP instances (sub-pixel shifts): residuals r_k = A_k x - y_k, [K][C][h][w], from k_forward_direct
+  const double* spw;     //   bilinear tap weight of every table entry, [MS][S][S]
+  int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
 };
 
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
