@@ -203,6 +203,22 @@ __device__ __forceinline__ constexpr int ci(int row, int col) {
   return row * C::CROW + posmod(col, C::TW / C::CW) * C::CC + C::CCL + floordiv(col, C::TW / C::CW);
 }
 
+// Read-only tables (frame table rounds > 0, edge-tile entries, sub-pixel tap weights) are read through the CONSTANT
+// address space: a uniform load from it is a scalar load wherever it stands -- from a plain global pointer the
+// compiler demotes uniform loads to vector loads + v_readfirstlane once the kernel has stored anything.
+template <typename U>
+__device__ __forceinline__ U ctab(const U* p, size_t i) {
+  typedef const U __attribute__((address_space(4))) * CP;
+  return ((CP)(unsigned long long)p)[i];
+}
+__device__ __forceinline__ ZEntry ctab(const ZEntry* p, size_t i) {
+  typedef const int __attribute__((address_space(4))) * CP;
+  CP q = (CP)(unsigned long long)(p + i);
+  ZEntry e;
+  e.k = q[0]; e.io = q[1]; e.jo = q[2]; e.oyx = q[3];
+  return e;
+}
+
 // blur tap (a, e) of the symmetric B x B kernel from its three distinct values
 template <int B, typename ArgsT>
 __device__ __forceinline__ auto blur_tap(const ArgsT& A, int a, int e) {
@@ -243,7 +259,7 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
     // A uniform branch per pixel made each request wait for its own scalar load: six serialised round trips per row.
     long long offs[S];
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) offs[pc] = (t == 0) ? A.off0[pr][pc] : A.off[slot + pc];  // t: uniform
+    for (int pc = 0; pc < S; ++pc) offs[pc] = (t == 0) ? A.off0[pr][pc] : ctab(A.off, slot + pc);  // t: uniform
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
@@ -256,7 +272,7 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
   // address clamped into the image (unused slots are frame 0, offset 0); validity is the consumer's business
   ZEntry ent[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) ent[pc] = (t == 0) ? A.aux0[pr][pc] : A.aux[slot + pc];  // t: uniform
+  for (int pc = 0; pc < S; ++pc) ent[pc] = (t == 0) ? A.aux0[pr][pc] : ctab(A.aux, slot + pc);  // t: uniform
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
@@ -341,7 +357,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
           z[v] += rr;
           if (own && count) cost += (double)rr * (double)rr;
         } else {
-          const ZEntry e = (t == 0) ? A.aux0[pr][pc] : A.aux[slot + pc];
+          const ZEntry e = (t == 0) ? A.aux0[pr][pc] : ctab(A.aux, slot + pc);
           const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
           T bxv = bx[v];
           if (B > 1) {
@@ -399,13 +415,13 @@ __device__ __forceinline__ void sp_load_round(const ArgsT& A, int pr, int rc, in
     rv[v] = T(0);
     wm[v] = T(0);
     if (!EDGE || t < cn[pc]) {  // uniform
-      const ZEntry e = A.aux[slot + pc];
+      const ZEntry e = ctab(A.aux, (size_t)(slot + pc));
       const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
       if (!EDGE || (unsigned)i < (unsigned)A.hl) {  // uniform
         const int jc = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
         const T* plane = A.rbuf + (size_t)(e.k * A.obs_C + ch) * nl;
         rv[v] = plane[i * A.wl + jc];
-        wm[v] = ((unsigned)j < (unsigned)A.wl) ? (T)A.spw[slot + pc] : T(0);
+        wm[v] = ((unsigned)j < (unsigned)A.wl) ? (T)ctab(A.spw, (size_t)(slot + pc)) : T(0);
       }
     }
   }
