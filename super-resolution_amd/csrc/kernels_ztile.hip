@@ -403,7 +403,9 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
 // (padding entries carry weight 0 and a harmless in-range offset).  Columns: the address is clamped and the WEIGHT
 // masked per lane (nothing is done to the loaded value before the multiply-add, so a round's loads stay in flight
 // together).
-template <typename T, int S, typename C, bool EDGE, typename ArgsT>
+// COLCLAMP = false (with EDGE = false): tile columns whose table columns all stay inside the LR image -- the address
+// is a uniform base + the lane, the weight a scalar operand of the multiply-add (no per-lane index arithmetic at all).
+template <typename T, int S, typename C, bool EDGE, bool COLCLAMP, typename ArgsT>
 __device__ __forceinline__ void sp_load_round(const ArgsT& A, int pr, int rc, int t, int cell0, int lane, int ch,
                                               const int (&cn)[S], T (&rv)[C::NV], T (&wm)[C::NV]) {
   constexpr int HB = C::HB, NV = C::NV;
@@ -418,16 +420,22 @@ __device__ __forceinline__ void sp_load_round(const ArgsT& A, int pr, int rc, in
       const ZEntry e = ctab(A.aux, (size_t)(slot + pc));
       const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
       if (!EDGE || (unsigned)i < (unsigned)A.hl) {  // uniform
-        const int jc = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
         const T* plane = A.rbuf + (size_t)(e.k * A.obs_C + ch) * nl;
-        rv[v] = plane[i * A.wl + jc];
-        wm[v] = ((unsigned)j < (unsigned)A.wl) ? (T)ctab(A.spw, (size_t)(slot + pc)) : T(0);
+        if (!EDGE && !COLCLAMP) {
+          const T* rowp = plane + ((long long)i * A.wl + (cell0 + dc + e.jo));  // uniform
+          rv[v] = rowp[(unsigned)lane];
+          wm[v] = (T)ctab(A.spw, (size_t)(slot + pc));
+        } else {
+          const int jc = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
+          rv[v] = plane[i * A.wl + jc];
+          wm[v] = ((unsigned)j < (unsigned)A.wl) ? (T)ctab(A.spw, (size_t)(slot + pc)) : T(0);
+        }
       }
     }
   }
 }
 
-template <typename T, int S, int B, typename C, bool EDGE, typename ArgsT>
+template <typename T, int S, int B, typename C, bool EDGE, bool COLCLAMP, typename ArgsT>
 __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int rowrel, int R0, int cell0, int lane, int ch,
                                          T (&zout)[S]) {
   constexpr int HB = C::HB, NV = C::NV;
@@ -442,7 +450,7 @@ __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int
   for (int v = 0; v < NV; ++v) z[v] = T(0);
   for (int t = 0; t < mmax; ++t) {
     T rv[NV], wm[NV];
-    sp_load_round<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ch, cn, rv, wm);
+    sp_load_round<T, S, C, EDGE, COLCLAMP>(A, pr, rc, t, cell0, lane, ch, cn, rv, wm);
 #pragma unroll
     for (int v = 0; v < NV; ++v) z[v] += wm[v] * rv[v];
   }
@@ -936,12 +944,18 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     T dummy[S];
     // table rows reach (Dr + S) / S LR rows around the tile's own: only the top / bottom tile rows can leave the image
     const bool row_edge = (R0 - A.Dr - 2 * S < 0) || (R0 + C::TH + A.Dr + 2 * S > A.H);
+    // table columns reach Dr / S + 1 LR cells around a pixel's own (+ 1 for the neighbour pixels of the cell)
+    const int mj = A.Dr / S + 3;
+    const bool col_inner = (CJ0 - mj >= 0) && (CJ0 + C::CW + mj <= A.wl);
     if (row_edge) {
-      z_row_sp<T, S, B, C, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
-      if (has_z_halo) z_row_sp<T, S, B, C, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+      z_row_sp<T, S, B, C, true, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) z_row_sp<T, S, B, C, true, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+    } else if (!col_inner) {
+      z_row_sp<T, S, B, C, false, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) z_row_sp<T, S, B, C, false, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
     } else {
-      z_row_sp<T, S, B, C, false>(A, zs, wv, R0, CJ0, lane, ch, zown);
-      if (has_z_halo) z_row_sp<T, S, B, C, false>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+      z_row_sp<T, S, B, C, false, false>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) z_row_sp<T, S, B, C, false, false>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
     }
   }
   if (!SP && want_data) {
