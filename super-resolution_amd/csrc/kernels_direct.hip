@@ -155,16 +155,22 @@ int launch_forward_direct(srmap_problem* p, const Geometry& g, const T* x, const
 // form at every HR pixel: zero-insertion upsample (image_data.cpp:99-115),
 // correlation with kernel.t() (blur_module.cpp:30-36), warpAffine(-dx,-dy)
 // (motion_module.cpp:40-51); each stage clipped to the H x W domain.
-template <typename T>
+// SC: the scale at compile time (2, 3, 4; 0 = run time): the divisions / remainders by it in the tap loops are
+// shifts and multiplies instead of ~40-instruction sequences (the ring mode was bound by them).
+template <typename T, int SC>
 __global__ __launch_bounds__(256) void k_gather_direct(
     const T* __restrict__ resid, T* __restrict__ gout, Geometry g,
     const WarpTaps<T>* __restrict__ warps, const T* __restrict__ blur_t, int k0,
-    int nk, T out_scale, int accumulate, int ring) {
-  // ring mode: 64 pixels per block, the frames split over 4 thread groups (short dependent-load chains), combined
-  // through LDS in fixed order; full mode: one pixel per thread, all frames
+    int nk, T out_scale, int accumulate, int ring, int ring_groups) {
+  // ring mode: 256 / nfg pixels per block, the frames split over nfg thread groups (nfg = 16 for 16 frames and more:
+  // one or a few frames per thread -- every frame costs two dependent memory round trips, its warp record and its
+  // residuals, and with 4 groups a thread walked through 8 of them), combined through LDS in fixed order;
+  // full mode: one pixel per thread, all frames
+  const int gs = SC ? SC : g.s;
   __shared__ T part[256];
-  int hp = ring > 0 ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * 256 + threadIdx.x;
-  const int fg = ring > 0 ? (int)(threadIdx.x >> 6) : 0, nfg = ring > 0 ? 4 : 1;
+  const int nfg = ring > 0 ? ring_groups : 1, ppb = 256 / nfg;
+  int hp = ring > 0 ? blockIdx.x * ppb + ((int)threadIdx.x % ppb) : blockIdx.x * 256 + threadIdx.x;
+  const int fg = ring > 0 ? (int)threadIdx.x / ppb : 0;
   const int c = blockIdx.y;
   const int N = g.W * g.H, n = g.w * g.h;
   bool live = true;
@@ -200,18 +206,18 @@ __global__ __launch_bounds__(256) void k_gather_direct(
       if (pr < 0 || pr >= g.H || pc < 0 || pc >= g.W) continue;
       T v = T(0);
       // only the taps that land on the LR grid (every s-th), visited in the same increasing (a, e) order
-      int a0 = (g.hb - pr) % g.s, e0 = (g.hb - pc) % g.s;
-      if (a0 < 0) a0 += g.s;
-      if (e0 < 0) e0 += g.s;
-      for (int a = a0; a < g.b; a += g.s) {
+      int a0 = (g.hb - pr) % gs, e0 = (g.hb - pc) % gs;
+      if (a0 < 0) a0 += gs;
+      if (e0 < 0) e0 += gs;
+      for (int a = a0; a < g.b; a += gs) {
         const int R = pr + a - g.hb;
         if (R < 0 || R >= g.H) continue;
-        const int li = R / g.s;
+        const int li = R / gs;
         if (li >= g.h) continue;
-        for (int e = e0; e < g.b; e += g.s) {
+        for (int e = e0; e < g.b; e += gs) {
           const int Cc = pc + e - g.hb;
           if (Cc < 0 || Cc >= g.W) continue;
-          const int lj = Cc / g.s;
+          const int lj = Cc / gs;
           if (lj >= g.w) continue;
           v += blur_t[a * g.b + e] * rk[(size_t)li * g.w + lj];
         }
@@ -224,7 +230,8 @@ __global__ __launch_bounds__(256) void k_gather_direct(
     part[threadIdx.x] = acc;
     __syncthreads();
     if (fg != 0 || !live) return;
-    acc = ((part[threadIdx.x] + part[threadIdx.x + 64]) + part[threadIdx.x + 128]) + part[threadIdx.x + 192];
+    acc = part[threadIdx.x];
+    for (int q = 1; q < nfg; ++q) acc += part[threadIdx.x + q * ppb];
   }
   const size_t o = (size_t)c * N + hp;
   const T base = accumulate ? gout[o] : T(0);
@@ -241,10 +248,17 @@ int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, 
     if (2 * ring >= geo.H || 2 * ring >= geo.W) ring = 0;
     else npix = 2 * (size_t)ring * geo.W + 2 * (size_t)ring * (geo.H - 2 * ring);
   }
-  dim3 grid((unsigned)(ring > 0 ? (npix + 63) / 64 : (npix + 255) / 256), geo.C);
-  hipLaunchKernelGGL(k_gather_direct<T>, grid, dim3(256), 0, st, resid, g, geo,
-                     p->has_motion ? (const WarpTaps<T>*)p->d_bwd_warps : nullptr,
-                     (const T*)p->d_blur_t, k0, nk, (T)out_scale, accumulate ? 1 : 0, ring);
+  int groups = 1;
+  while (groups < 16 && groups < nk) groups *= 2;  // thread groups of the ring mode: a power of two, at most 16
+  const unsigned ppb = 256u / (unsigned)groups;
+  dim3 grid((unsigned)(ring > 0 ? (npix + ppb - 1) / ppb : (npix + 255) / 256), geo.C);
+  const WarpTaps<T>* wp = p->has_motion ? (const WarpTaps<T>*)p->d_bwd_warps : nullptr;
+  const T* bt = (const T*)p->d_blur_t;
+  const int acc1 = accumulate ? 1 : 0;
+  if (geo.s == 2) hipLaunchKernelGGL((k_gather_direct<T, 2>), grid, dim3(256), 0, st, resid, g, geo, wp, bt, k0, nk, (T)out_scale, acc1, ring, groups);
+  else if (geo.s == 3) hipLaunchKernelGGL((k_gather_direct<T, 3>), grid, dim3(256), 0, st, resid, g, geo, wp, bt, k0, nk, (T)out_scale, acc1, ring, groups);
+  else if (geo.s == 4) hipLaunchKernelGGL((k_gather_direct<T, 4>), grid, dim3(256), 0, st, resid, g, geo, wp, bt, k0, nk, (T)out_scale, acc1, ring, groups);
+  else hipLaunchKernelGGL((k_gather_direct<T, 0>), grid, dim3(256), 0, st, resid, g, geo, wp, bt, k0, nk, (T)out_scale, acc1, ring, groups);
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
 }
