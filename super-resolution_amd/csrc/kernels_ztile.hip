@@ -552,7 +552,7 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
 // xs / cs arrive already offset by the lane's row (rowrel * XROW / rowrel * CROW): every index below is an immediate.
 // BORDER = false: the window stays inside the image (no per-tap masks).
 template <typename T, int S, int REGK, int R, typename C, int COL, bool BORDER>
-__device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __restrict__ cs, const T* __restrict__ wplane,
+__device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __restrict__ cs, const T wt,
                                              int rowrel, int R0, int C0, int W, int H, T lambda,
                                              const T (&pw)[C::NP]) {
   constexpr int WIN = C::WIN;
@@ -560,7 +560,6 @@ __device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __rest
   constexpr int xrow = C::HU;
   T cr2 = T(0);
   if (gr >= 0 && gr < H && gc >= 0 && gc < W && !(REGK == 2 && gr == 0 && gc == 0)) {
-    const T wt = wplane ? wplane[(size_t)gr * W + gc] : T(1);
     const T x0 = xs[xi<C>(xrow, COL)];
     T r = T(0);
     if (REGK == 2) {
@@ -818,6 +817,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   __shared__ T zs[C::ZS_ELEMS > 0 ? C::ZS_ELEMS : 1];
   __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
   __shared__ double red[2][C::NW];
+  __shared__ T wcs[32];  // IRLS weights of the left-halo-column pixels (two columns x up to 16 rows)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -913,6 +913,16 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     for (int pc = 0; pc < S; ++pc) whalo[pc] = wplane[(size_t)(R0 + hrow) * A.W + gc0 + pc];
   }
 
+  // weight of the left-halo-column pixel this lane evaluates in phase 1 (waves 4 / 5, one row per lane): requested
+  // with the tile's other inputs and parked in LDS with the x tile -- a load inside the task stalled these two waves,
+  // and with them the workgroup's second barrier, for a memory round trip
+  T wcolv = T(1);
+  const bool col_task = reg_halo_on && (wv == 4 || wv == 5) && lane < C::TH + RU;
+  if (col_task && wplane != nullptr) {
+    const int hgr = R0 + lane - RU, hgc = C0 - (wv == 4 ? 1 : 2);
+    if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
+  }
+
   // ---------------- x tile -> LDS, polyphase ----------------
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
@@ -926,9 +936,9 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
       }
     }
   }
+  if (col_task) wcs[(wv - 4) * 16 + lane] = wcolv;
   __syncthreads();
 
-  const T* wcol = wplane;
   // in-image mask of this thread's pixels (partial tiles at the right / bottom edge)
   T mk[S];
 #pragma unroll
@@ -989,7 +999,8 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     }
     // left halo columns -1 .. -RU, one row per lane, one column per wave (a few-lane task with a
     // long dependent chain -- both columns on one wave made the whole workgroup wait for it at the barrier)
-    if (reg_halo_on && (wv == 4 || wv == 5) && lane < C::TH + RU) {  // waves 4 / 5: their SIMDs carry the z halo rows only
+    if (col_task) {  // waves 4 / 5: their SIMDs carry the z halo rows only
+      const T wcol = wcs[(wv - 4) * 16 + lane];
       const int rowrel = lane - RU;
       const int lo = rowrel * C::XROW, lc = rowrel * C::CROW;  // per-lane row offsets
       if (reg_border) {
