@@ -818,6 +818,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
   __shared__ double red[2][C::NW];
   __shared__ T wcs[32];  // IRLS weights of the left-halo-column pixels (two columns x up to 16 rows)
+  __shared__ T whs[(C::RU > 0 ? C::RU : 1) * S * C::CW];  // IRLS weights of the halo rows of 2*lambda*w*r
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -937,6 +938,10 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     }
   }
   if (col_task) wcs[(wv - 4) * 16 + lane] = wcolv;
+  if (has_reg_halo) {  // the halo row's weights wait in LDS too (eight registers less across the data term)
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) whs[((wv - 2) * S + pc) * C::CW + lane] = whalo[pc];
+  }
   __syncthreads();
 
   // in-image mask of this thread's pixels (partial tiles at the right / bottom edge)
@@ -990,12 +995,15 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (has_reg_halo) {
       T dacc[S];
       double dc = 0.0;
+      T whl[S];
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) whl[pc] = whs[((wv - 2) * S + pc) * C::CW + lane];
       // right-edge masks follow the tile's; the rows above a tile reach below the image only when the tile keeps
       // fewer than WIN rows of it (a partial bottom tile: found by tests/test_gpu_fuzz.py, H - R0 = 2 with BTV(3))
       if (C0 + C::TW + C::WIN > A.W || R0 + C::WIN > A.H)
-        reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
+        reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whl, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
       else
-        reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whalo, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
+        reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whl, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
     }
     // left halo columns -1 .. -RU, one row per lane, one column per wave (a few-lane task with a
     // long dependent chain -- both columns on one wave made the whole workgroup wait for it at the barrier)
