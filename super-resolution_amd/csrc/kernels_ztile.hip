@@ -842,7 +842,9 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   {
     const int n = blockIdx.x, q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
     tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
-    tbx = by;
+    // tile columns in the order first, last, second, ...: the masked edge columns (longest-lived tiles) are not the
+    // launch's last generation
+    tbx = (by == 0) ? 0 : (by == 1 ? nby_t - 1 : by - 1);
   }
   const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;
   const int ch = blockIdx.z;
