@@ -1,6 +1,7 @@
 // kernels_ztile.hip -- the hot path: one MAP gradient iteration
 // (ObjectiveFunction::ComputeAllTerms, objective_function.cpp:5-20) as ONE
-// LDS-tiled launch + a thin exact border launch, for the common geometry:
+// LDS-tiled launch (border blocks ride at the front of its grid) + the one-block
+// finish launch, for the common geometry:
 // integer motion shifts, HR = LR * S, S in {2,3,4}, blur size B in {1,3}, first
 // regulariser 2-D TV or BTV with range <= 3.  Everything else is evaluated by
 // kernels_direct.hip.
@@ -26,10 +27,11 @@
 //   (c) LR pixels exist only inside the LR image                -> validity mask (EDGE);
 //   (d) the transpose warp clips its SOURCE: frame k contributes to output pixel q
 //       only if q - o_k is inside the image.  That depends on (q, k), so it cannot
-//       be folded into the frame-summed z: the tile kernel adds every frame and
-//       k_border subtracts the excluded contributions for the pixels within
-//       E = max|shift| of the image edge; k_border also adds the cost of the
-//       residuals whose z position lies outside the image (they have no owner).
+//       be folded into the frame-summed z: the tiles add every frame and the
+//       border blocks collect the excluded contributions for the pixels within
+//       E = max|shift| of the image edge (k_finish_eval subtracts them), and the
+//       cost of the residuals whose z position lies outside the image (they have
+//       no owner).
 //
 // Tile kernel k_eval_z: a workgroup of 8 waves owns 8 HR rows x 64*S columns;
 // wave = HR row, lane = LR cell, a thread owns the S consecutive pixels of its
@@ -39,8 +41,11 @@
 //            the matching frames (host-built table per (row phase, col phase)),
 //            horizontal half of B^T in registers -> zh to LDS; regulariser
 //            pass 1 (values, self term, 2*lambda*w*r -> LDS); halo rows of zh /
-//            2*lambda*w*r by whole waves, the left halo columns by one wave;
+//            2*lambda*w*r by whole waves (0-1 / 2-3), the left halo columns one per
+//            wave (4 / 5, lanes = rows); their IRLS weights wait in LDS;
 //   phase 2  vertical half of B^T from zh; regulariser pass 2; g store.
+// The frame table's counts and round 0 travel by value in the kernel arguments
+// (scalar loads only); later rounds are read through the constant address space.
 // No MFMA: stencil path.  Cost partials are reduced in fixed order
 // (deterministic).
 #include <algorithm>
