@@ -57,9 +57,13 @@ enum {
   SRMAP_TERM_ALL = 3u
 };
 
-/* Kernel family selection (for tests and A/B measurements; AUTO picks the
- * LDS-tiled kernels whenever the problem geometry admits them). */
-typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2 } srmap_impl;
+/* Kernel family selection (for tests and A/B measurements).  AUTO picks the
+ * fastest family the problem geometry admits: the single-launch marching-wave
+ * kernel (integer shifts, scale 2..4, blur size 1 or 3), the workgroup-tile
+ * kernels (the same geometries plus sub-pixel shifts), else the direct kernels.
+ * TILED / MARCH force one family and fail with SRMAP_EUNSUPPORTED when it does
+ * not cover the problem. */
+typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */
 /* Binds HIP device `device_id`.  Replaces nothing in the reference (it has no

@@ -48,768 +48,13 @@
 // (scalar loads only); later rounds are read through the constant address space.
 // No MFMA: stencil path.  Cost partials are reduced in fixed order
 // (deterministic).
-#include <algorithm>
-#include <climits>
-#include <cmath>
-#include <cstdlib>
-#include <vector>
 
-#include "srmap_internal.hpp"
+
+#include "ztile_dev.hpp"
 
 namespace srmap {
 
-// integer floor division / modulo on the host
-static inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
-static inline int pmod(int a, int b) { return a - fdiv(a, b) * b; }
-
 namespace {
-
-// Sum over the 64 lanes of a wave, result in EVERY lane.  DPP lane permutations (register-to-register: the
-// __shfl_down tree went through ds_bpermute, twelve dependent LDS round trips at the end of every workgroup's life)
-// inside the rows of 16 lanes, then the four row sums through v_readlane.  Fixed order: deterministic.
-template <int CTRL>
-__device__ __forceinline__ double dpp_perm_d(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_d(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-  v += dpp_perm_d<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_perm_d<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_perm_d<0x141>(v);  // row_half_mirror
-  v += dpp_perm_d<0x140>(v);  // row_mirror: every lane holds the sum of its row of 16
-  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
-}
-
-constexpr int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
-constexpr int posmod(int a, int b) { return a - floordiv(a, b) * b; }
-
-template <typename T>
-__device__ __forceinline__ T absv(T d) { return d < T(0) ? -d : d; }
-template <>
-__device__ __forceinline__ float absv<float>(float d) { return __builtin_fabsf(d); }
-template <>
-__device__ __forceinline__ double absv<double>(double d) { return __builtin_fabs(d); }
-
-constexpr int zmax(int a, int b) { return a > b ? a : b; }
-constexpr int zceil(int a, int b) { return (a + b - 1) / b; }
-
-template <typename T, int S, int B, int REGK, int R>
-struct ZCfg {
-  static constexpr int NW = 8;                 // waves = HR rows per tile
-  static constexpr int NT = 64 * NW;
-  static constexpr int TH = NW;
-  static constexpr int CW = 64;                // LR cells per tile row = lanes
-  static constexpr int TW = CW * S;
-  static constexpr int HB = (B - 1) / 2;
-  static constexpr int WIN = REGK == 2 ? R : (REGK == 1 ? 1 : 0);      // pass 1 reaches WIN pixels right / down
-  static constexpr int RU = REGK == 2 ? R - 1 : (REGK == 1 ? 1 : 0);   // pass 2 reaches RU pixels up / left
-  static constexpr int HU = zmax(RU, 2 * HB);  // x halo rows above / below the tile
-  static constexpr int HD = zmax(WIN, 2 * HB);
-  static constexpr int XCL = zceil(zmax(RU, 2 * HB), S);   // x halo cells left / right
-  static constexpr int XCR = zceil(zmax(WIN, 2 * HB), S);
-  static constexpr int XC = CW + XCL + XCR;
-  static constexpr int XR = TH + HU + HD;
-  static constexpr int XROW = S * XC;
-  static constexpr int XS_ELEMS = XR * XROW;
-  static constexpr int NV = S + 2 * HB;        // pixels a thread evaluates B x / z at: own S + HB each side
-  static constexpr int ZR = (B > 1) ? TH + 2 * HB : 0;     // zh rows -HB .. TH-1+HB (own columns only)
-  static constexpr int ZROW = S * CW;
-  static constexpr int ZS_ELEMS = ZR * ZROW;
-  static constexpr int CCL = RU > 0 ? zceil(RU, S) : 0;    // 2*lambda*w*r: halo cells on the left
-  static constexpr int CC = CW + CCL;
-  static constexpr int CROW = S * CC;
-  static constexpr int CRR = REGK ? TH + RU : 0;
-  static constexpr int CS_ELEMS = CRR * CROW;
-  static constexpr int NP = REGK == 2 ? 2 * R + 1 : 1;
-};
-
-struct ZEntry { int k, io, jo, oyx; };  // frame, LR row / column offset of the residual a pixel of this phase owns,
-                                         // forward offset packed (oy << 16) | (ox & 0xffff)
-
-template <typename T> struct BorderArgs;
-
-template <typename T, int B, int NP>
-struct ZArgs {
-  // Field order = order of first use: what a workgroup needs before its first request shares the first cache lines of
-  // the argument block (each separately fetched line was a scalar-load round trip at the head of every workgroup).
-  const T* x;
-  const T* y;
-  const T* w;        // IRLS weights or nullptr
-  T* g;              // nullptr = cost only
-  int W, H, wl, hl;
-  int nby;           // grid rows (blockIdx.y) taken by border blocks; 0 = none
-  int E;             // max |shift| (edge tiles take the masked code path)
-  int terms;         // SRMAP_TERM_*
-  int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
-  // ---- 64 bytes ----
-  int cr0, cr1;      // HR rows whose cost terms are counted (row-band sharding; default 0, H)
-  int n_tile_partials;  // border partials are stored behind the tile partials
-  int MS;                // slots per (row phase, column phase); tables are [MS][S][S] (round, row phase, column phase)
-  // the frame table by value (kernel-argument segment: always scalar loads, no table round trip before the first request):
-  int cntk[4][8];        //   cnt; [pr][S + 1] = min over the column phases (rounds below it need no per-pixel test)
-  long long off0[4][4];  //   round 0 of off
-  T blur3[3];        // k * k^T (blur_module.cpp:20-22) of the symmetric kernel: corner, edge, centre (B == 1: 1, 1, 1)
-  T k1s[2];          // the separable factor (B^T z is evaluated as two 1-D passes): outer tap, centre tap
-  T lambda;
-  T powtab[NP];      // BTV alpha^(i+j)
-  T pwsum;           // BTV: sum of alpha^(i+j) over the gradient's (exclusive) window
-  double* partials;
-  const T* dvec;         // WD instances: search direction d; the kernel also produces partials of g.d
-  double* partials_gd;   //   (same indexing as partials)
-  const BorderArgs<T>* bd;  // device-resident constants of the border blocks
-  // ---- edge tiles, later rounds, sub-pixel instances ----
-  ZEntry aux0[4][4];     // round 0 of aux (edge tiles)
-  const int* cnt;        // [S][8]  residuals per (row phase, column phase); [pr][S] = max over the column phases
-  const long long* off;  // [MS][S][S] element offset of the observation relative to (channel plane + LR cell row * w + cell)
-  const ZEntry* aux;     // [MS][S][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
-  const T* rbuf;         // SP instances (sub-pixel shifts): residuals r_k = A_k x - y_k, [K][C][h][w], from k_forward_direct
-  const double* spw;     //   bilinear tap weight of every table entry, [MS][S][S]
-  int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
-};
-
-// The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
-// true difference times 2^Q, large enough that sgn(d) * pw is just a clamp to [-pw, pw] (no ldexp per tap), and
-// the scale drops out of the sums exactly (r = r' * 2^-Q, B x = (B x') * 2^-Q).  Exact for |d| >= 2^-Q and pixel
-// magnitudes below 2^(Emax - Q - 3): Q = 1000 (f64), 100 (f32).
-template <typename T> struct Pre;
-template <> struct Pre<double> {
-  static constexpr int Q = 1000;
-  static __device__ __forceinline__ double up(double v) { return __builtin_ldexp(v, Q); }
-  static __device__ __forceinline__ double down(double v) { return __builtin_ldexp(v, -Q); }
-};
-template <> struct Pre<float> {
-  static constexpr int Q = 100;
-  static __device__ __forceinline__ float up(float v) { return __builtin_ldexpf(v, Q); }
-  static __device__ __forceinline__ float down(float v) { return __builtin_ldexpf(v, -Q); }
-};
-// sgn(d) * pw for a pre-scaled difference dq = d * 2^Q: clamp (pw <= 1 << 2^Q * |d| for every d the reference
-// distinguishes from 0).
-template <typename T>
-__device__ __forceinline__ T sgn_pre(T dq, T pw) { return __builtin_fmin(__builtin_fmax(dq, -pw), pw); }
-template <>
-__device__ __forceinline__ float sgn_pre<float>(float dq, float pw) { return __builtin_amdgcn_fmed3f(dq, -pw, pw); }
-// (sgn(d) + 1) / 2 of a pre-scaled difference: dq + 0.5 clamped to [0, 1] -- ONE instruction (v_add_f64 ... clamp):
-// 0 / 0.5 / 1 for d < 0 / d == 0 / d > 0 (|dq| >= 1 whenever d != 0)
-template <typename T>
-__device__ __forceinline__ T step_pre(T dq) { return __builtin_fmin(__builtin_fmax(dq + T(0.5), T(0)), T(1)); }
-
-// ---- index helpers: `col` is a pixel column relative to the first pixel of the thread's cell ----
-template <typename C>
-__device__ __forceinline__ constexpr int xi(int row, int col) {
-  return row * C::XROW + posmod(col, C::TW / C::CW) * C::XC + C::XCL + floordiv(col, C::TW / C::CW);
-}
-template <typename C>
-__device__ __forceinline__ constexpr int ci(int row, int col) {
-  return row * C::CROW + posmod(col, C::TW / C::CW) * C::CC + C::CCL + floordiv(col, C::TW / C::CW);
-}
-
-// Read-only tables (frame table rounds > 0, edge-tile entries, sub-pixel tap weights) are read through the CONSTANT
-// address space: a uniform load from it is a scalar load wherever it stands -- from a plain global pointer the
-// compiler demotes uniform loads to vector loads + v_readfirstlane once the kernel has stored anything.
-template <typename U>
-__device__ __forceinline__ U ctab(const U* p, size_t i) {
-  typedef const U __attribute__((address_space(4))) * CP;
-  return ((CP)(unsigned long long)p)[i];
-}
-__device__ __forceinline__ ZEntry ctab(const ZEntry* p, size_t i) {
-  typedef const int __attribute__((address_space(4))) * CP;
-  CP q = (CP)(unsigned long long)(p + i);
-  ZEntry e;
-  e.k = q[0]; e.io = q[1]; e.jo = q[2]; e.oyx = q[3];
-  return e;
-}
-
-// blur tap (a, e) of the symmetric B x B kernel from its three distinct values
-template <int B, typename ArgsT>
-__device__ __forceinline__ auto blur_tap(const ArgsT& A, int a, int e) {
-  if (B == 1) return A.blur3[2];
-  const bool ca = a == (B - 1) / 2, ce = e == (B - 1) / 2;
-  return (ca && ce) ? A.blur3[2] : ((ca || ce) ? A.blur3[1] : A.blur3[0]);
-}
-template <int B, typename ArgsT>
-__device__ __forceinline__ auto k1_tap(const ArgsT& A, int a) { return (B == 1 || a == (B - 1) / 2) ? A.k1s[1] : A.k1s[0]; }
-
-// Observation of LR pixel (i, j) of frame plane yk, address clamped into the image.
-template <typename T>
-__device__ __forceinline__ T obs_at(const T* __restrict__ yk, int i, int j, int hl, int wl) {
-  const int ic = i < 0 ? 0 : (i >= hl ? hl - 1 : i);
-  const int jc = j < 0 ? 0 : (j >= wl ? wl - 1 : j);
-  return yk[(size_t)ic * wl + jc];
-}
-
-// Row phase / LR cell row of HR row gr (floor division; gr may be negative in the top halo).
-template <int S>
-__device__ __forceinline__ void row_phase(int gr, int& rc, int& pr) {
-  rc = (gr >= 0) ? gr / S : -((-gr + S - 1) / S);
-  pr = gr - rc * S;
-}
-
-// Observations of the t-th residual of each of the NV pixels of the thread's cell in an HR row of phase pr
-// (frame table: SURVEY.md section 8a' restated per HR pixel).  Interior tiles: one scalar offset per pixel phase,
-// address = row base + offset + cell.  EDGE: explicit (frame, LR row, LR column), clamped into the image.
-template <typename T, int S, typename C, bool EDGE, typename ArgsT>
-__device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int t, int cell0, int lane,
-                                             const T* __restrict__ ybase, const int (&cn)[S], T (&yv)[C::NV]) {
-  constexpr int HB = C::HB, NV = C::NV;
-  const size_t slot = (size_t)(t * S + pr) * S;  // uniform; round-major: round 0 (the prefetch) needs no table size
-  const T* yrow = ybase + ((long long)rc * A.wl + cell0);  // uniform: LR cell row rc, first cell of the tile
-  if (!EDGE) {
-    // branch-free: the S offsets of this table row come as ONE scalar load and every pixel's observation is
-    // requested (unused slots hold offset 0 = a valid element of this LR row; their values are never consumed).
-    // A uniform branch per pixel made each request wait for its own scalar load: six serialised round trips per row.
-    long long offs[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) offs[pc] = (t == 0) ? A.off0[pr][pc] : ctab(A.off, slot + pc);  // t: uniform
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-      const T* yp = yrow + (offs[pc] + dc);  // uniform pointer; the lane adds its (non-negative) cell index
-      yv[v] = yp[(unsigned)lane];
-    }
-    return;
-  }
-  // EDGE: the same without branches -- (frame, LR row, LR column) entries of the table row in one scalar load, every
-  // address clamped into the image (unused slots are frame 0, offset 0); validity is the consumer's business
-  ZEntry ent[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) ent[pc] = (t == 0) ? A.aux0[pr][pc] : ctab(A.aux, slot + pc);  // t: uniform
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-    const ZEntry e = ent[pc];
-    yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
-  }
-  (void)cn;
-}
-
-// ---- data term, phase 1, for the S pixels of one cell in tile row `rowrel` (wave-uniform) ----
-// B x at NV pixels, residuals of the frames whose LR grid hits each pixel, z; returns z (B == 1) or writes the
-// horizontal half of B^T z to LDS (B == 3).  `count`: the row is owned by this tile (cost is counted).
-// EDGE: tiles near the image border (and partial tiles) -- LR validity masks, in-image masks and the dropped blur
-// taps of LR row 0 / column 0.  The staged x is pre-scaled by 2^Q: residual = (B x') * 2^-Q - y.
-template <typename T, int S, int B, typename C, bool EDGE, typename ArgsT>
-__device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ zs, int rowrel,
-                                      int R0, int cell0, int lane, const T* __restrict__ ybase, bool use_pre,
-                                      const T (&ypre)[C::NV], bool count, const T (&mk)[S], T (&zout)[S],
-                                      double& cost) {
-  constexpr int HB = C::HB, NV = C::NV;
-  int rc, pr;
-  row_phase<S>(R0 + rowrel, rc, pr);
-  const int xrow = rowrel + C::HU;
-  T bx[NV], btop[NV], bleft[NV], bcorner[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) { bx[v] = T(0); btop[v] = T(0); bleft[v] = T(0); bcorner[v] = T(0); }
-#pragma unroll
-  for (int a = 0; a < B; ++a) {
-    T xr[NV + B - 1];
-#pragma unroll
-    for (int j = 0; j < NV + B - 1; ++j) xr[j] = xs[xi<C>(xrow + a - HB, j - 2 * HB) + lane];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-#pragma unroll
-      for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, a, e) * xr[v + e];
-      if (EDGE && B > 1) {
-        bleft[v] += blur_tap<B>(A, a, 0) * xr[v];  // tap column 0
-        if (a == 0) {
-#pragma unroll
-          for (int e = 0; e < B; ++e) btop[v] += blur_tap<B>(A, 0, e) * xr[v + e];  // tap row 0
-          bcorner[v] = blur_tap<B>(A, 0, 0) * xr[v];
-        }
-      }
-    }
-  }
-  const T unscale = Pre<T>::down(T(1));
-  int cn[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-  const int mmax = A.cntk[pr][S];
-  const int mfull = EDGE ? 0 : A.cntk[pr][S + 1];  // rounds in which every column phase owns a residual
-  T z[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) z[v] = T(0);
-  for (int t = 0; t < mmax; ++t) {
-    T yv[NV];
-    if (t == 0 && use_pre) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) yv[v] = ypre[v];
-    } else {
-      load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ybase, cn, yv);
-    }
-    if (!EDGE && t < mfull) {  // uniform; the common case (K a multiple of S*S distinct phases): no per-pixel selects
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int pcv = v - HB;
-        const T rr = bx[v] * unscale - yv[v];
-        z[v] += rr;
-        if (pcv >= 0 && pcv < S && count) cost += (double)rr * (double)rr;
-      }
-      continue;
-    }
-    const size_t slot = (size_t)(t * S + pr) * S;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-      const bool own = pcv >= 0 && pcv < S;
-      if (t < cn[pc]) {  // uniform
-        T rr;
-        if (!EDGE) {
-          rr = bx[v] * unscale - yv[v];
-          z[v] += rr;
-          if (own && count) cost += (double)rr * (double)rr;
-        } else {
-          const ZEntry e = (t == 0) ? A.aux0[pr][pc] : ctab(A.aux, slot + pc);
-          const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
-          T bxv = bx[v];
-          if (B > 1) {
-            // filter2D's zero padding acts on the warped image: LR row 0 loses blur tap row 0, LR column 0 tap column 0
-            const bool j0 = j == 0;
-            if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
-            else bxv = bxv - (j0 ? bleft[v] : T(0));
-          }
-          rr = bxv * unscale - yv[v];
-          // no such LR pixel (row: uniform, column: per lane)
-          rr = ((unsigned)i < (unsigned)A.hl && (unsigned)j < (unsigned)A.wl) ? rr : T(0);
-          z[v] += rr;
-          if (own && count && S * i >= A.cr0 && S * i < A.cr1) {
-            const double rd = (double)(rr * mk[own ? pcv : 0]);
-            cost += rd * (double)rr;
-          }
-        }
-      }
-    }
-  }
-  if (B == 1) {
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) zout[pc] = z[pc];
-  } else {
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      T zh = T(0);
-#pragma unroll
-      for (int e = 0; e < B; ++e) zh += k1_tap<B>(A, e) * z[pc + e];
-      zs[(rowrel + HB) * C::ZROW + pc * C::CW + lane] = zh;
-    }
-  }
-}
-
-// ---- data term, phase 1, SUB-PIXEL shifts ----
-// The transpose warp of a sub-pixel shift is a 4-tap bilinear gather (motion_module.cpp:40-51: warpAffine with the
-// negated shift); in the interior it commutes with B^T like the integer shift does, so
-//     z(p) = sum_k sum_b w'_{k,b} [ (p + o'_k + tap_b) on the LR grid ] r_k((p + o'_k + tap_b) / S),   g_data = 2 S^2 B^T z.
-// The residuals come from k_forward_direct (exact 4-tap forward warp, every clip); which (frame, tap) pairs hit a
-// pixel depends only on its phase: host-built table (frame, LR row / column offset, weight).  No cost here (the
-// forward kernel counts it); the pixels within Dr of the edge are evaluated by the exact ring pass instead.
-// EDGE = false: tiles whose table rows all stay inside the LR image -- no uniform branches, one table row per round
-// (padding entries carry weight 0 and a harmless in-range offset).  Columns: the address is clamped and the WEIGHT
-// masked per lane (nothing is done to the loaded value before the multiply-add, so a round's loads stay in flight
-// together).
-// COLCLAMP = false (with EDGE = false): tile columns whose table columns all stay inside the LR image -- the address
-// is a uniform base + the lane, the weight a scalar operand of the multiply-add (no per-lane index arithmetic at all).
-template <typename T, int S, typename C, bool EDGE, bool COLCLAMP, typename ArgsT>
-__device__ __forceinline__ void sp_load_round(const ArgsT& A, int pr, int rc, int t, int cell0, int lane, int ch,
-                                              const int (&cn)[S], T (&rv)[C::NV], T (&wm)[C::NV]) {
-  constexpr int HB = C::HB, NV = C::NV;
-  const size_t nl = (size_t)A.wl * A.hl;
-  const int slot = (t * S + pr) * S;
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-    rv[v] = T(0);
-    wm[v] = T(0);
-    if (!EDGE || t < cn[pc]) {  // uniform
-      const ZEntry e = ctab(A.aux, (size_t)(slot + pc));
-      const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
-      if (!EDGE || (unsigned)i < (unsigned)A.hl) {  // uniform
-        const T* plane = A.rbuf + (size_t)(e.k * A.obs_C + ch) * nl;
-        if (!EDGE && !COLCLAMP) {
-          const T* rowp = plane + ((long long)i * A.wl + (cell0 + dc + e.jo));  // uniform
-          rv[v] = rowp[(unsigned)lane];
-          wm[v] = (T)ctab(A.spw, (size_t)(slot + pc));
-        } else {
-          const int jc = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
-          rv[v] = plane[i * A.wl + jc];
-          wm[v] = ((unsigned)j < (unsigned)A.wl) ? (T)ctab(A.spw, (size_t)(slot + pc)) : T(0);
-        }
-      }
-    }
-  }
-}
-
-template <typename T, int S, int B, typename C, bool EDGE, bool COLCLAMP, typename ArgsT>
-__device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int rowrel, int R0, int cell0, int lane, int ch,
-                                         T (&zout)[S]) {
-  constexpr int HB = C::HB, NV = C::NV;
-  int rc, pr;
-  row_phase<S>(R0 + rowrel, rc, pr);
-  int cn[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-  const int mmax = A.cntk[pr][S];
-  T z[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) z[v] = T(0);
-  for (int t = 0; t < mmax; ++t) {
-    T rv[NV], wm[NV];
-    sp_load_round<T, S, C, EDGE, COLCLAMP>(A, pr, rc, t, cell0, lane, ch, cn, rv, wm);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) z[v] += wm[v] * rv[v];
-  }
-  if (B == 1) {
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) zout[pc] = z[pc];
-  } else {
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      T zh = T(0);
-#pragma unroll
-      for (int e = 0; e < B; ++e) zh += k1_tap<B>(A, e) * z[pc + e];
-      zs[(rowrel + HB) * C::ZROW + pc * C::CW + lane] = zh;
-    }
-  }
-}
-
-// t = 0 observations of the NV pixels of the thread's cell in tile row `rowrel`, issued at kernel start.
-template <typename T, int S, int B, typename C, typename ArgsT>
-__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cell0, int lane, bool edge,
-                                               const T* __restrict__ ybase, T (&ypre)[C::NV]) {
-  int rc, pr;
-  row_phase<S>(R0 + rowrel, rc, pr);
-  int cn[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-  if (edge) load_obs_row<T, S, C, true>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
-  else load_obs_row<T, S, C, false>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
-}
-
-// ---- regulariser pass 1 for the S pixels of one cell (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
-// FULL: values, self term into acc, cost, 2*lambda*w*r into cs (own rows).  !FULL: 2*lambda*w*r only (halo rows).
-// Stores 0 for pixels outside the image and, BTV only, for the absolute pixel (0,0) (btv_regularizer.cpp:143-146).
-template <typename T, int S, int REGK, int R, typename C, bool BORDER, bool FULL>
-__device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __restrict__ xs, T* __restrict__ cs,
-                                        const T (&wv)[S], int rowrel, int lane, int gr, int gc0, int W, int H,
-                                        T lambda, const T (&pw)[C::NP], T pwsum, bool cost_row) {
-  constexpr int WIN = C::WIN;
-  constexpr int NC = S + WIN;
-  const int xrow = rowrel + C::HU;
-  T x0v[S], rv[S], dv[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); }
-  // the window is walked row by row (i outer, j inner per pixel: the reference's summation order)
-#pragma unroll
-  for (int i = 0; i <= WIN; ++i) {
-    T row[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) row[j] = xs[xi<C>(xrow + i, j) + lane];
-    if (i == 0) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) x0v[pc] = row[pc];
-    }
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      if (REGK == 2) {
-#pragma unroll
-        for (int j = 0; j <= R; ++j) {
-          if (i == 0 && j == 0) continue;  // |x0 - x0| = 0 and sgn(0) = 0
-          T d = x0v[pc] - row[pc + j];
-          if (BORDER) d = ((gr + i < H) && (gc0 + pc + j < W)) ? d : T(0);  // skipped tap == zero difference
-          rv[pc] += pw[i + j] * absv(d);
-          if (FULL && i < R && j < R) {  // exclusive window in the gradient
-            if (sizeof(T) == 8) dv[pc] += pw[i + j] * step_pre<T>(d);  // (sgn + 1) / 2: add with clamp + FMA, two f64 issues
-            else dv[pc] += sgn_pre<T>(d, pw[i + j]);
-          }
-        }
-      } else if (i == 1) {
-        T dyv = row[pc] - x0v[pc];
-        if (BORDER) dyv = (gr + 1 < H) ? dyv : T(0);
-        rv[pc] = absv(dyv) + rv[pc];
-        if (FULL) dv[pc] = dv[pc] - sgn_pre<T>(dyv, T(1));
-      } else {
-        T dxv = row[pc + 1] - x0v[pc];
-        if (BORDER) dxv = (gc0 + pc + 1 < W) ? dxv : T(0);
-        rv[pc] = absv(dxv);
-        if (FULL) dv[pc] = -sgn_pre<T>(dxv, T(1));
-      }
-    }
-  }
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) {
-    const T r = Pre<T>::down(rv[pc]);  // the staged x is pre-scaled: r = r' * 2^-Q exactly
-    const T c = lambda * wv[pc];
-    T cr2 = T(2) * c * r;
-    const bool in_img = (unsigned)gr < (unsigned)H && (unsigned)(gc0 + pc) < (unsigned)W;
-    if (FULL) {
-      if (REGK == 2 && sizeof(T) == 8) dv[pc] = T(2) * dv[pc] - pwsum;  // sum pw * sgn = 2 * sum pw * (sgn + 1) / 2 - sum pw
-      acc[pc] += cr2 * dv[pc];
-      const double cd = (in_img && cost_row) ? (double)c * (double)r * (double)r : 0.0;
-      cost += cd;
-    }
-    if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
-    cs[ci<C>(rowrel + C::RU, pc) + lane] = cr2;
-  }
-}
-
-// 2*lambda*w*r of ONE pixel at tile-relative (rowrel (per lane), col (compile time, < 0)): the left halo columns.
-// xs / cs arrive already offset by the lane's row (rowrel * XROW / rowrel * CROW): every index below is an immediate.
-// BORDER = false: the window stays inside the image (no per-tap masks).
-template <typename T, int S, int REGK, int R, typename C, int COL, bool BORDER>
-__device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __restrict__ cs, const T wt,
-                                             int rowrel, int R0, int C0, int W, int H, T lambda,
-                                             const T (&pw)[C::NP]) {
-  constexpr int WIN = C::WIN;
-  const int gr = R0 + rowrel, gc = C0 + COL;
-  constexpr int xrow = C::HU;
-  T cr2 = T(0);
-  if (gr >= 0 && gr < H && gc >= 0 && gc < W && !(REGK == 2 && gr == 0 && gc == 0)) {
-    const T x0 = xs[xi<C>(xrow, COL)];
-    T r = T(0);
-    if (REGK == 2) {
-#pragma unroll
-      for (int i = 0; i <= WIN; ++i) {
-#pragma unroll
-        for (int j = 0; j <= WIN; ++j) {
-          if (i == 0 && j == 0) continue;
-          const T v = xs[xi<C>(xrow + i, COL + j)];
-          const T d = (!BORDER || (gr + i < H && gc + j < W)) ? x0 - v : T(0);
-          r += pw[i + j] * absv(d);
-        }
-      }
-    } else {
-      const T yv = (!BORDER || gr + 1 < H) ? absv(xs[xi<C>(xrow + 1, COL)] - x0) : T(0);
-      const T xv = (!BORDER || gc + 1 < W) ? absv(xs[xi<C>(xrow, COL + 1)] - x0) : T(0);
-      r = yv + xv;
-    }
-    cr2 = T(2) * (lambda * wt) * Pre<T>::down(r);
-  }
-  cs[ci<C>(C::RU, COL)] = cr2;
-}
-
-// ---- regulariser pass 2: contributions of the up / left neighbours (tv_regularizer.cpp:172-203,
-// btv_regularizer.cpp:137-162) ----
-template <typename T, int S, int REGK, int R, typename C>
-__device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs, const T* __restrict__ cs, int rowrel,
-                                           int lane, const T (&pw)[C::NP]) {
-  constexpr int RU = C::RU;
-  if (RU == 0) return;
-  constexpr int NC = S + RU;
-  const int xrow = rowrel + C::HU, crow = rowrel + RU;
-  T x0v[S], sum[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) sum[pc] = T(0);
-#pragma unroll
-  for (int i = 0; i <= RU; ++i) {  // neighbour row r - i
-    T xw[NC], cw[NC];              // columns -RU .. S-1
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      xw[j] = xs[xi<C>(xrow - i, j - RU) + lane];
-      cw[j] = cs[ci<C>(crow - i, j - RU) + lane];
-    }
-    if (i == 0) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) x0v[pc] = xw[pc + RU];
-    }
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      if (REGK == 2) {
-        if (i < R) {
-#pragma unroll
-          for (int j = 0; j < R; ++j) {
-            if (i == 0 && j == 0) continue;
-            // -sgn(x[q] - x[p]) * alpha^(i+j) * 2 c[q] r[q],  q = p - (i, j)
-            sum[pc] += cw[pc + RU - j] * sgn_pre<T>(x0v[pc] - xw[pc + RU - j], pw[i + j]);
-          }
-        }
-      } else {
-        if (i == 0) sum[pc] += cw[pc + RU - 1] * sgn_pre<T>(x0v[pc] - xw[pc + RU - 1], T(1));
-        else sum[pc] += cw[pc + RU] * sgn_pre<T>(x0v[pc] - xw[pc + RU], T(1));
-      }
-    }
-  }
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) acc[pc] += sum[pc];
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Border blocks: what the frame-summed tile path cannot express, with the reference's literal per-frame formulas
-// (SURVEY.md section 8a').  They are extra workgroups at the FRONT of k_eval_z's grid (dispatched first, they run
-// beside the first tiles and cost no launch of their own).  One thread per pixel q of the frame of width 2E around
-// the image edge, [-E, H+E) x [-E, W+E) minus [E, H-E) x [E, W-E), E = max |shift|:
-//   q OUTSIDE the image: cost of the residuals whose z position is q (they have no owner thread among the tiles);
-//   q INSIDE: the transpose warp clips its source (motion_module.cpp:40-51 on an H x W image): frame k reaches
-//       q only if q - o_k is inside the image.  The tiles add every frame; the excluded ones are collected here,
-//       corr[q] = 2 S^2 sum_tap B^T[tap] sum_{k in L(q + tap), q - o_k outside} r_k, and subtracted from g by
-//       k_finish_eval after the tile kernel.
-constexpr int kBorderTabEntries = 256;  // frame-table entries staged in LDS by the border blocks
-
-template <typename T>
-struct BorderArgs {      // device-resident (one per problem): only the border blocks read it
-  const int2* hdr;       // flat frame table: (count, first entry) per (row phase, column phase)
-  const ZEntry* ent;
-  const T* blur_d;       // [b*b] device copies (dynamic indexing)
-  T* corr;               // [C][n_ring]
-  int S, b, hb;
-  int n_ring;            // pixels of the frame
-  int n_ent;             // entries of the frame table
-  int obs_C;             // channels of the observation stack
-};
-
-__device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
-
-// pixel of the frame for thread index t: top band, bottom band (2E rows x We each), then the left / right strips
-__device__ __forceinline__ void ring_pixel(int t, int W, int H, int E, int& qr, int& qc) {
-  const int We = W + 2 * E, E2 = 2 * E;
-  const int band = E2 * We;
-  if (t < band) { qr = -E + t / We; qc = -E + t % We; }
-  else if (t < 2 * band) { const int u = t - band; qr = H - E + u / We; qc = -E + u % We; }
-  else {
-    const int u = t - 2 * band;
-    const int per = 2 * E2;
-    qr = E + u / per;
-    const int m = u % per;
-    qc = m < E2 ? -E + m : W - E + (m - E2);
-  }
-}
-
-// r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
-// S, B at compile time and the taps from the kernel arguments: the B * B loads of a residual are requested together
-// (with run-time loop bounds and a tap table in memory every tap was its own round trip: ~9 us per border block).
-template <typename T, int S, int B, typename ArgsT>
-__device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int wl, const T* __restrict__ xplane,
-                                             const T* __restrict__ yk, int ox, int oy, int i, int j) {
-  constexpr int hb = (B - 1) / 2;
-  T xv[B * B];
-  const T yv = yk[(size_t)i * wl + j];
-  // 32-bit element offsets inside the plane (the plan admits planes below 2^31 elements), column terms hoisted out of
-  // the row loop, every request at a valid address (masked afterwards)
-  int cix[B];
-  bool cok[B];
-#pragma unroll
-  for (int e = 0; e < B; ++e) {
-    const int cc = S * j + e - hb;
-    const int sc = cc + ox;
-    cok[e] = cc >= 0 && cc < W && sc >= 0 && sc < W;
-    cix[e] = cok[e] ? sc : 0;
-  }
-#pragma unroll
-  for (int a = 0; a < B; ++a) {
-    const int rr = S * i + a - hb;
-    const int sr = rr + oy;
-    // filter2D BORDER_CONSTANT on the warped image, warpAffine BORDER_CONSTANT on the source
-    const bool rok = rr >= 0 && rr < H && sr >= 0 && sr < H;
-    const int rix = rok ? sr * W : 0;
-#pragma unroll
-    for (int e = 0; e < B; ++e) {
-      // mask as a multiply: a select on the loaded value lets the compiler sink each load under its own branch
-      xv[a * B + e] = xplane[(unsigned)(rix + cix[e])] * ((rok && cok[e]) ? T(1) : T(0));
-    }
-  }
-  T acc = T(0);
-#pragma unroll
-  for (int a = 0; a < B; ++a)
-#pragma unroll
-    for (int e = 0; e < B; ++e) acc += blur_tap<B>(A, a, e) * xv[a * B + e];
-  return acc - yv;
-}
-
-// One border block of NT threads; smem: scratch of at least 16 int2 + kBorderTabEntries ZEntry + 8 doubles.
-template <typename T, int S, int B, int NT, bool WD, typename ArgsT>
-__device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>& Bd, int bidx, int ch, void* smem) {
-  const int obs_C = Bd.obs_C;
-  int2* s_hdr = reinterpret_cast<int2*>(smem);
-  ZEntry* s_ent = reinterpret_cast<ZEntry*>(s_hdr + 16);
-  double* red = reinterpret_cast<double*>(s_ent + kBorderTabEntries);
-  const int tid = threadIdx.x;
-  const int t = bidx * NT + tid;
-  const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
-  // the frame table -> LDS (one global latency for the whole block instead of one per lookup)
-  if (tid < S * S) s_hdr[tid] = Bd.hdr[tid];
-  for (int i = tid; i < Bd.n_ent; i += NT) s_ent[i] = Bd.ent[i];
-  __syncthreads();
-  double cost = 0.0, gdc = 0.0;
-  if (t < Bd.n_ring) {
-    int qr, qc;
-    ring_pixel(t, A.W, A.H, A.E, qr, qc);
-    const T* xplane = A.x + (size_t)ch * N;
-    const T* ybase = A.y + (size_t)ch * nl;
-    const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
-    T corr = T(0);
-    if (!inside) {
-      if (A.terms & SRMAP_TERM_DATA) {
-        const int rc = dfdiv(qr, S), cc = dfdiv(qc, S);
-        const int2 h = s_hdr[(qr - rc * S) * S + (qc - cc * S)];
-        for (int n = 0; n < h.x; ++n) {
-          const ZEntry e = s_ent[h.y + n];
-          const int i = rc + e.io, j = cc + e.jo;
-          if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
-          if (S * i < A.cr0 || S * i >= A.cr1) continue;
-          const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-          const double r = (double)border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane,
-                                                            ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
-          cost += r * r;
-        }
-      }
-    } else if (A.g != nullptr && (A.terms & SRMAP_TERM_DATA)) {
-      constexpr int hb = (B - 1) / 2;
-#pragma unroll
-      for (int a = 0; a < B; ++a) {
-#pragma unroll
-        for (int b2 = 0; b2 < B; ++b2) {
-          const int pr = qr + a - hb, pc = qc + b2 - hb;
-          const int rc = dfdiv(pr, S), cc = dfdiv(pc, S);
-          const int2 h = s_hdr[(pr - rc * S) * S + (pc - cc * S)];
-          for (int n = 0; n < h.x; ++n) {
-            const ZEntry e = s_ent[h.y + n];
-            const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-            const int ur = qr - oy, uc = qc - ox;
-            if (ur >= 0 && ur < A.H && uc >= 0 && uc < A.W) continue;  // frame reaches q: already correct
-            const int i = rc + e.io, j = cc + e.jo;
-            if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
-            // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
-            corr += blur_tap<B>(A, b2, a) *
-                    border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
-          }
-        }
-      }
-      corr *= (T)(2 * S * S);
-      // g.d of the corrected gradient: the correction's share, over the rows whose terms this problem counts
-      if (WD && qr >= A.cr0 && qr < A.cr1) gdc = -(double)corr * (double)A.dvec[(size_t)ch * N + (size_t)qr * A.W + qc];
-    }
-    if (A.g != nullptr) Bd.corr[(size_t)ch * Bd.n_ring + t] = corr;
-  }
-  // block partial (s^2 * sum of squares), stored behind the tile partials
-  {
-    double v = cost;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int lane = tid & 63, wid = tid >> 6;
-    if (lane == 0) red[wid] = v;
-    __syncthreads();
-    if (tid == 0) {
-      double sum = 0.0;
-      for (int i = 0; i < NT / 64; ++i) sum += red[i];
-      const int nbb = A.nby * gridDim.x;
-      A.partials[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(S * S) * sum;
-    }
-    if (WD) {
-      double w2 = gdc;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) w2 += __shfl_down(w2, o, 64);
-      __syncthreads();
-      if (lane == 0) red[wid] = w2;
-      __syncthreads();
-      if (tid == 0) {
-        double sum = 0.0;
-        for (int i = 0; i < NT / 64; ++i) sum += red[i];
-        const int nbb = A.nby * gridDim.x;
-        A.partials_gd[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = sum;
-      }
-    }
-  }
-}
 
 template <typename T, int S, int B, int REGK, int R, bool WD, bool SP>
 __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_z(
@@ -1089,7 +334,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 // in index order (deterministic).  Block 0 reduces; all blocks apply corrections.
 template <typename T>
 __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T* __restrict__ corr, int n_ring, int W,
-                                                     int H, int E, int C, const double* __restrict__ partials,
+                                                     int H, RingRects ring, int C, const double* __restrict__ partials,
                                                      int n_partials, double* __restrict__ cost_out,
                                                      const double* __restrict__ partials_gd, double* pub,
                                                      double* tag_slot, double tag) {
@@ -1115,7 +360,7 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
   const int t = ((int)blockIdx.x - 1) * 256 + (int)threadIdx.x;
   if (g != nullptr && blockIdx.x > 0 && t < n_ring) {
     int qr, qc;
-    ring_pixel(t, W, H, E, qr, qc);
+    ring_pixel(t, W, H, ring, qr, qc);
     if (qr >= 0 && qr < H && qc >= 0 && qc < W) {
       for (int ch = 0; ch < C; ++ch) {
         const T c = corr[(size_t)ch * n_ring + t];
@@ -1149,28 +394,6 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
 
 // ---------------------------------------------------------------------------------------------------------
 // host side: plan (per problem, owned by the problem) and launch
-struct ZPlan {
-  int S = 0, B = 1;
-  int regk = 0, regr = 0, reg_index = -1;
-  bool subpix = false;  // sub-pixel shifts: residuals from k_forward_direct, z by 4-tap tables, exact ring by k_gather_direct
-  int Dr = 0;           //   ring width
-  double* d_spw = nullptr;
-  SpForwardPlan spf;    //   forward tile kernel (kernels_spfwd.hip); the direct forward kernel when it does not apply
-  int E = 0;   // max |shift|
-  int MS = 1;  // table slots per (row phase, column phase)
-  int n_ent = 0;
-  int2* d_hdr = nullptr;       // flat table of k_border: (count, first entry) per phase
-  ZEntry* d_ent = nullptr;
-  int h_cnt[32] = {0};         // host copies handed to the kernel by value: [4][8] counts (+ max, min over the column phases)
-  long long h_off0[16] = {0};  //   [4][4] round-0 offsets
-  ZEntry h_aux0[16] = {};      //   [4][4] round-0 (frame, LR row / column offset) entries
-  int* d_cnt = nullptr;        // tile kernel: [S][8]
-  long long* d_off = nullptr;  //              [MS][S][S]
-  ZEntry* d_aux = nullptr;     //              [MS][S][S]
-  int n_ring = 0;              // pixels of the border frame (0 without motion)
-  void* d_corr = nullptr;      // [C][n_ring] border corrections of the gradient
-  void* d_bd = nullptr;        // BorderArgs<T> (device)
-};
 
 void ztile_release(srmap_problem* p) {
   ZPlan* z = static_cast<ZPlan*>(p->zplan);
@@ -1184,6 +407,8 @@ void ztile_release(srmap_problem* p) {
   spfwd_release(&z->spf);
   if (z->d_corr) (void)hipFree(z->d_corr);
   if (z->d_bd) (void)hipFree(z->d_bd);
+  if (z->d_ctr) (void)hipFree(z->d_ctr);
+  if (z->d_mpart) (void)hipFree(z->d_mpart);
   delete z;
   p->zplan = nullptr;
 }
@@ -1353,9 +578,22 @@ bool ztile_plan(srmap_problem* p) {
             hipMalloc((void**)&z->d_aux, sizeof(ZEntry) * aux.size()) == hipSuccess &&
             hipMemcpy(z->d_aux, aux.data(), sizeof(ZEntry) * aux.size(), hipMemcpyHostToDevice) == hipSuccess;
   if (ok && z->E > 0) {
-    const long long We = g.W + 2 * z->E, E2 = 2 * z->E;
-    z->n_ring = (int)(2 * E2 * We + 2 * E2 * (long long)(g.H - 2 * z->E));
-    ok = hipMalloc(&z->d_corr, (size_t)g.C * z->n_ring * p->elem()) == hipSuccess;
+    // the rectangles of the border frame that can carry work (ztile_dev.hpp RingRects)
+    int mnx = 0, mxx = 0, mny = 0, mxy = 0;
+    for (int k = 0; k < K; ++k) {
+      mnx = std::min(mnx, ox[k]); mxx = std::max(mxx, ox[k]);
+      mny = std::min(mny, oy[k]); mxy = std::max(mxy, oy[k]);
+    }
+    RingRects rr;
+    rr.rg[0] = (B > 1) ? std::max(0, mxy) : 0;   // corrections need a blur tap between the pixel and the residual
+    rr.rg[1] = (B > 1) ? std::max(0, mxx) : 0;
+    rr.rg[2] = std::max(0, -mny);
+    rr.rg[3] = std::max(0, mxy - S + 1);
+    rr.rg[4] = std::max(0, -mnx);
+    rr.rg[5] = std::max(0, mxx - S + 1);
+    z->ring = rr;
+    z->n_ring = (int)ring_count(rr, g.W, g.H);
+    if (z->n_ring > 0) ok = hipMalloc(&z->d_corr, (size_t)g.C * z->n_ring * p->elem()) == hipSuccess;
   }
   if (ok) {
     auto put = [&](auto bd) {
@@ -1367,8 +605,15 @@ bool ztile_plan(srmap_problem* p) {
     ok = p->dtype == SRMAP_F32 ? put(BorderArgs<float>()) : put(BorderArgs<double>());
   }
   p->zplan = z;
+  if (ok) ok = march_alloc(p, z);
+  p->zplan = z;
   if (!ok) { ztile_release(p); return false; }
   return true;  // the caller preloads the kernel instance (ztile_preload)
+}
+
+bool ztile_covers_march(const srmap_problem* p) {
+  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
+  return z != nullptr && !z->subpix;
 }
 
 size_t ztile_partials_needed(const srmap_problem* p) {
@@ -1376,8 +621,8 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   const size_t tiles = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * g.C;
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   size_t ring = 0;
-  if (z && z->E > 0) ring = (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * g.C;  // border blocks fill whole grid rows
-  return tiles + ring;
+  if (z && z->n_ring > 0) ring = (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * g.C;  // border blocks fill whole grid rows
+  return std::max(tiles + ring, march_partials_needed(p));
 }
 
 template <typename T, int S, int B, int REGK, int R>
@@ -1396,6 +641,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
   A.obs_C = p->geo.C;
   A.E = z.E;
+  A.ring = z.ring;
   A.cr0 = geo.cr0; A.cr1 = geo.cr1;
   A.terms = (int)terms;
   if (B == 1) { A.blur3[0] = A.blur3[1] = A.blur3[2] = T(1); A.k1s[0] = A.k1s[1] = T(1); }
@@ -1423,7 +669,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.bd = (const BorderArgs<T>*)z.d_bd;
   A.nby = 0; A.n_tile_partials = n_tile_partials;
   int nbb = 0;
-  if ((terms & SRMAP_TERM_DATA) && z.E > 0) {
+  if ((terms & SRMAP_TERM_DATA) && z.n_ring > 0) {
     const int need = (z.n_ring + C::NT - 1) / C::NT;
     A.nby = (need + (int)grid.x - 1) / (int)grid.x;
     nbb = A.nby * (int)grid.x;
@@ -1472,6 +718,7 @@ static void preload_sb(int S, int B, int regk, int regr) {
 void ztile_preload(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   if (!z) return;
+  if (!z->subpix) march_preload(p);
   if (p->dtype == SRMAP_F32) preload_sb<float>(z->S, z->B, z->regk, z->regr);
   else preload_sb<double>(z->S, z->B, z->regk, z->regr);
 }
@@ -1531,7 +778,14 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
   p->gd_valid = false;
   p->eval_published = false;
-  if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
+  // marching waves (kernels_march.hip): everything but sub-pixel shifts; SRMAP_IMPL_TILED keeps the workgroup tiles
+  const bool march = !z.subpix && p->impl != SRMAP_IMPL_TILED;
+  bool march_finished = false;
+  if (march) {
+    rc = launch_eval_march<T>(p, geo, obs_c0, zterms, x, g, wts, regk, regr, partials, &nb, !more_regs, &march_finished, st,
+                              dv, pgd, with_d && p->eval_pub != nullptr);
+  }
+  else if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
   else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
   else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
   else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
@@ -1568,13 +822,23 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
       total += nb2;
     }
   }
+  if (march) {  // corrections were applied in the kernel; the cost too unless more partials followed / too many
+    if (march_finished) {
+      p->gd_valid = with_d;  // d_cost[1] = g.d
+      p->eval_published = with_d && p->eval_pub != nullptr;
+      *nblocks = 0;
+      return SRMAP_OK;
+    }
+    *nblocks = total;
+    return SRMAP_OK;
+  }
   // finish: border corrections of g + the fixed-order cost reduction, one launch
-  const bool corr_on = (terms & SRMAP_TERM_DATA) && z.E > 0 && g != nullptr;
+  const bool corr_on = (terms & SRMAP_TERM_DATA) && z.n_ring > 0 && g != nullptr;
   if (total <= 16384) {
     const int nring = corr_on ? z.n_ring : 0;
     const unsigned nb_f = 1u + (unsigned)((nring + 255) / 256);
     hipLaunchKernelGGL(k_finish_eval<T>, dim3(nb_f), dim3(256), 0, st, corr_on ? g : (T*)nullptr, (const T*)z.d_corr,
-                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, total, p->d_cost, (const double*)pgd,
+                       z.n_ring, geo.W, geo.H, z.ring, geo.C, (const double*)partials, total, p->d_cost, (const double*)pgd,
                        with_d ? p->eval_pub : (double*)nullptr, p->eval_pub_tag_slot, p->eval_pub_tag);
     SRMAP_HIP(p->ctx, hipGetLastError());
     p->gd_valid = with_d;  // d_cost[1] = g.d
@@ -1585,7 +849,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   // many partials (multi-channel problems): corrections here, two-stage reduction by the caller
   if (corr_on) {
     hipLaunchKernelGGL(k_finish_eval<T>, dim3(1u + (unsigned)((z.n_ring + 255) / 256)), dim3(256), 0, st, g, (const T*)z.d_corr,
-                       z.n_ring, geo.W, geo.H, z.E, geo.C, (const double*)partials, 0, p->d_cost + 1, (const double*)nullptr,
+                       z.n_ring, geo.W, geo.H, z.ring, geo.C, (const double*)partials, 0, p->d_cost + 1, (const double*)nullptr,
                        (double*)nullptr, (double*)nullptr, 0.0);
     SRMAP_HIP(p->ctx, hipGetLastError());
   }

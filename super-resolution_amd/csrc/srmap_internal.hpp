@@ -167,6 +167,7 @@ int launch_reduce_partials(srmap_problem* p, const double* partials, int n,
 bool ztile_plan(srmap_problem* p);
 void ztile_release(srmap_problem* p);
 void ztile_preload(const srmap_problem* p);
+bool ztile_covers_march(const srmap_problem* p);  // the plan is served by the marching kernel (kernels_march.hip)
 size_t ztile_partials_needed(const srmap_problem* p);
 template <typename T>
 int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,
