@@ -76,6 +76,9 @@ struct MArgs : ZArgs<T, B, NP> {
   int ntasks_total;     // ... of the evaluation
   int n_wave_partials;  // cost partials: one per wave, then one per border task
   int n_partials;
+  int duty_at_end;      // no wave consumes border corrections: the border tasks are picked up by waves that have finished
+  unsigned long long task_base;  // value of the task counter (ctr64) at launch
+  unsigned long long* ctr64;     // monotonic task counter of the end-of-wave pick-up
   int one_round;        // every pixel phase owns exactly one residual (K = S*S frames with distinct phases)
   int finish;           // 1: the last arriver reduces the partials into cost_out
   unsigned* ctr;        // [0] ticket, [1] duty waves done, [2] a border wait timed out
@@ -98,6 +101,16 @@ __device__ __forceinline__ constexpr int mci(int col) {
   return posmod(col, C::TW / C::CW) * C::CC + C::CCL + floordiv(col, C::TW / C::CW);
 }
 
+// Phase boundary: the values are formed HERE, before any later memory operation, and no later memory operation moves up
+// past this point.  Left alone the compiler sinks a phase's arithmetic below the next phase's LDS reads (and hoists those
+// reads to the top of the iteration), the iteration's live values exceed the register file and the prefetched inputs of
+// the next iteration go to scratch memory behind an s_waitcnt on requests that were issued a moment ago.
+template <typename T, int N>
+__device__ __forceinline__ void m_pin(T (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]) : : "memory");
+}
+
 template <typename U>
 __device__ __forceinline__ U ld_agent(const U* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename U>
@@ -109,25 +122,37 @@ __device__ __forceinline__ void st_agent(U* p, U v) { __hip_atomic_store(p, v, _
 // EDGE: bands near the image border -- LR validity masks, in-image masks and the dropped blur taps of LR row 0 /
 // column 0 (kernels_ztile.hip z_row).  The staged x is pre-scaled by 2^Q: residual = (B x') * 2^-Q - y.
 // ONE: every (row phase, column phase) owns exactly one residual (K = S*S frames with distinct phases): one round, no loop.
-template <typename T, int S, int B, typename C, bool EDGE, bool ONE, typename ArgsT>
+// DM: 0 interior, 1 only COLUMNS can leave the LR image (first / last strips away from the image top / bottom; ONE only),
+// 2 the general EDGE path.
+template <typename T, int S, int B, typename C, int DM, bool ONE, typename ArgsT>
 __device__ __forceinline__ void mz_row(const ArgsT& A, const T* const (&xr)[C::NZ], int zr, int cell0, int lane,
                                        const T* __restrict__ ybase, const T (&ypre)[C::NV], bool count,
                                        const T (&mk)[S], T (&zout)[S], double& cost) {
   constexpr int HB = C::HB, NV = C::NV;
+  constexpr bool EDGE = DM == 2;
+  static_assert(DM != 1 || ONE, "the column-edge path serves one residual per pixel phase");
   int rc, pr;
   row_phase<S>(zr, rc, pr);
   T bx[NV], btop[NV], bleft[NV], bcorner[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) { bx[v] = T(0); btop[v] = T(0); bleft[v] = T(0); bcorner[v] = T(0); }
+  {
+    // one window row of look-ahead, pinned: left alone the scheduler requests every row of every phase up front and
+    // the prefetched inputs of the next iteration end up in scratch memory
+    T xv[B][NV + B - 1];
 #pragma unroll
-  for (int a = 0; a < B; ++a) {
-    T xv[NV + B - 1];
+    for (int j = 0; j < NV + B - 1; ++j) xv[0][j] = xr[0][mxi<C>(j - 2 * HB)];
 #pragma unroll
-    for (int j = 0; j < NV + B - 1; ++j) xv[j] = xr[a][mxi<C>(j - 2 * HB)];
+    for (int a = 0; a < B; ++a) {
+      if (a + 1 < B) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
+        for (int j = 0; j < NV + B - 1; ++j) xv[a + 1][j] = xr[a + 1][mxi<C>(j - 2 * HB)];
+      }
 #pragma unroll
-      for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, a, e) * xv[v + e];
+      for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, a, e) * xv[a][v + e];
+      }
     }
   }
   // filter2D's zero padding acts on the WARPED image: a residual of LR row 0 loses blur tap row 0, of LR column 0 tap
@@ -154,6 +179,33 @@ __device__ __forceinline__ void mz_row(const ArgsT& A, const T* const (&xr)[C::N
     }
   }
   const T unscale = Pre<T>::down(T(1));
+  if (DM == 1) {
+    // rows are interior: every (frame, LR row) of the table exists; an LR column outside the image (per lane) is a
+    // zero residual.  No dropped blur taps unless a frame has a positive column offset (need_left: general path).
+    T z[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+      const int j = cell0 + lane + dc + A.aux0[pr][pc].jo;
+      T rr = bx[v] * unscale - ypre[v];
+      rr = ((unsigned)j < (unsigned)A.wl) ? rr : T(0);
+      z[v] = rr;
+      if (pcv >= 0 && pcv < S && count) cost += (double)(rr * mk[pcv >= 0 && pcv < S ? pcv : 0]) * (double)rr;
+    }
+    if (B == 1) {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) zout[pc] = z[pc];
+    } else {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) {
+        T zh = T(0);
+#pragma unroll
+        for (int e = 0; e < B; ++e) zh += k1_tap<B>(A, e) * z[pc + e];
+        zout[pc] = zh;
+      }
+    }
+    return;
+  }
   int cn[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
@@ -241,9 +293,11 @@ __device__ __forceinline__ void mz_row(const ArgsT& A, const T* const (&xr)[C::N
 // propagated (btv_regularizer.cpp:143-146).
 template <typename T, int S, int REGK, int R, typename C, bool BORDER, bool FULL>
 __device__ __forceinline__ void mreg_row(T (&acc)[S], double& cost, const T* const (&xr)[C::WIN + 1], T* __restrict__ csrow,
-                                         const T (&wv)[S], int lane, int gr, int gc0, int W, int H, T lambda,
+                                         const T (&c2v)[S], int lane, int gr, int gc0, int W, int H,
                                          const T (&pw)[C::NP], T pwsum, bool cost_row, bool zero00,
                                          const T (&cmk)[C::WIN > 0 ? C::WIN : 1]) {
+  // c2v = 2 * (lambda * w): the caller forms it when the weights arrive, so that their registers can take the next
+  // row's request at once.  2 c r = c2v r and c r^2 = (c2v r) r / 2 exactly (powers of two).
   // BORDER masks: a window ROW below the image is skipped as a whole (uniform); a window COLUMN right of the image
   // can only be one of the WIN columns behind the thread's own cell: cmk[c] = 1 / 0 for relative column S + c (a
   // multiply on the difference: skipped tap == zero difference).
@@ -252,9 +306,17 @@ __device__ __forceinline__ void mreg_row(T (&acc)[S], double& cost, const T* con
   T x0v[S], rv[S], dv[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); }
-  // the window is walked row by row (i outer, j inner per pixel: the reference's summation order)
+  // the window is walked row by row (i outer, j inner per pixel: the reference's summation order), the next row's LDS
+  // reads one row ahead of the arithmetic and pinned there (see mz_row)
+  T rows[WIN + 1][NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) rows[0][j] = xr[0][mxi<C>(j)];
 #pragma unroll
   for (int i = 0; i <= WIN; ++i) {
+    if (i < WIN) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) rows[i + 1][j] = xr[i + 1][mxi<C>(j)];
+    }
     if (BORDER && i > 0 && gr + i >= H) {  // uniform
       if (REGK == 2 && FULL && i < R && sizeof(T) == 8) {
         // zero differences: (sgn + 1) / 2 = 1 / 2 for each of the row's taps inside the gradient's window
@@ -266,9 +328,7 @@ __device__ __forceinline__ void mreg_row(T (&acc)[S], double& cost, const T* con
       }
       continue;
     }
-    T row[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) row[j] = xr[i][mxi<C>(j)];
+    const T (&row)[NC] = rows[i];
     if (i == 0) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) x0v[pc] = row[pc];
@@ -298,17 +358,19 @@ __device__ __forceinline__ void mreg_row(T (&acc)[S], double& cost, const T* con
         if (FULL) dv[pc] = -sgn_pre<T>(dxv, T(1));
       }
     }
+    // one window row of look-ahead, no more: row i+1 was requested above, row i+2 waits behind this point
+    m_pin(rv);
+    if (FULL) m_pin(dv);
   }
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) {
     const T r = Pre<T>::down(rv[pc]);  // the staged x is pre-scaled: r = r' * 2^-Q exactly
-    const T c = lambda * wv[pc];
-    T cr2 = T(2) * c * r;
+    T cr2 = c2v[pc] * r;
     const bool in_img = !BORDER || gc0 + pc < W;
     if (FULL) {
       if (REGK == 2 && sizeof(T) == 8) dv[pc] = T(2) * dv[pc] - pwsum;  // sum pw * sgn = 2 * sum pw * (sgn + 1) / 2 - sum pw
       acc[pc] += cr2 * dv[pc];
-      const double cd = (in_img && cost_row) ? (double)c * (double)r * (double)r : 0.0;
+      const double cd = (in_img && cost_row) ? (double)(T(0.5) * cr2) * (double)r : 0.0;
       cost += cd;
     }
     if (BORDER && !in_img) cr2 = T(0);
@@ -329,8 +391,9 @@ __device__ __forceinline__ void mreg_pass2(T (&acc)[S], const T* const (&xu)[C::
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) sum[pc] = T(0);
 #pragma unroll
-  for (int i = 0; i <= RU; ++i) {  // neighbour row r - i
-    T xw[NC], cw[NC];              // columns -RU .. S-1
+  for (int i = 0; i <= RU; ++i) {  // neighbour row r - i (one row at a time: the registers of a second row in flight
+                                    // are what pushes the iteration over the register file)
+    T xw[NC], cw[NC];               // columns -RU .. S-1
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       xw[j] = xu[i][mxi<C>(j - RU)];
@@ -356,6 +419,7 @@ __device__ __forceinline__ void mreg_pass2(T (&acc)[S], const T* const (&xu)[C::
         else sum[pc] += cw[pc + RU] * sgn_pre<T>(x0v[pc] - xw[pc + RU], T(1));
       }
     }
+    m_pin(sum);  // one row of look-ahead (see mreg_row)
   }
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) acc[pc] += sum[pc];
@@ -430,70 +494,83 @@ __device__ __forceinline__ void march_halo_finish(const ArgsT& A, T* __restrict_
   if (h.live) csh[base + lane] = h.on ? cr2 : T(0);
 }
 
-// Border tasks (kernels_ztile.hip border_block, 64 pixels of the border frame per task), carried by the first nduty
-// waves of the grid: task = gw, gw + nduty, ...  Corrections and cost partials leave with write-through stores; the
-// duty wave then counts itself done.
-template <typename T, int S, int B, typename ArgsT>
-__device__ __forceinline__ void march_border_duty(const ArgsT& A, const BorderArgs<T>& Bd, int gw, int lane, void* smem) {
-  const int obs_C = Bd.obs_C;
+// Border tasks (kernels_ztile.hip border_block, 64 pixels of the border frame per task).  Corrections and cost partials
+// leave with write-through stores.  Two schedules:
+//   * some wave consumes corrections (frames with positive offsets): the first nduty waves of the grid carry the tasks
+//     (task = gw, gw + nduty, ...) before their own band, and count themselves done (march_border_duty);
+//   * nobody does (the tasks only produce cost partials): waves that have finished their band pick the tasks up from a
+//     counter (k_eval_march, "duty_at_end") -- the earliest finishers absorb them, no wave starts late.
+template <typename T, int S>
+__device__ __forceinline__ void march_border_tables(const BorderArgs<T>& Bd, int lane, void* smem) {
   int2* s_hdr = reinterpret_cast<int2*>(smem);
   ZEntry* s_ent = reinterpret_cast<ZEntry*>(s_hdr + 16);
-  const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
   if (lane < S * S) s_hdr[lane] = Bd.hdr[lane];
   for (int i = lane; i < Bd.n_ent; i += 64) s_ent[i] = Bd.ent[i];
   __syncthreads();
-  for (int task = gw; task < A.ntasks_total; task += A.nduty) {
-    const int ch = task / A.ntasks, bidx = task - ch * A.ntasks;
-    const int t = bidx * 64 + lane;
-    double cost = 0.0;
-    if (t < Bd.n_ring) {
-      int qr, qc;
-      ring_pixel(t, A.W, A.H, A.ring, qr, qc);
-      const T* xplane = A.x + (size_t)ch * N;
-      const T* ybase = A.y + (size_t)ch * nl;
-      const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
-      T corr = T(0);
-      if (!inside) {
-        const int rc = dfdiv(qr, S), cc = dfdiv(qc, S);
-        const int2 h = s_hdr[(qr - rc * S) * S + (qc - cc * S)];
-        for (int n = 0; n < h.x; ++n) {
-          const ZEntry e = s_ent[h.y + n];
-          const int i = rc + e.io, j = cc + e.jo;
-          if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
-          if (S * i < A.cr0 || S * i >= A.cr1) continue;
-          const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-          const double r = (double)border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
-          cost += r * r;
-        }
-      } else if (A.g != nullptr) {
-        constexpr int hb = (B - 1) / 2;
+}
+
+template <typename T, int S, int B, typename ArgsT>
+__device__ __forceinline__ void march_border_task(const ArgsT& A, const BorderArgs<T>& Bd, int task, int lane, void* smem) {
+  const int obs_C = Bd.obs_C;
+  const int2* s_hdr = reinterpret_cast<const int2*>(smem);
+  const ZEntry* s_ent = reinterpret_cast<const ZEntry*>(s_hdr + 16);
+  const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
+  const int ch = task / A.ntasks, bidx = task - ch * A.ntasks;
+  const int t = bidx * 64 + lane;
+  double cost = 0.0;
+  if (t < Bd.n_ring) {
+    int qr, qc;
+    ring_pixel(t, A.W, A.H, A.ring, qr, qc);
+    const T* xplane = A.x + (size_t)ch * N;
+    const T* ybase = A.y + (size_t)ch * nl;
+    const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
+    T corr = T(0);
+    if (!inside) {
+      const int rc = dfdiv(qr, S), cc = dfdiv(qc, S);
+      const int2 h = s_hdr[(qr - rc * S) * S + (qc - cc * S)];
+      for (int n = 0; n < h.x; ++n) {
+        const ZEntry e = s_ent[h.y + n];
+        const int i = rc + e.io, j = cc + e.jo;
+        if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
+        if (S * i < A.cr0 || S * i >= A.cr1) continue;
+        const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
+        const double r = (double)border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
+        cost += r * r;
+      }
+    } else if (A.g != nullptr) {
+      constexpr int hb = (B - 1) / 2;
 #pragma unroll
-        for (int a = 0; a < B; ++a) {
+      for (int a = 0; a < B; ++a) {
 #pragma unroll
-          for (int b2 = 0; b2 < B; ++b2) {
-            const int pr = qr + a - hb, pc = qc + b2 - hb;
-            const int rc = dfdiv(pr, S), cc = dfdiv(pc, S);
-            const int2 h = s_hdr[(pr - rc * S) * S + (pc - cc * S)];
-            for (int n = 0; n < h.x; ++n) {
-              const ZEntry e = s_ent[h.y + n];
-              const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-              const int ur = qr - oy, uc = qc - ox;
-              if (ur >= 0 && ur < A.H && uc >= 0 && uc < A.W) continue;  // frame reaches q: already correct
-              const int i = rc + e.io, j = cc + e.jo;
-              if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
-              // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
-              corr += blur_tap<B>(A, b2, a) *
-                      border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
-            }
+        for (int b2 = 0; b2 < B; ++b2) {
+          const int pr = qr + a - hb, pc = qc + b2 - hb;
+          const int rc = dfdiv(pr, S), cc = dfdiv(pc, S);
+          const int2 h = s_hdr[(pr - rc * S) * S + (pc - cc * S)];
+          for (int n = 0; n < h.x; ++n) {
+            const ZEntry e = s_ent[h.y + n];
+            const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
+            const int ur = qr - oy, uc = qc - ox;
+            if (ur >= 0 && ur < A.H && uc >= 0 && uc < A.W) continue;  // frame reaches q: already correct
+            const int i = rc + e.io, j = cc + e.jo;
+            if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
+            // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
+            corr += blur_tap<B>(A, b2, a) *
+                    border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
           }
         }
-        corr *= (T)(2 * S * S);
       }
-      if (A.g != nullptr && inside) st_agent(&Bd.corr[(size_t)ch * Bd.n_ring + t], corr);
+      corr *= (T)(2 * S * S);
     }
-    const double cw = wave_sum_d(cost);
-    if (lane == 0) st_agent(A.finish ? &A.mpart[(size_t)A.n_wave_partials + task] : &A.partials[(size_t)A.n_wave_partials + task], (double)(S * S) * cw);
+    if (A.g != nullptr && inside) st_agent(&Bd.corr[(size_t)ch * Bd.n_ring + t], corr);
   }
+  const double cw = wave_sum_d(cost);
+  if (lane == 0) st_agent(A.finish ? &A.mpart[(size_t)A.n_wave_partials + task] : &A.partials[(size_t)A.n_wave_partials + task], (double)(S * S) * cw);
+}
+
+template <typename T, int S, int B, typename ArgsT>
+__device__ __forceinline__ void march_border_duty(const ArgsT& A, const BorderArgs<T>& Bd, int gw, int lane, void* smem) {
+  march_border_tables<T, S>(Bd, lane, smem);
+  for (int task = gw; task < A.ntasks_total; task += A.nduty) march_border_task<T, S, B>(A, Bd, task, lane, smem);
   __syncthreads();  // the scratch is the x ring's again
   if (lane == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the count
@@ -516,73 +593,89 @@ struct MBand {
 };
 
 // ---- requests ----
-// x row grr -> registers: lane l loads cell CJ0 - XCL + l, the first EXTRA lanes also the cells behind the strip.
+// x row grr -> registers: lane l loads cell CJ0 - XCL + l (S pixels); the EXTRA cells behind those 64 are loaded one
+// PIXEL per lane by the first EXTRA * S lanes (contiguous in memory).
 // SLOW: rows / cells outside the image read address 0 and are staged as 0 (the warp's zero fill); the scale 2^Q and
 // that mask are ONE multiply when the row goes to LDS (a select on the loaded value makes the compiler wait for the
 // load where it stands).
-template <typename T, int S, typename C, bool SLOW, typename ArgsT>
-__device__ __forceinline__ void m_issue_x(const ArgsT& A, const MBand<T>& b, int grr, T (&va)[S], T (&vb)[S], T& ma, T& mb) {
+template <typename T, int S, typename C, int DM, typename ArgsT>
+__device__ __forceinline__ void m_issue_x(const ArgsT& A, const MBand<T>& b, int grr, T (&va)[S], T& vb, T& ma, T& mb) {
+  constexpr bool SLOW = DM != 0;
   constexpr int EXTRA = C::XC - C::CW;
-  const int gca = b.CJ0 - C::XCL + b.lane, gcb = gca + C::CW;
+  const int gca = b.CJ0 - C::XCL + b.lane;                     // cell of the S-pixel request
+  const int hpx = (b.CJ0 - C::XCL + C::CW) * S + b.lane;       // HR column of the halo-pixel request
+  const bool hl = b.lane < EXTRA * S;
   if (SLOW) {
-    const bool row_in = (unsigned)grr < (unsigned)A.H;  // uniform
+    const bool row_in = DM == 1 || (unsigned)grr < (unsigned)A.H;  // uniform (DM 1: the rows are interior)
     const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
-    const bool inb = row_in && b.lane < EXTRA && (unsigned)gcb < (unsigned)A.wl;
+    const bool inb = row_in && hl && hpx < A.W;
     const T* sa = b.xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
-    const T* sb = b.xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
+    const T* sb = b.xplane + (inb ? (size_t)grr * A.W + (size_t)hpx : (size_t)0);
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) va[pc] = sa[pc];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) vb[pc] = sb[pc];
+    vb = sb[0];
     ma = ina ? Pre<T>::up(T(1)) : T(0);
     mb = inb ? Pre<T>::up(T(1)) : T(0);
   } else {
     const T* rowp = b.xplane + (size_t)grr * A.W;  // uniform
-    const T* sa = rowp + gca * S;
-    const T* sb = rowp + (b.lane < EXTRA ? gcb : gca) * S;  // every lane requests a valid cell
+    const T* sa = rowp + (unsigned)(gca * S);
+    const T* sb = rowp + (unsigned)(hl ? hpx : gca * S);  // every lane requests a valid pixel
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) va[pc] = sa[pc];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) vb[pc] = sb[pc];
+    vb = sb[0];
     ma = Pre<T>::up(T(1));
     mb = ma;
   }
 }
 template <typename T, int S, typename C>
-__device__ __forceinline__ void m_put_x(T* __restrict__ row, int lane, const T (&va)[S], const T (&vb)[S], T ma, T mb) {
+__device__ __forceinline__ void m_put_x(T* __restrict__ row, int lane, const T (&va)[S], T vb, T ma, T mb) {
   constexpr int EXTRA = C::XC - C::CW;
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) row[pc * C::XC + lane] = va[pc] * ma;
-  if (lane < EXTRA) {
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) row[pc * C::XC + C::CW + lane] = vb[pc] * mb;
-  }
+  if (lane < EXTRA * S) row[(lane % S) * C::XC + C::CW + lane / S] = vb * mb;
 }
-template <typename T, int S, bool SLOW, typename ArgsT>
+template <typename T, int S, int DM, typename ArgsT>
 __device__ __forceinline__ void m_issue_w(const ArgsT& A, const MBand<T>& b, int gr, T (&wv)[S]) {
+  constexpr bool SLOW = DM != 0;
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) wv[pc] = T(1);
   if (b.wplane == nullptr) return;  // uniform
   // SLOW: rows / lanes outside the image request element 0 (their values are never used): no branch around a load
-  const bool ok = !SLOW || ((unsigned)gr < (unsigned)A.H && b.gc0 < A.W);
+  const bool ok = !SLOW || ((DM == 1 || (unsigned)gr < (unsigned)A.H) && b.gc0 < A.W);
   const T* wp = b.wplane + (ok ? (size_t)gr * A.W + b.gc0 : (size_t)0);
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) wv[pc] = wp[pc];
 }
-template <typename T, int S, typename C, bool SLOW, typename ArgsT>
+template <typename T, int S, typename C, int DM, typename ArgsT>
 __device__ __forceinline__ void m_issue_y(const ArgsT& A, const MBand<T>& b, int zr, T (&yv)[C::NV]) {
   int rc, pr;
   row_phase<S>(zr, rc, pr);
+  if (DM == 1) {
+    // round 0 only (ONE); (frame, LR row) exist, the LR column is clamped into the image per lane
+    constexpr int HB = C::HB;
+    const size_t nl = (size_t)A.wl * A.hl;
+#pragma unroll
+    for (int v = 0; v < C::NV; ++v) {
+      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+      const ZEntry e = A.aux0[pr][pc];
+      const T* rowp = b.ybase + (size_t)e.k * A.obs_C * nl + (size_t)(rc + e.io) * A.wl;  // uniform
+      int j = b.CJ0 + b.lane + dc + e.jo;
+      j = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
+      yv[v] = rowp[(unsigned)j];
+    }
+    return;
+  }
   int cn[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-  load_obs_row<T, S, C, SLOW>(A, pr, rc, 0, b.CJ0, b.lane, b.ybase, cn, yv);
+  load_obs_row<T, S, C, DM == 2>(A, pr, rc, 0, b.CJ0, b.lane, b.ybase, cn, yv);
 }
 
 // WD: search direction of row gr (zero where the row's terms are not counted / outside the image)
-template <typename T, int S, bool SLOW, typename ArgsT>
+template <typename T, int S, int DM, typename ArgsT>
 __device__ __forceinline__ void m_issue_d(const ArgsT& A, const MBand<T>& b, int gr, T (&dv)[S]) {
-  const bool ok = SLOW ? ((unsigned)gr < (unsigned)A.H && b.gc0 < A.W && gr >= A.cr0 && gr < A.cr1) : true;
+  constexpr bool SLOW = DM != 0;
+  const bool ok = DM == 2 ? ((unsigned)gr < (unsigned)A.H && b.gc0 < A.W && gr >= A.cr0 && gr < A.cr1) : (DM == 1 ? b.gc0 < A.W : true);
   const T* dp = A.dvec + (size_t)b.ch * b.N + (ok ? (size_t)gr * A.W + b.gc0 : (size_t)0);
   const T dm = ok ? T(1) : T(0);
 #pragma unroll
@@ -592,34 +685,37 @@ __device__ __forceinline__ void m_issue_d(const ArgsT& A, const MBand<T>& b, int
 // State a wave carries from row to row.
 template <typename T, int S, typename C>
 struct MState {
-  T wcur[S], wnext[S];            // IRLS weights of row t / t+1
-  T ycur[C::NV], ynext[C::NV];    // observations of residual row t+HB / t+1+HB
-  T dcur[S], dnext[S];            // WD: search direction of row t / t+1
-  T nva[S], nvb[S], nma, nmb;     // x row t+HD+1 on its way to the ring
-  T zhw[C::NZ][S];                // horizontally blurred residual rows t-HB .. t+HB
+  T w[S];                         // IRLS weights of the next pass-1 row (single buffer: re-requested as soon as consumed)
+  T y[C::NV], ynext[C::NV];       // observations of residual row t+HB, and of row t+1+HB on their way (requested a whole
+                                  // iteration ahead with the x row: the one wait of an iteration must not find young requests)
+  T nva[S], nvb, nma, nmb;        // x row t+HD+1 on its way to the ring
+  T p1[S], p2[S];                 // vertical half of B^T in flight: k0 zh[t-1] + k1 zh[t], and k0 zh[t]
   T cmk[C::WIN > 0 ? C::WIN : 1]; // RBD: window columns S .. S+WIN-1 behind the thread's cell, inside the image?
   T mk[S];                        // in-image mask of the thread's pixels
   int ph, phc;                    // ring phases: window row i of x lives in slot (ph + i) mod NRX, of 2*lambda*w*r in (phc + i) mod NRC
   double cost_data, cost_reg, gd;
 };
 
-// One row.  Order inside an iteration (the counter of outstanding memory operations drains in order for loads but
-// not between loads and stores: a wait for a load also waits for every store issued before it):
-//   A  arithmetic of row t (ring, wcur, ycur)
-//   B  the requests of the PREVIOUS iteration have landed: x row t+HD+1 -> ring, next -> cur
+// One row.  The counter of outstanding memory operations drains in order for loads, but not between loads and
+// stores: a wait for a load also waits for every store issued before it.  So an iteration has ONE point where it
+// waits, for everything, placed where everything is old:
+//   A  arithmetic of row t: 2*lambda*w from the weights (their registers take the request for row t+1 at once),
+//      residual row t+HB, pass 1, vertical B^T, pass 2;
+//      requests consumed at B (search direction, border corrections) go out first
+//   B  everything requested so far has landed: x row t+HD+1 -> ring, corrections, g.d
 //   C  store g row t
-//   D  requests for the iteration after next (x row t+HD+2, weights / direction t+2, observations t+2+HB)
-// so that every wait finds requests that are a whole iteration old, and no load is waited for behind a young store.
+//   D  request x row t+HD+2 and the observations of residual row t+2+HB
 // SLOW: masks of the image border (data term EDGE path, lane masks of partial strips, rows / cells outside the image,
 // border corrections); RBD: the regulariser's windows leave the image at the right / bottom edge; SIMPLE: data term +
 // regulariser + gradient requested, IRLS weights present, one residual per pixel phase (no uniform branches, no loops);
 // OUT: row t is an output row of the band (the PRE rows before it only feed the rings).
-template <typename T, int S, int B, int REGK, int R, bool WD, bool SLOW, bool RBD, bool SIMPLE, bool OUT, typename ArgsT>
+template <typename T, int S, int B, int REGK, int R, bool WD, int DM, bool RBD, bool SIMPLE, bool OUT, typename ArgsT>
 __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __restrict__ xs, T* __restrict__ cs,
                                        const T* __restrict__ csh, MState<T, S, MCfg<T, S, B, REGK, R>>& st, int t) {
   using C = MCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU, WIN = C::WIN, HD = C::HD, NRX = C::NRX, NRC = C::NRC, NZ = C::NZ;
   constexpr int PRE = C::PRE;
+  constexpr bool SLOW = DM != 0, FULLEDGE = DM == 2;
   const int lane = b.lane;
   const bool want_data = SIMPLE || b.want_data, want_reg = SIMPLE ? (REGK != 0) : b.want_reg, outg = SIMPLE || b.outg;
   const T* xw[NRX];  // rows t-RU .. t+HD, lane folded in
@@ -638,10 +734,11 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
   }
 
   // ---------------- A ----------------
-  T cq[S];
+  T dreg[S], cq[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) cq[pc] = T(0);
-  if (SLOW && OUT && b.has_ring) {  // uniform: bands with gradient corrections (top rows / left columns of the image)
+  for (int pc = 0; pc < S; ++pc) { dreg[pc] = T(0); cq[pc] = T(0); }
+  if (WD && OUT) m_issue_d<T, S, DM>(A, b, t, dreg);
+  if (FULLEDGE && OUT && b.has_ring) {  // uniform: bands with gradient corrections (top rows / left columns of the image)
     if (t == b.R0) {
       // the border tasks ran at the head of the grid; their corrections must have left before this wave reads them
       if (lane == 0) {
@@ -660,28 +757,65 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
       cq[pc] = ri >= 0 ? cv : T(0);
     }
   }
+  const bool reg_row = want_reg && (RU == PRE || t >= b.R0 - RU);
+  T c2[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) c2[pc] = T(2) * (A.lambda * st.w[pc]);
+  if (reg_row) m_issue_w<T, S, DM>(A, b, t + 1, st.w);  // weights of the next row into the same registers
+
   T acc[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) acc[pc] = T(0);
 
+  // data term: residual row t + HB, then the vertical half of B^T for row t
+  T zz[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) zz[pc] = T(0);
+  if (want_data && (2 * HB == PRE || t >= b.R0 - 2 * HB)) {
+    const T* xr[NZ];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) xr[a] = xw[RU + a];  // rows t .. t + 2 HB
+    const int zr = t + HB;
+    const bool count = zr >= b.R0 && zr < b.tend;
+    T znew[S];
+    mz_row<T, S, B, C, DM, SIMPLE>(A, xr, zr, b.CJ0, lane, b.ybase, st.y, count, st.mk, znew, st.cost_data);
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      if (B == 1) {
+        zz[pc] = znew[pc];
+      } else {  // zz = k0 zh[t-1] + k1 zh[t] + k0 zh[t+1], summed in this order
+        zz[pc] = st.p1[pc] + k1_tap<B>(A, 2) * znew[pc];
+        st.p1[pc] = st.p2[pc] + k1_tap<B>(A, 1) * znew[pc];
+        st.p2[pc] = k1_tap<B>(A, 0) * znew[pc];
+      }
+    }
+    if (OUT && outg) {
+      const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) acc[pc] = sc * zz[pc];
+    }
+    m_pin(acc);
+    if (B > 1) { m_pin(st.p1); m_pin(st.p2); }
+  }
+
   // regulariser pass 1, row t
-  if (want_reg && (RU == PRE || t >= b.R0 - RU)) {
+  if (reg_row) {
     T* csrow = cw[NRC > 0 ? NRC - 1 : 0];
-    if (SLOW && t < 0) {
+    if (FULLEDGE && t < 0) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) csrow[mci<C>(pc)] = T(0);
     } else {
       const T* xr[WIN + 1];
 #pragma unroll
       for (int i = 0; i <= WIN; ++i) xr[i] = xw[RU + i];
-      const bool cost_row = !SLOW || (t >= A.cr0 && t < A.cr1);
-      const bool zero00 = SLOW && t == 0 && b.C0 == 0;
+      const bool cost_row = !FULLEDGE || (t >= A.cr0 && t < A.cr1);
+      const bool zero00 = FULLEDGE && t == 0 && b.C0 == 0;
       if (OUT) {
-        mreg_row<T, S, REGK, R, C, RBD, true>(acc, st.cost_reg, xr, csrow, st.wcur, lane, t, b.gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row, zero00, st.cmk);
+        mreg_row<T, S, REGK, R, C, RBD, true>(acc, st.cost_reg, xr, csrow, c2, lane, t, b.gc0, A.W, A.H, A.powtab, A.pwsum, cost_row, zero00, st.cmk);
       } else {
         T dacc[S];
         double dc = 0.0;
-        mreg_row<T, S, REGK, R, C, RBD, false>(dacc, dc, xr, csrow, st.wcur, lane, t, b.gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false, zero00, st.cmk);
+        mreg_row<T, S, REGK, R, C, RBD, false>(dacc, dc, xr, csrow, c2, lane, t, b.gc0, A.W, A.H, A.powtab, A.pwsum, false, zero00, st.cmk);
       }
     }
     // the left halo columns of this row, from the table of the prologue
@@ -691,44 +825,11 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
       if (lane == 0) c0row[mci<C>(-1)] = hv;
       else c0row[mci<C>(-2)] = hv;
     }
+    m_pin(acc);
   }
 
-  __builtin_amdgcn_sched_barrier(0);  // phase boundary: keeps the scheduler from hoisting the next phase's LDS reads
-  // data term: residual row t + HB
-  if (want_data && (2 * HB == PRE || t >= b.R0 - 2 * HB)) {
-    const T* xr[NZ];
-#pragma unroll
-    for (int a = 0; a < NZ; ++a) xr[a] = xw[RU + a];  // rows t .. t + 2 HB
-    const int zr = t + HB;
-    const bool count = zr >= b.R0 && zr < b.tend;
-    T znew[S];
-    mz_row<T, S, B, C, SLOW, SIMPLE>(A, xr, zr, b.CJ0, lane, b.ybase, st.ycur, count, st.mk, znew, st.cost_data);
-#pragma unroll
-    for (int a = 0; a + 1 < NZ; ++a)
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) st.zhw[a][pc] = st.zhw[a + 1][pc];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) st.zhw[NZ - 1][pc] = znew[pc];
-  }
-
-  __builtin_amdgcn_sched_barrier(0);
-  // row t: vertical half of B^T, pass 2, correction
+  // row t: data gradient, pass 2
   if (OUT && outg) {
-    if (want_data) {
-      const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) {
-        T zz;
-        if (B == 1) {
-          zz = st.zhw[0][pc];
-        } else {
-          zz = T(0);
-#pragma unroll
-          for (int a = 0; a < B; ++a) zz += k1_tap<B>(A, a) * st.zhw[a][pc];  // rows t-HB+a
-        }
-        acc[pc] += sc * zz;
-      }
-    }
     if (want_reg && RU > 0) {
       const T* xu[RU + 1];
       const T* cu[RU + 1];
@@ -739,26 +840,23 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
       }
       mreg_pass2<T, S, REGK, R, C>(acc, xu, cu, A.powtab);
     }
-    if (SLOW) {
+    m_pin(acc);
+  }
+
+  // ---------------- B: every request so far has landed ----------------
+  m_put_x<T, S, C>(xs + st.ph * C::XROW, lane, st.nva, st.nvb, st.nma, st.nmb);  // x row t+HD+1 replaces row t-RU
+#pragma unroll
+  for (int v = 0; v < NV; ++v) st.y[v] = st.ynext[v];
+  if (OUT && outg) {
+    if (FULLEDGE) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) acc[pc] -= cq[pc];
     }
     if (WD) {
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) st.gd += (double)acc[pc] * (double)st.dcur[pc];
+      for (int pc = 0; pc < S; ++pc) st.gd += (double)acc[pc] * (double)dreg[pc];
     }
-  }
-
-  __builtin_amdgcn_sched_barrier(0);
-  // ---------------- B: last iteration's requests -> ring / current registers ----------------
-  m_put_x<T, S, C>(xs + st.ph * C::XROW, lane, st.nva, st.nvb, st.nma, st.nmb);  // replaces row t-RU
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) { st.wcur[pc] = st.wnext[pc]; if (WD) st.dcur[pc] = st.dnext[pc]; }
-#pragma unroll
-  for (int v = 0; v < NV; ++v) st.ycur[v] = st.ynext[v];
-
-  // ---------------- C: store g row t ----------------
-  if (OUT && outg) {
+    // ---------------- C: store g row t ----------------
     if (!SLOW || b.gc0 < A.W) {
       T* dst = A.g + (size_t)b.ch * b.N + (size_t)t * A.W + b.gc0;
 #pragma unroll
@@ -766,49 +864,74 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
     }
   }
 
-  // ---------------- D: requests for the iteration after next ----------------
-  m_issue_x<T, S, C, SLOW>(A, b, t + HD + 2, st.nva, st.nvb, st.nma, st.nmb);
-  if (want_reg) m_issue_w<T, S, SLOW>(A, b, t + 2, st.wnext);
-  if (want_data) m_issue_y<T, S, C, SLOW>(A, b, t + 2 + HB, st.ynext);
-  if (WD) m_issue_d<T, S, SLOW>(A, b, t + 2, st.dnext);
+  // ---------------- D: request x row t+HD+2 and the observations of residual row t+2+HB ----------------
+  m_issue_x<T, S, C, DM>(A, b, t + HD + 2, st.nva, st.nvb, st.nma, st.nmb);
+  if (want_data) m_issue_y<T, S, C, DM>(A, b, t + 2 + HB, st.ynext);
 
   st.ph = (st.ph + 1 == NRX) ? 0 : st.ph + 1;
   if (NRC > 0) st.phc = (st.phc + 1 == NRC) ? 0 : st.phc + 1;
 }
 
-// The band: the PRE rows before the first output row (pass 1 values / residual rows only), then the output rows.
-// On entry the ring holds x rows t0 .. t0+HD; st.wcur / st.ycur (/ st.dcur) hold the inputs of row t0.
-template <typename T, int S, int B, int REGK, int R, bool WD, bool SLOW, bool RBD, bool SIMPLE, typename ArgsT>
+// The band, from its first request to its last row: prologue (requests, left halo columns, ring fill), the PRE rows
+// before the first output row (pass 1 values / residual rows only), the output rows.  Every code-path variant is its
+// own instance of this function: nothing but the band description is live across the choice of the variant.
+template <typename T, int S, int B, int REGK, int R, bool WD, int DM, bool RBD, bool SIMPLE, typename ArgsT>
 __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T* __restrict__ xs, T* __restrict__ cs,
-                                           const T* __restrict__ csh, MState<T, S, MCfg<T, S, B, REGK, R>>& st) {
+                                           T* __restrict__ csh, double& cost_data, double& cost_reg, double& gd) {
   using C = MCfg<T, S, B, REGK, R>;
-  constexpr int HB = C::HB, HD = C::HD, WIN = C::WIN, NZ = C::NZ;
-  const bool want_data = SIMPLE || b.want_data, want_reg = SIMPLE ? (REGK != 0) : b.want_reg;
+  constexpr int HB = C::HB, HD = C::HD, WIN = C::WIN, RU = C::RU, NV = C::NV;
+  constexpr bool SLOW = DM != 0;
+  const int lane = b.lane;
+  const bool want_data = SIMPLE || b.want_data, want_reg = SIMPLE ? (REGK != 0) : b.want_reg, outg = SIMPLE || b.outg;
+  MState<T, S, C> st;
+  // ---- requests: the left halo columns' windows first (small, and their arithmetic runs while the rows are in
+  // flight), then the band's first HD + 1 rows of x, the first row's weights and observations ----
+  const bool halo_on = RU > 0 && want_reg && outg;
+  MHalo<T, C> hreg;
+  if (halo_on) march_halo_issue<T, S, REGK, R, C>(A, b.xplane, b.wplane, b.R0, b.tend, b.C0, lane, 0, hreg);
+  T pva[HD + 1][S], pvb[HD + 1], pma[HD + 1], pmb[HD + 1];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) st.w[pc] = T(1);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) st.y[v] = T(0);
+#pragma unroll
+  for (int k = 0; k <= HD; ++k) m_issue_x<T, S, C, DM>(A, b, b.t0 + k, pva[k], pvb[k], pma[k], pmb[k]);
+  if (want_reg) m_issue_w<T, S, DM>(A, b, b.t0, st.w);
+  if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + HB, st.y);
+  // ---- left halo columns of 2*lambda*w*r ----
+  if (halo_on) {
+    march_halo_finish<T, S, REGK, R, C>(A, csh, lane, 0, hreg);
+    for (int base = 64; base < (b.tend - b.R0 + RU) * RU; base += 64) {  // tall bands only
+      march_halo_issue<T, S, REGK, R, C>(A, b.xplane, b.wplane, b.R0, b.tend, b.C0, lane, base, hreg);
+      march_halo_finish<T, S, REGK, R, C>(A, csh, lane, base, hreg);
+    }
+  }
+  // ---- x rows -> ring ----
+#pragma unroll
+  for (int k = 0; k <= HD; ++k) m_put_x<T, S, C>(xs + (RU + k) * C::XROW, lane, pva[k], pvb[k], pma[k], pmb[k]);
+
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) st.mk[pc] = (!SLOW || b.gc0 + pc < A.W) ? T(1) : T(0);
 #pragma unroll
   for (int c = 0; c < (WIN > 0 ? WIN : 1); ++c) st.cmk[c] = (!RBD || b.gc0 + S + c < A.W) ? T(1) : T(0);
 #pragma unroll
-  for (int a = 0; a < NZ; ++a)
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) st.zhw[a][pc] = T(0);
+  for (int pc = 0; pc < S; ++pc) { st.p1[pc] = T(0); st.p2[pc] = T(0); }
   st.ph = 0; st.phc = 0;
-  // the requests "D" of a virtual iteration t0 - 1
+  st.cost_data = 0.0; st.cost_reg = 0.0; st.gd = 0.0;
+  m_issue_x<T, S, C, DM>(A, b, b.t0 + HD + 1, st.nva, st.nvb, st.nma, st.nmb);  // "D" of a virtual iteration t0 - 1
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) { st.wnext[pc] = T(1); st.dnext[pc] = T(0); }
-#pragma unroll
-  for (int v = 0; v < C::NV; ++v) st.ynext[v] = T(0);
-  m_issue_x<T, S, C, SLOW>(A, b, b.t0 + HD + 1, st.nva, st.nvb, st.nma, st.nmb);
-  if (want_reg) m_issue_w<T, S, SLOW>(A, b, b.t0 + 1, st.wnext);
-  if (want_data) m_issue_y<T, S, C, SLOW>(A, b, b.t0 + 1 + HB, st.ynext);
-  if (WD) m_issue_d<T, S, SLOW>(A, b, b.t0 + 1, st.dnext);
+  for (int v = 0; v < NV; ++v) st.ynext[v] = T(0);
+  if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + 1 + HB, st.ynext);
 #pragma unroll 1
-  for (int t = b.t0; t < b.R0; ++t) m_step<T, S, B, REGK, R, WD, SLOW, RBD, SIMPLE, false>(A, b, xs, cs, csh, st, t);
+  for (int t = b.t0; t < b.R0; ++t) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, false>(A, b, xs, cs, csh, st, t);
 #pragma unroll 1
-  for (int t = b.R0; t < b.tend; ++t) m_step<T, S, B, REGK, R, WD, SLOW, RBD, SIMPLE, true>(A, b, xs, cs, csh, st, t);
+  for (int t = b.R0; t < b.tend; ++t) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, true>(A, b, xs, cs, csh, st, t);
+  cost_data = st.cost_data; cost_reg = st.cost_reg; gd = st.gd;
 }
 
-template <typename T, int S, int B, int REGK, int R, bool WD>
+// SIMPLE (host-decided): data term + fused regulariser + gradient requested, IRLS weights present, one residual per
+// pixel phase -- the loop bodies are straight-line code.  Otherwise the general loop bodies.
+template <typename T, int S, int B, int REGK, int R, bool WD, bool SIMPLE>
 __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, REGK, R>::NP> A) {
   using C = MCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU, WIN = C::WIN, HD = C::HD;
@@ -871,76 +994,23 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
   b.has_ring = b.want_data && b.outg && (R0 < A.ring.rg[0] || C0 < A.ring.rg[1]);
   b.corr = b.has_ring ? A.bd->corr + (size_t)b.ch * A.bd->n_ring : nullptr;
 
-  // ---------------- requests: the left halo columns' windows first (small, and their arithmetic runs while the rows
-  // are in flight), then the band's first HD + 1 rows of x, the first row's weights and observations ------------
-  const bool halo_on = RU > 0 && b.want_reg && b.outg;
-  MHalo<T, C> hreg;
-  if (halo_on) march_halo_issue<T, S, REGK, R, C>(A, b.xplane, b.wplane, R0, b.tend, C0, lane, 0, hreg);
-  T pva[HD + 1][S], pvb[HD + 1][S], pma[HD + 1], pmb[HD + 1];
-  MState<T, S, C> st;
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) { st.wcur[pc] = T(1); st.dcur[pc] = T(0); }
-#pragma unroll
-  for (int v = 0; v < NV; ++v) st.ycur[v] = T(0);
-  if (slow) {
-#pragma unroll
-    for (int k = 0; k <= HD; ++k) m_issue_x<T, S, C, true>(A, b, b.t0 + k, pva[k], pvb[k], pma[k], pmb[k]);
-    if (b.want_reg) m_issue_w<T, S, true>(A, b, b.t0, st.wcur);
-    if (b.want_data) m_issue_y<T, S, C, true>(A, b, b.t0 + HB, st.ycur);
-    if (WD) m_issue_d<T, S, true>(A, b, b.t0, st.dcur);
-  } else {
-#pragma unroll
-    for (int k = 0; k <= HD; ++k) m_issue_x<T, S, C, false>(A, b, b.t0 + k, pva[k], pvb[k], pma[k], pmb[k]);
-    if (b.want_reg) m_issue_w<T, S, false>(A, b, b.t0, st.wcur);
-    if (b.want_data) m_issue_y<T, S, C, false>(A, b, b.t0 + HB, st.ycur);
-    if (WD) m_issue_d<T, S, false>(A, b, b.t0, st.dcur);
-  }
+  // data-path mode of this band: 0 interior; 1 only columns can leave the image (SIMPLE kernels); 2 general
+  const bool rows_in = !(R0 - rm < 0) && !(R0 + RB + rm + 2 > A.H) && A.cr0 == 0 && A.cr1 >= A.H && R0 >= PRE &&
+                       R0 + RB + HD + 2 <= A.H && R0 + RB + WIN <= A.H;
+  const int dm = !slow ? 0 : ((SIMPLE && rows_in && !b.has_ring && A.ring.rg[1] == 0) ? 1 : 2);
 
-  // ---------------- border duty: the first waves of the grid, while their rows are in flight ----------------
-  if (b.want_data && gw < A.nduty) march_border_duty<T, S, B>(A, *A.bd, gw, lane, (void*)lds);
-
-  // ---------------- left halo columns of 2*lambda*w*r ----------------
-  if (halo_on) {
-    march_halo_finish<T, S, REGK, R, C>(A, csh, lane, 0, hreg);
-    for (int base = 64; base < (b.tend - R0 + RU) * RU; base += 64) {  // tall bands only
-      march_halo_issue<T, S, REGK, R, C>(A, b.xplane, b.wplane, R0, b.tend, C0, lane, base, hreg);
-      march_halo_finish<T, S, REGK, R, C>(A, csh, lane, base, hreg);
-    }
-  }
-
+  // ---------------- border duty at the head of the grid: only when some wave consumes the corrections ----------------
+  if (b.want_data && !A.duty_at_end && gw < A.nduty) march_border_duty<T, S, B>(A, *A.bd, gw, lane, (void*)lds);
 #ifdef SRMAP_DEV_INSTANCES
   ts1 = __builtin_amdgcn_s_memrealtime();
+  ts2 = ts1;
 #endif
-  // ---------------- x rows -> ring ----------------
-#pragma unroll
-  for (int k = 0; k <= HD; ++k) m_put_x<T, S, C>(xs + (RU + k) * C::XROW, lane, pva[k], pvb[k], pma[k], pmb[k]);
-
-#ifdef SRMAP_DEV_INSTANCES
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  ts2 = __builtin_amdgcn_s_memrealtime();
-#endif
-  st.cost_data = 0.0; st.cost_reg = 0.0; st.gd = 0.0;
-  // SIMPLE: everything requested, weights present, one residual per pixel phase -- the loop body is straight-line code
-  const bool simple = b.want_data && b.want_reg && b.outg && b.wplane != nullptr && A.one_round != 0;
-#ifdef MARCH_ONLY
-  if (MARCH_ONLY == 0) march_band<T, S, B, REGK, R, WD, false, false, true>(A, b, xs, cs, csh, st);
-  if (MARCH_ONLY == 1) march_band<T, S, B, REGK, R, WD, true, false, true>(A, b, xs, cs, csh, st);
-  if (MARCH_ONLY == 2) march_band<T, S, B, REGK, R, WD, true, true, true>(A, b, xs, cs, csh, st);
-  if (MARCH_ONLY == 3) march_band<T, S, B, REGK, R, WD, false, false, false>(A, b, xs, cs, csh, st);
-  if (MARCH_ONLY == 4) march_band<T, S, B, REGK, R, WD, true, false, false>(A, b, xs, cs, csh, st);
-  if (MARCH_ONLY == 5) march_band<T, S, B, REGK, R, WD, true, true, false>(A, b, xs, cs, csh, st);
-#else
-  if (simple) {
-    if (reg_border) march_band<T, S, B, REGK, R, WD, true, true, true>(A, b, xs, cs, csh, st);
-    else if (slow) march_band<T, S, B, REGK, R, WD, true, false, true>(A, b, xs, cs, csh, st);
-    else march_band<T, S, B, REGK, R, WD, false, false, true>(A, b, xs, cs, csh, st);
-  } else {
-    if (reg_border) march_band<T, S, B, REGK, R, WD, true, true, false>(A, b, xs, cs, csh, st);
-    else if (slow) march_band<T, S, B, REGK, R, WD, true, false, false>(A, b, xs, cs, csh, st);
-    else march_band<T, S, B, REGK, R, WD, false, false, false>(A, b, xs, cs, csh, st);
-  }
-#endif
-  const double cost_data = st.cost_data, cost_reg = st.cost_reg, gd = st.gd;
+  double cost_data = 0.0, cost_reg = 0.0, gd = 0.0;
+  // three code paths (each variant more in one kernel costs every variant registers): interior; first / last strips away
+  // from the image top / bottom (column masks only; the regulariser's right-edge masks ride along); everything else
+  if (dm == 0) march_band<T, S, B, REGK, R, WD, 0, false, SIMPLE>(A, b, xs, cs, csh, cost_data, cost_reg, gd);
+  else if (SIMPLE && dm == 1) march_band<T, S, B, REGK, R, WD, (SIMPLE ? 1 : 2), true, SIMPLE>(A, b, xs, cs, csh, cost_data, cost_reg, gd);
+  else march_band<T, S, B, REGK, R, WD, 2, true, SIMPLE>(A, b, xs, cs, csh, cost_data, cost_reg, gd);
 
 #ifdef SRMAP_DEV_INSTANCES
   ts3 = __builtin_amdgcn_s_memrealtime();
@@ -954,7 +1024,7 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
   if (A.dbg != nullptr && lane == 0) {
     unsigned long long* d = A.dbg + (size_t)gw * 8;
     d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = __builtin_amdgcn_s_memrealtime();
-    d[5] = (unsigned long long)slow | ((unsigned long long)(gw < A.nduty) << 1) | ((unsigned long long)b.has_ring << 2) | ((unsigned long long)reg_border << 3);
+    d[5] = (unsigned long long)slow | ((unsigned long long)(gw < A.nduty) << 1) | ((unsigned long long)b.has_ring << 2) | ((unsigned long long)reg_border << 3) | ((unsigned long long)dm << 4);
     d[6] = ((unsigned long long)strip << 32) | (unsigned)band;
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -969,7 +1039,21 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
       st_agent(&A.mpart[gw], cwv);
       if (WD) st_agent(&A.mpart_gd[gw], gdv);
     }
-    if ((unsigned)gw != nwaves - 1) return;
+    if ((unsigned)gw != nwaves - 1) {
+      // border tasks nobody waits for: picked up by the waves that finish first
+      if (A.duty_at_end && b.want_data) {
+        bool tables = false;
+        while (true) {
+          unsigned long long tkn = 0;
+          if (lane == 0) tkn = __hip_atomic_fetch_add(A.ctr64, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.task_base;
+          const unsigned tlo = __builtin_amdgcn_readfirstlane((unsigned)tkn), thi = __builtin_amdgcn_readfirstlane((unsigned)(tkn >> 32));
+          if (thi != 0 || tlo >= (unsigned)A.ntasks_total) break;
+          if (!tables) { march_border_tables<T, S>(*A.bd, lane, (void*)lds); tables = true; }
+          march_border_task<T, S, B>(A, *A.bd, (int)tlo, lane, (void*)lds);
+        }
+      }
+      return;
+    }
     constexpr int U = 40;  // requests in flight per lane and round; the order of the additions is fixed
     double v = 0.0, v2 = 0.0;
     bool timed_out = false;
@@ -993,7 +1077,7 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
             missing |= (i < n) && a[u] == kMarchSentinel;
           }
           if (!__any(missing)) break;
-          if (++spins > (1u << 18)) { timed_out = true; break; }
+          if (++spins > (1u << 14)) { timed_out = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
 #pragma unroll
@@ -1046,7 +1130,9 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
 
 // ---------------------------------------------------------------------------------------------------------
 // host side
+static int g_march_end_duty = 1;
 #ifdef SRMAP_DEV_INSTANCES
+extern "C" void srmap_dev_set_end_duty(int v) { g_march_end_duty = v; }
 static unsigned long long* g_march_dbg = nullptr;
 extern "C" void srmap_dev_set_march_dbg(void* p) { g_march_dbg = (unsigned long long*)p; }
 #endif
@@ -1090,10 +1176,17 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.nby = 0; A.n_tile_partials = 0;
   A.rbuf = nullptr; A.spw = nullptr; A.Dr = 0;
   // ---- bands: as few generations of waves as possible, each as short as possible ----
-  const void* kfn = (dvec != nullptr && finish_ok) ? reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true>)
-                                    : reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false>);
-  static int occ_cache[2] = {0, 0};  // per kernel instance (this function is one template instance)
-  int& occ = occ_cache[dvec != nullptr ? 1 : 0];
+  bool simple = REGK != 0 && (terms & SRMAP_TERM_DATA) && (terms & SRMAP_TERM_REG) && g != nullptr && wts != nullptr;
+  for (int pr = 0; pr < S; ++pr)
+    for (int pc = 0; pc < S; ++pc)
+      if (z.h_cnt[pr * 8 + pc] != 1) simple = false;
+  const bool wd = dvec != nullptr && finish_ok;
+  const void* kfn = simple ? (wd ? reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true, true>)
+                                 : reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false, true>))
+                           : (wd ? reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true, false>)
+                                 : reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false, false>));
+  static int occ_cache[4] = {0, 0, 0, 0};  // per kernel instance (this function is one template instance)
+  int& occ = occ_cache[(wd ? 1 : 0) + (simple ? 2 : 0)];
   if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64, 0) != hipSuccess || occ < 1)) occ = 4;
   const int cus = p->ctx->num_cus > 0 ? p->ctx->num_cus : 256;
   const long long slots = (long long)cus * occ;
@@ -1140,10 +1233,7 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     const long long cap = std::max<long long>(1, std::min<long long>(slots / 2, nwaves));
     A.nduty = (int)std::min<long long>(A.ntasks_total, cap);
   }
-  A.one_round = 1;
-  for (int pr = 0; pr < S; ++pr)
-    for (int pc = 0; pc < S; ++pc)
-      if (z.h_cnt[pr * 8 + pc] != 1) A.one_round = 0;
+  A.one_round = simple ? 1 : 0;
   A.n_wave_partials = nwaves;
   A.n_partials = nwaves + A.ntasks_total;
   const bool finish = finish_ok && z.d_mpart != nullptr && (size_t)A.n_partials <= z.mpart_cap;  // else the caller reduces the partials (two stages)
@@ -1151,19 +1241,33 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.dvec = dvec; A.partials_gd = partials_gd;
   A.finish = finish ? 1 : 0;
   *finished = finish;
+  A.duty_at_end = 0; A.task_base = 0;
+  if (g_march_end_duty && finish && A.ntasks_total > 0 && z.ring.rg[0] == 0 && z.ring.rg[1] == 0 && z.d_ctr64 != nullptr) {
+    // no in-image correction pixels: nobody waits for the border tasks
+    A.duty_at_end = 1;
+    A.nduty = 0;
+    A.task_base = z.task_count;
+    z.task_count += (unsigned long long)A.ntasks_total + (unsigned long long)(nwaves - 1);  // every picker ends on a miss
+  }
   A.ctr = z.d_ctr;
   A.cost_out = p->d_cost;
   A.pub = (publish && dvec != nullptr) ? p->eval_pub : nullptr;
   A.tag_slot = p->eval_pub_tag_slot;
   A.tag = p->eval_pub_tag;
+  A.ctr64 = z.d_ctr64;
   A.mpart = z.d_mpart;
   A.mpart_gd = z.d_mpart ? z.d_mpart + z.mpart_cap : nullptr;
   A.dbg = nullptr;
 #ifdef SRMAP_DEV_INSTANCES
   A.dbg = g_march_dbg;
 #endif
-  if (dvec != nullptr) hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, true>), grid, dim3(64), 0, st, A);
-  else hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, false>), grid, dim3(64), 0, st, A);
+  if (simple) {
+    if (dvec != nullptr) hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, true, true>), grid, dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, false, true>), grid, dim3(64), 0, st, A);
+  } else {
+    if (dvec != nullptr) hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, true, false>), grid, dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, false, false>), grid, dim3(64), 0, st, A);
+  }
   *nblocks = A.n_partials;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
@@ -1217,8 +1321,12 @@ template int launch_eval_march<double>(srmap_problem*, const Geometry&, int, uns
 template <typename T, int S, int B, int REGK, int R>
 static void preload_m() {
   hipFuncAttributes attr;
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false>));
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true, false>));
+  if (REGK != 0) {
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false, true>));
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true, true>));
+  }
 }
 template <typename T, int S, int B>
 static void preload_mreg(int regk, int regr) {
@@ -1255,6 +1363,9 @@ void march_preload(const srmap_problem* p) {
 bool march_alloc(srmap_problem* p, ZPlan* z) {
   if (hipMalloc((void**)&z->d_ctr, 4 * sizeof(unsigned)) != hipSuccess) return false;
   if (hipMemset(z->d_ctr, 0, 4 * sizeof(unsigned)) != hipSuccess) return false;
+  if (hipMalloc((void**)&z->d_ctr64, sizeof(unsigned long long)) != hipSuccess) return false;
+  if (hipMemset(z->d_ctr64, 0, sizeof(unsigned long long)) != hipSuccess) return false;
+  z->task_count = 0;
   // granules for the in-kernel reduction: enough for every band height the launcher may choose, up to a cap beyond
   // which the caller's two-stage reduction is used anyway
   const size_t cap = std::min<size_t>(march_partials_needed(p), (size_t)16384);

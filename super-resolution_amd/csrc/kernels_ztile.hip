@@ -408,6 +408,7 @@ void ztile_release(srmap_problem* p) {
   if (z->d_corr) (void)hipFree(z->d_corr);
   if (z->d_bd) (void)hipFree(z->d_bd);
   if (z->d_ctr) (void)hipFree(z->d_ctr);
+  if (z->d_ctr64) (void)hipFree(z->d_ctr64);
   if (z->d_mpart) (void)hipFree(z->d_mpart);
   delete z;
   p->zplan = nullptr;

@@ -827,6 +827,8 @@ struct ZPlan {
   void* d_bd = nullptr;        // BorderArgs<T> (device)
   double* d_mpart = nullptr;   // marching kernel: write-through partial granules, [2][mpart_cap] (cost, g.d); sentinel = unpublished
   size_t mpart_cap = 0;
+  unsigned long long* d_ctr64 = nullptr;        // marching kernel: monotonic counter of the end-of-wave border task pick-up
+  mutable unsigned long long task_count = 0;  //   its value after the launches issued so far
   unsigned* d_ctr = nullptr;   // marching kernel: [0] ticket, [1] border duty waves done, [2] wait timed out (zero between launches)
 };
 

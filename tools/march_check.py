@@ -61,8 +61,11 @@ def timing(ctx, W):
     p.set_observations_device(y.data_ptr())
     r = p.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
     p.update_irls_weights_device(r, x.data_ptr())
-    for name, impl in (("tiled", sr.IMPL_TILED), ("march", sr.IMPL_MARCH)):
+    import ctypes as C
+    lib = sr.load()
+    for name, impl in (("tiled", sr.IMPL_TILED), ("march", sr.IMPL_MARCH), ("march-headduty", sr.IMPL_MARCH)):
         p.set_impl(impl)
+        if hasattr(lib, "srmap_dev_set_end_duty"): lib.srmap_dev_set_end_duty(0 if name == "march-headduty" else 1)
         for _ in range(2000): p.eval_device(x.data_ptr(), g.data_ptr(), sr.TERM_ALL)
         for rep in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 1000

@@ -45,6 +45,24 @@ desc("duty", duty)
 desc("fast non-duty", ~slow & ~duty)
 desc("slow non-duty", slow & ~duty)
 desc("ring waves", ring)
+dm = ((d[:, 5] >> np.uint64(4)) & np.uint64(3)).astype(int)
+for k in range(3): desc("dm=%d" % k, dm == k)
+strip = (d[:, 6] >> np.uint64(32)).astype(int); band = (d[:, 6] & np.uint64(0xffffffff)).astype(int)
+for sidx in range(strip.max() + 1):
+    m = strip == sidx
+    print("strip %d: n=%d loop mean %.2f min %.2f max %.2f end max %.2f" % (sidx, m.sum(), loop[m].mean(), loop[m].min(), loop[m].max(), end[m].max()))
+print("dm=0 band-time histogram (us):", np.histogram(loop[dm == 0], bins=[20,22,24,26,28,30,32,34,36,38,40,45,50,60])[0])
+print("dm=1 band-time histogram (us):", np.histogram(loop[dm == 1], bins=[20,22,24,26,28,30,32,34,36,38,40,45,50,60])[0])
+hwk = xcc * 10000 + ((d[:, 7] & np.uint64(0xffffffff)).astype(np.int64) >> 4 & 0xfff)
+import collections
+grp = collections.defaultdict(list)
+for i in range(n): grp[int(hwk[i])].append(i)
+pairs = [(loop[v[0]], loop[v[1]], dm[v[0]], dm[v[1]]) for v in grp.values() if len(v) == 2]
+pa = np.array(pairs)
+print("SIMD pairs: %d; corr of band times within a pair %.2f; mean |diff| %.2f" % (len(pa), np.corrcoef(pa[:,0], pa[:,1])[0,1], np.abs(pa[:,0]-pa[:,1]).mean()))
+print("pair max-time histogram:", np.histogram(np.maximum(pa[:,0],pa[:,1]), bins=[20,24,28,32,36,40,45,50,60])[0])
+late = np.argsort(-end)[:12]
+for i in late: print("late wave strip %d band %d dm %d xcc %d start %.2f loop %.2f end %.2f" % (strip[i], band[i], dm[i], int(d[i,7] >> np.uint64(32)), st[i], loop[i], end[i]))
 xcc = (d[:, 7] >> np.uint64(32)).astype(int)
 for k in range(8):
     m = xcc == k
