@@ -496,8 +496,8 @@ __device__ __forceinline__ void march_halo_finish(const ArgsT& A, T* __restrict_
 
 // Border tasks (kernels_ztile.hip border_block, 64 pixels of the border frame per task).  Corrections and cost partials
 // leave with write-through stores.  Two schedules:
-//   * some wave consumes corrections (frames with positive offsets): the first nduty waves of the grid carry the tasks
-//     (task = gw, gw + nduty, ...) before their own band, and count themselves done (march_border_duty);
+//   * some wave consumes corrections (frames with positive offsets): the tasks run as their own launch, k_march_border,
+//     before k_eval_march (the kernel boundary orders corrections and their readers);
 //   * nobody does (the tasks only produce cost partials): waves that have finished their band pick the tasks up from a
 //     counter (k_eval_march, "duty_at_end") -- the earliest finishers absorb them, no wave starts late.
 template <typename T, int S>
@@ -565,17 +565,6 @@ __device__ __forceinline__ void march_border_task(const ArgsT& A, const BorderAr
   }
   const double cw = wave_sum_d(cost);
   if (lane == 0) st_agent(A.finish ? &A.mpart[(size_t)A.n_wave_partials + task] : &A.partials[(size_t)A.n_wave_partials + task], (double)(S * S) * cw);
-}
-
-template <typename T, int S, int B, typename ArgsT>
-__device__ __forceinline__ void march_border_duty(const ArgsT& A, const BorderArgs<T>& Bd, int gw, int lane, void* smem) {
-  march_border_tables<T, S>(Bd, lane, smem);
-  for (int task = gw; task < A.ntasks_total; task += A.nduty) march_border_task<T, S, B>(A, Bd, task, lane, smem);
-  __syncthreads();  // the scratch is the x ring's again
-  if (lane == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the count
-    __hip_atomic_fetch_add(&A.ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 constexpr int kMarchBorderLds = (int)(16 * sizeof(int2) + kBorderTabEntries * sizeof(ZEntry) + 64);
@@ -739,21 +728,10 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
   for (int pc = 0; pc < S; ++pc) { dreg[pc] = T(0); cq[pc] = T(0); }
   if (WD && OUT) m_issue_d<T, S, DM>(A, b, t, dreg);
   if (FULLEDGE && OUT && b.has_ring) {  // uniform: bands with gradient corrections (top rows / left columns of the image)
-    if (t == b.R0) {
-      // the border tasks ran at the head of the grid; their corrections must have left before this wave reads them
-      if (lane == 0) {
-        unsigned spins = 0;
-        while (ld_agent(&A.ctr[1]) < (unsigned)A.nduty) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > (1u << 22)) { st_agent(&A.ctr[2], 1u); break; }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
       const int ri = (b.gc0 + pc < A.W) ? ring_index(t, b.gc0 + pc, A.W, A.H, A.ring) : -1;
-      const T cv = ld_agent(&b.corr[ri >= 0 ? ri : 0]);
+      const T cv = b.corr[ri >= 0 ? ri : 0];  // written by k_march_border, launched before this kernel
       cq[pc] = ri >= 0 ? cv : T(0);
     }
   }
@@ -999,8 +977,8 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
                        R0 + RB + HD + 2 <= A.H && R0 + RB + WIN <= A.H;
   const int dm = !slow ? 0 : ((SIMPLE && rows_in && !b.has_ring && A.ring.rg[1] == 0) ? 1 : 2);
 
-  // ---------------- border duty at the head of the grid: only when some wave consumes the corrections ----------------
-  if (b.want_data && !A.duty_at_end && gw < A.nduty) march_border_duty<T, S, B>(A, *A.bd, gw, lane, (void*)lds);
+  // (border tasks: when some wave consumes their corrections they ran in k_march_border, launched before this kernel;
+  // when they only produce cost partials they are picked up at the end of this kernel by the waves that finish first)
 #ifdef SRMAP_DEV_INSTANCES
   ts1 = __builtin_amdgcn_s_memrealtime();
   ts2 = ts1;
@@ -1024,7 +1002,7 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
   if (A.dbg != nullptr && lane == 0) {
     unsigned long long* d = A.dbg + (size_t)gw * 8;
     d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = __builtin_amdgcn_s_memrealtime();
-    d[5] = (unsigned long long)slow | ((unsigned long long)(gw < A.nduty) << 1) | ((unsigned long long)b.has_ring << 2) | ((unsigned long long)reg_border << 3) | ((unsigned long long)dm << 4);
+    d[5] = (unsigned long long)slow | ((unsigned long long)0 << 1) | ((unsigned long long)b.has_ring << 2) | ((unsigned long long)reg_border << 3) | ((unsigned long long)dm << 4);
     d[6] = ((unsigned long long)strip << 32) | (unsigned)band;
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1124,6 +1102,16 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
       st_agent(&A.ctr[2], 0u);
     }
   }
+}
+
+// Border tasks as their own launch (one wave per task), BEFORE k_eval_march: used when frames with positive offsets
+// exist, i.e. when the corrections of the tasks are consumed by the bands (the kernel boundary orders them).
+template <typename T, int S, int B, int NP>
+__global__ __launch_bounds__(64) void k_march_border(MArgs<T, B, NP> A) {
+  __shared__ T lds[(kMarchBorderLds + (int)sizeof(T) - 1) / (int)sizeof(T)];
+  const int lane = threadIdx.x;
+  march_border_tables<T, S>(*A.bd, lane, (void*)lds);
+  march_border_task<T, S, B>(A, *A.bd, (int)blockIdx.x, lane, (void*)lds);
 }
 
 }  // namespace
@@ -1261,6 +1249,8 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
 #ifdef SRMAP_DEV_INSTANCES
   A.dbg = g_march_dbg;
 #endif
+  if (A.ntasks_total > 0 && !A.duty_at_end)
+    hipLaunchKernelGGL((k_march_border<T, S, B, C::NP>), dim3((unsigned)A.ntasks_total), dim3(64), 0, st, A);
   if (simple) {
     if (dvec != nullptr) hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, true, true>), grid, dim3(64), 0, st, A);
     else hipLaunchKernelGGL((k_eval_march<T, S, B, REGK, R, false, true>), grid, dim3(64), 0, st, A);
