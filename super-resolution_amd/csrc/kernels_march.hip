@@ -79,6 +79,7 @@ struct MArgs : ZArgs<T, B, NP> {
   int duty_at_end;      // no wave consumes border corrections: the border tasks are picked up by waves that have finished
   unsigned long long task_base;  // value of the task counter (ctr64) at launch
   unsigned long long* ctr64;     // monotonic task counter of the end-of-wave pick-up
+  int stagger;          // start delay spread, in units of 64 cycles (0 = none)
   int one_round;        // every pixel phase owns exactly one residual (K = S*S frames with distinct phases)
   int finish;           // 1: the last arriver reduces the partials into cost_out
   unsigned* ctr;        // [0] ticket, [1] duty waves done, [2] a border wait timed out
@@ -115,6 +116,64 @@ template <typename U>
 __device__ __forceinline__ U ld_agent(const U* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename U>
 __device__ __forceinline__ void st_agent(U* p, U v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The frame table's by-value part (counts, round 0) is indexed with the row phase of the current row: a run-time index.
+// Reading it through `A` makes the argument block an indexed aggregate, and once the kernel is large the compiler keeps
+// a private copy of the WHOLE block in scratch memory (every argument then costs a scratch load).  These accessors read
+// the kernel-argument segment directly (uniform address -> scalar load); `A` itself is only ever indexed statically.
+template <typename ArgsT, typename U>
+__device__ __forceinline__ U m_karg(size_t byte_off) {
+  typedef const char __attribute__((address_space(4))) * CP;
+  typedef const U __attribute__((address_space(4))) * UP;
+  CP base = (CP)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(UP)(base + byte_off);
+}
+template <typename ArgsT>
+__device__ __forceinline__ int m_cntk(int pr, int i) {
+  return m_karg<ArgsT, int>(__builtin_offsetof(ArgsT, cntk) + (size_t)(pr * 8 + i) * sizeof(int));
+}
+template <typename ArgsT>
+__device__ __forceinline__ long long m_off0(int pr, int pc) {
+  return m_karg<ArgsT, long long>(__builtin_offsetof(ArgsT, off0) + (size_t)(pr * 4 + pc) * sizeof(long long));
+}
+template <typename ArgsT>
+__device__ __forceinline__ ZEntry m_aux0(int pr, int pc) {
+  const size_t o = __builtin_offsetof(ArgsT, aux0) + (size_t)(pr * 4 + pc) * sizeof(ZEntry);
+  ZEntry e;
+  e.k = m_karg<ArgsT, int>(o); e.io = m_karg<ArgsT, int>(o + 4); e.jo = m_karg<ArgsT, int>(o + 8); e.oyx = m_karg<ArgsT, int>(o + 12);
+  return e;
+}
+
+// Observations of the t-th residual of each of the NV pixels of the thread's cell in an HR row of phase pr
+// (ztile_dev.hpp load_obs_row, with the by-value table read through the accessors above).
+template <typename T, int S, typename C, bool EDGE, typename ArgsT>
+__device__ __forceinline__ void m_load_obs_row(const ArgsT& A, int pr, int rc, int t, int cell0, int lane,
+                                               const T* __restrict__ ybase, T (&yv)[C::NV]) {
+  constexpr int HB = C::HB, NV = C::NV;
+  const size_t slot = (size_t)(t * S + pr) * S;  // uniform; round-major: round 0 (the prefetch) needs no table size
+  const T* yrow = ybase + ((long long)rc * A.wl + cell0);  // uniform: LR cell row rc, first cell of the strip
+  if (!EDGE) {
+    long long offs[S];
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) offs[pc] = (t == 0) ? m_off0<ArgsT>(pr, pc) : ctab(A.off, slot + pc);  // t: uniform
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+      const T* yp = yrow + (offs[pc] + dc);  // uniform pointer; the lane adds its (non-negative) cell index
+      yv[v] = yp[(unsigned)lane];
+    }
+    return;
+  }
+  ZEntry ent[S];
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) ent[pc] = (t == 0) ? m_aux0<ArgsT>(pr, pc) : ctab(A.aux, slot + pc);  // t: uniform
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+    const ZEntry e = ent[pc];
+    yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
+  }
+}
 
 // ---- data term for the S pixels of one cell in HR row zr (wave-uniform) ----
 // B x at NV pixels, residuals of the frames whose LR grid hits each pixel, z; returns z (B == 1) or the horizontal
@@ -186,7 +245,7 @@ __device__ __forceinline__ void mz_row(const ArgsT& A, const T* const (&xr)[C::N
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-      const int j = cell0 + lane + dc + A.aux0[pr][pc].jo;
+      const int j = cell0 + lane + dc + m_aux0<ArgsT>(pr, pc).jo;
       T rr = bx[v] * unscale - ypre[v];
       rr = ((unsigned)j < (unsigned)A.wl) ? rr : T(0);
       z[v] = rr;
@@ -208,9 +267,9 @@ __device__ __forceinline__ void mz_row(const ArgsT& A, const T* const (&xr)[C::N
   }
   int cn[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-  const int mmax = ONE ? 1 : A.cntk[pr][S];
-  const int mfull = EDGE ? 0 : (ONE ? 1 : A.cntk[pr][S + 1]);  // rounds in which every column phase owns a residual
+  for (int pc = 0; pc < S; ++pc) cn[pc] = ONE ? 1 : m_cntk<ArgsT>(pr, pc);
+  const int mmax = ONE ? 1 : m_cntk<ArgsT>(pr, S);
+  const int mfull = EDGE ? 0 : (ONE ? 1 : m_cntk<ArgsT>(pr, S + 1));  // rounds in which every column phase owns a residual
   T z[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) z[v] = T(0);
@@ -221,7 +280,7 @@ __device__ __forceinline__ void mz_row(const ArgsT& A, const T* const (&xr)[C::N
 #pragma unroll
       for (int v = 0; v < NV; ++v) yv[v] = ypre[v];
     } else {
-      load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ybase, cn, yv);
+      m_load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ybase, yv);
     }
     if (!EDGE && t < mfull) {  // uniform; the common case (K a multiple of S*S distinct phases): no per-pixel selects
 #pragma unroll
@@ -252,7 +311,7 @@ __device__ __forceinline__ void mz_row(const ArgsT& A, const T* const (&xr)[C::N
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
       const bool own = pcv >= 0 && pcv < S;
-      const ZEntry e = (t == 0) ? A.aux0[pr][pc] : ctab(A.aux, slot + pc);
+      const ZEntry e = (t == 0) ? m_aux0<ArgsT>(pr, pc) : ctab(A.aux, slot + pc);
       const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
       const bool row_ok = (ONE || t < cn[pc]) && (unsigned)i < (unsigned)A.hl;  // uniform
       T bxv = bx[v];
@@ -358,9 +417,6 @@ __device__ __forceinline__ void mreg_row(T (&acc)[S], double& cost, const T* con
         if (FULL) dv[pc] = -sgn_pre<T>(dxv, T(1));
       }
     }
-    // one window row of look-ahead, no more: row i+1 was requested above, row i+2 waits behind this point
-    m_pin(rv);
-    if (FULL) m_pin(dv);
   }
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) {
@@ -419,7 +475,6 @@ __device__ __forceinline__ void mreg_pass2(T (&acc)[S], const T* const (&xu)[C::
         else sum[pc] += cw[pc + RU] * sgn_pre<T>(x0v[pc] - xw[pc + RU], T(1));
       }
     }
-    m_pin(sum);  // one row of look-ahead (see mreg_row)
   }
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) acc[pc] += sum[pc];
@@ -646,7 +701,7 @@ __device__ __forceinline__ void m_issue_y(const ArgsT& A, const MBand<T>& b, int
 #pragma unroll
     for (int v = 0; v < C::NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-      const ZEntry e = A.aux0[pr][pc];
+      const ZEntry e = m_aux0<ArgsT>(pr, pc);
       const T* rowp = b.ybase + (size_t)e.k * A.obs_C * nl + (size_t)(rc + e.io) * A.wl;  // uniform
       int j = b.CJ0 + b.lane + dc + e.jo;
       j = j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j);
@@ -654,10 +709,7 @@ __device__ __forceinline__ void m_issue_y(const ArgsT& A, const MBand<T>& b, int
     }
     return;
   }
-  int cn[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-  load_obs_row<T, S, C, DM == 2>(A, pr, rc, 0, b.CJ0, b.lane, b.ybase, cn, yv);
+  m_load_obs_row<T, S, C, DM == 2>(A, pr, rc, 0, b.CJ0, b.lane, b.ybase, yv);
 }
 
 // WD: search direction of row gr (zero where the row's terms are not counted / outside the image)
@@ -675,8 +727,10 @@ __device__ __forceinline__ void m_issue_d(const ArgsT& A, const MBand<T>& b, int
 template <typename T, int S, typename C>
 struct MState {
   T w[S];                         // IRLS weights of the next pass-1 row (single buffer: re-requested as soon as consumed)
-  T y[C::NV], ynext[C::NV];       // observations of residual row t+HB, and of row t+1+HB on their way (requested a whole
-                                  // iteration ahead with the x row: the one wait of an iteration must not find young requests)
+  T ya[C::NV], yb[C::NV];         // observations of residual rows t+HB and t+1+HB, ping-pong: the buffer a row has consumed takes
+                                  // the request for the row after next (a whole iteration ahead of its wait, with the x row); no
+                                  // copies -- a rotation of loop-carried values makes the compiler wait for the young request at
+                                  // the loop's back edge
   T nva[S], nvb, nma, nmb;        // x row t+HD+1 on its way to the ring
   T p1[S], p2[S];                 // vertical half of B^T in flight: k0 zh[t-1] + k1 zh[t], and k0 zh[t]
   T cmk[C::WIN > 0 ? C::WIN : 1]; // RBD: window columns S .. S+WIN-1 behind the thread's cell, inside the image?
@@ -698,7 +752,7 @@ struct MState {
 // border corrections); RBD: the regulariser's windows leave the image at the right / bottom edge; SIMPLE: data term +
 // regulariser + gradient requested, IRLS weights present, one residual per pixel phase (no uniform branches, no loops);
 // OUT: row t is an output row of the band (the PRE rows before it only feed the rings).
-template <typename T, int S, int B, int REGK, int R, bool WD, int DM, bool RBD, bool SIMPLE, bool OUT, typename ArgsT>
+template <typename T, int S, int B, int REGK, int R, bool WD, int DM, bool RBD, bool SIMPLE, bool OUT, int PP, typename ArgsT>
 __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __restrict__ xs, T* __restrict__ cs,
                                        const T* __restrict__ csh, MState<T, S, MCfg<T, S, B, REGK, R>>& st, int t) {
   using C = MCfg<T, S, B, REGK, R>;
@@ -756,7 +810,7 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
     const int zr = t + HB;
     const bool count = zr >= b.R0 && zr < b.tend;
     T znew[S];
-    mz_row<T, S, B, C, DM, SIMPLE>(A, xr, zr, b.CJ0, lane, b.ybase, st.y, count, st.mk, znew, st.cost_data);
+    mz_row<T, S, B, C, DM, SIMPLE>(A, xr, zr, b.CJ0, lane, b.ybase, PP ? st.yb : st.ya, count, st.mk, znew, st.cost_data);
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
       if (B == 1) {
@@ -823,8 +877,6 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
 
   // ---------------- B: every request so far has landed ----------------
   m_put_x<T, S, C>(xs + st.ph * C::XROW, lane, st.nva, st.nvb, st.nma, st.nmb);  // x row t+HD+1 replaces row t-RU
-#pragma unroll
-  for (int v = 0; v < NV; ++v) st.y[v] = st.ynext[v];
   if (OUT && outg) {
     if (FULLEDGE) {
 #pragma unroll
@@ -844,7 +896,7 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
 
   // ---------------- D: request x row t+HD+2 and the observations of residual row t+2+HB ----------------
   m_issue_x<T, S, C, DM>(A, b, t + HD + 2, st.nva, st.nvb, st.nma, st.nmb);
-  if (want_data) m_issue_y<T, S, C, DM>(A, b, t + 2 + HB, st.ynext);
+  if (want_data) m_issue_y<T, S, C, DM>(A, b, t + 2 + HB, PP ? st.yb : st.ya);  // into the buffer this row has consumed
 
   st.ph = (st.ph + 1 == NRX) ? 0 : st.ph + 1;
   if (NRC > 0) st.phc = (st.phc + 1 == NRC) ? 0 : st.phc + 1;
@@ -871,11 +923,11 @@ __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T*
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) st.w[pc] = T(1);
 #pragma unroll
-  for (int v = 0; v < NV; ++v) st.y[v] = T(0);
+  for (int v = 0; v < NV; ++v) { st.ya[v] = T(0); st.yb[v] = T(0); }
 #pragma unroll
   for (int k = 0; k <= HD; ++k) m_issue_x<T, S, C, DM>(A, b, b.t0 + k, pva[k], pvb[k], pma[k], pmb[k]);
   if (want_reg) m_issue_w<T, S, DM>(A, b, b.t0, st.w);
-  if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + HB, st.y);
+  if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + HB, st.ya);
   // ---- left halo columns of 2*lambda*w*r ----
   if (halo_on) {
     march_halo_finish<T, S, REGK, R, C>(A, csh, lane, 0, hreg);
@@ -897,13 +949,19 @@ __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T*
   st.ph = 0; st.phc = 0;
   st.cost_data = 0.0; st.cost_reg = 0.0; st.gd = 0.0;
   m_issue_x<T, S, C, DM>(A, b, b.t0 + HD + 1, st.nva, st.nvb, st.nma, st.nmb);  // "D" of a virtual iteration t0 - 1
-#pragma unroll
-  for (int v = 0; v < NV; ++v) st.ynext[v] = T(0);
-  if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + 1 + HB, st.ynext);
+  if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + 1 + HB, st.yb);
+  // the PRE rows before the first output row, then the output rows two at a time (ping-pong observation buffers)
+  constexpr int PRE = C::PRE;
+  if (PRE >= 1) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, false, 0>(A, b, xs, cs, csh, st, b.t0);
+  if (PRE >= 2) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, false, 1>(A, b, xs, cs, csh, st, b.t0 + 1);
+  static_assert(PRE <= 2, "pre-rows are unrolled by hand");
+  int t = b.R0;
 #pragma unroll 1
-  for (int t = b.t0; t < b.R0; ++t) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, false>(A, b, xs, cs, csh, st, t);
-#pragma unroll 1
-  for (int t = b.R0; t < b.tend; ++t) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, true>(A, b, xs, cs, csh, st, t);
+  for (; t + 1 < b.tend; t += 2) {
+    m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, true, (PRE & 1)>(A, b, xs, cs, csh, st, t);
+    m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, true, (PRE & 1) ^ 1>(A, b, xs, cs, csh, st, t + 1);
+  }
+  if (t < b.tend) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, true, (PRE & 1)>(A, b, xs, cs, csh, st, t);
   cost_data = st.cost_data; cost_reg = st.cost_reg; gd = st.gd;
 }
 
@@ -983,6 +1041,13 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
   ts1 = __builtin_amdgcn_s_memrealtime();
   ts2 = ts1;
 #endif
+  // De-phase the waves: they all start within half a microsecond and would march in lock-step -- the whole chip
+  // requesting, then the whole chip computing.  A start delay of up to A.stagger * 64 cycles, by wave index.
+  if (A.stagger > 0) {
+    const unsigned hsh = ((unsigned)gw * 2654435761u) >> 16;
+    const unsigned slp = (hsh % (unsigned)A.stagger);
+    for (unsigned i = 0; i < slp; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   double cost_data = 0.0, cost_reg = 0.0, gd = 0.0;
   // three code paths (each variant more in one kernel costs every variant registers): interior; first / last strips away
   // from the image top / bottom (column masks only; the regulariser's right-edge masks ride along); everything else
@@ -1119,8 +1184,10 @@ __global__ __launch_bounds__(64) void k_march_border(MArgs<T, B, NP> A) {
 // ---------------------------------------------------------------------------------------------------------
 // host side
 static int g_march_end_duty = 1;
+static int g_march_stagger = 0;
 #ifdef SRMAP_DEV_INSTANCES
 extern "C" void srmap_dev_set_end_duty(int v) { g_march_end_duty = v; }
+extern "C" void srmap_dev_set_stagger(int v) { g_march_stagger = v; }
 static unsigned long long* g_march_dbg = nullptr;
 extern "C" void srmap_dev_set_march_dbg(void* p) { g_march_dbg = (unsigned long long*)p; }
 #endif
@@ -1222,6 +1289,7 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     A.nduty = (int)std::min<long long>(A.ntasks_total, cap);
   }
   A.one_round = simple ? 1 : 0;
+  A.stagger = g_march_stagger;
   A.n_wave_partials = nwaves;
   A.n_partials = nwaves + A.ntasks_total;
   const bool finish = finish_ok && z.d_mpart != nullptr && (size_t)A.n_partials <= z.mpart_cap;  // else the caller reduces the partials (two stages)
