@@ -58,11 +58,12 @@ enum {
 };
 
 /* Kernel family selection (for tests and A/B measurements).  AUTO picks the
- * fastest family the problem geometry admits: the single-launch marching-wave
- * kernel (integer shifts, scale 2..4, blur size 1 or 3), the workgroup-tile
- * kernels (the same geometries plus sub-pixel shifts), else the direct kernels.
- * TILED / MARCH force one family and fail with SRMAP_EUNSUPPORTED when it does
- * not cover the problem. */
+ * workgroup-tile kernels whenever the problem geometry admits them (scale
+ * 2..4, blur size 1 or 3, integer or sub-pixel shifts), else the direct
+ * kernels.  MARCH is the opt-in single-launch marching-wave implementation of
+ * the integer-shift geometries of the BASELINE configurations (DESIGN.md
+ * section 3.4).  TILED / MARCH force one family and fail with
+ * SRMAP_EUNSUPPORTED when it does not cover the problem. */
 typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */

@@ -30,10 +30,6 @@ namespace srmap {
 
 namespace {
 
-// A granule that has not been published yet holds this NaN pattern (both 32-bit halves equal: hipMemsetD32 writes it).
-constexpr unsigned kMarchSentinel32 = 0x7FF9ABCDu;
-constexpr unsigned long long kMarchSentinel = ((unsigned long long)kMarchSentinel32 << 32) | kMarchSentinel32;
-
 constexpr int kMarchMaxRB = 64;   // rows per band (the left-halo-column table in LDS is sized for it)
 constexpr int kMarchMinRB = 4;
 
@@ -79,7 +75,6 @@ struct MArgs : ZArgs<T, B, NP> {
   int duty_at_end;      // no wave consumes border corrections: the border tasks are picked up by waves that have finished
   unsigned long long task_base;  // value of the task counter (ctr64) at launch
   unsigned long long* ctr64;     // monotonic task counter of the end-of-wave pick-up
-  int stagger;          // start delay spread, in units of 64 cycles (0 = none)
   int one_round;        // every pixel phase owns exactly one residual (K = S*S frames with distinct phases)
   int finish;           // 1: the last arriver reduces the partials into cost_out
   unsigned* ctr;        // [0] ticket, [1] duty waves done, [2] a border wait timed out
@@ -111,11 +106,6 @@ __device__ __forceinline__ void m_pin(T (&a)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]) : : "memory");
 }
-
-template <typename U>
-__device__ __forceinline__ U ld_agent(const U* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename U>
-__device__ __forceinline__ void st_agent(U* p, U v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The frame table's by-value part (counts, round 0) is indexed with the row phase of the current row: a run-time index.
 // Reading it through `A` makes the argument block an indexed aggregate, and once the kernel is large the compiler keeps
@@ -737,6 +727,9 @@ struct MState {
   T mk[S];                        // in-image mask of the thread's pixels
   int ph, phc;                    // ring phases: window row i of x lives in slot (ph + i) mod NRX, of 2*lambda*w*r in (phc + i) mod NRC
   double cost_data, cost_reg, gd;
+#ifdef SRMAP_DEV_INSTANCES
+  unsigned long long t_wait, t_pass1, t_z, t_p2;  // development: cycles spent waiting at B / in the phases of A
+#endif
 };
 
 // One row.  The counter of outstanding memory operations drains in order for loads, but not between loads and
@@ -948,6 +941,9 @@ __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T*
   for (int pc = 0; pc < S; ++pc) { st.p1[pc] = T(0); st.p2[pc] = T(0); }
   st.ph = 0; st.phc = 0;
   st.cost_data = 0.0; st.cost_reg = 0.0; st.gd = 0.0;
+#ifdef SRMAP_DEV_INSTANCES
+  st.t_wait = 0;
+#endif
   m_issue_x<T, S, C, DM>(A, b, b.t0 + HD + 1, st.nva, st.nvb, st.nma, st.nmb);  // "D" of a virtual iteration t0 - 1
   if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + 1 + HB, st.yb);
   // the PRE rows before the first output row, then the output rows two at a time (ping-pong observation buffers)
@@ -963,6 +959,9 @@ __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T*
   }
   if (t < b.tend) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, true, (PRE & 1)>(A, b, xs, cs, csh, st, t);
   cost_data = st.cost_data; cost_reg = st.cost_reg; gd = st.gd;
+#ifdef SRMAP_DEV_INSTANCES
+  if (A.dbg != nullptr && lane == 0) A.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 1] = st.t_wait;
+#endif
 }
 
 // SIMPLE (host-decided): data term + fused regulariser + gradient requested, IRLS weights present, one residual per
@@ -1041,13 +1040,6 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
   ts1 = __builtin_amdgcn_s_memrealtime();
   ts2 = ts1;
 #endif
-  // De-phase the waves: they all start within half a microsecond and would march in lock-step -- the whole chip
-  // requesting, then the whole chip computing.  A start delay of up to A.stagger * 64 cycles, by wave index.
-  if (A.stagger > 0) {
-    const unsigned hsh = ((unsigned)gw * 2654435761u) >> 16;
-    const unsigned slp = (hsh % (unsigned)A.stagger);
-    for (unsigned i = 0; i < slp; ++i) __builtin_amdgcn_s_sleep(1);
-  }
   double cost_data = 0.0, cost_reg = 0.0, gd = 0.0;
   // three code paths (each variant more in one kernel costs every variant registers): interior; first / last strips away
   // from the image top / bottom (column masks only; the regulariser's right-edge masks ride along); everything else
@@ -1066,7 +1058,7 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
 #ifdef SRMAP_DEV_INSTANCES
   if (A.dbg != nullptr && lane == 0) {
     unsigned long long* d = A.dbg + (size_t)gw * 8;
-    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = __builtin_amdgcn_s_memrealtime();
+    d[0] = ts0; d[2] = ts2; d[3] = ts3; d[4] = __builtin_amdgcn_s_memrealtime();
     d[5] = (unsigned long long)slow | ((unsigned long long)0 << 1) | ((unsigned long long)b.has_ring << 2) | ((unsigned long long)reg_border << 3) | ((unsigned long long)dm << 4);
     d[6] = ((unsigned long long)strip << 32) | (unsigned)band;
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1117,7 +1109,7 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int i = base + u * 64 + lane;
-            missing |= (i < n) && a[u] == kMarchSentinel;
+            missing |= (i < n) && a[u] == kSentinel;
           }
           if (!__any(missing)) break;
           if (++spins > (1u << 14)) { timed_out = true; break; }
@@ -1133,9 +1125,9 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
       if (pass == 0) v = acc; else v2 = acc;
     }
     // re-arm: the next evaluation finds every granule unpublished
-    for (int i = lane; i < A.n_partials; i += 64) st_agent(reinterpret_cast<unsigned long long*>(A.mpart) + i, kMarchSentinel);
+    for (int i = lane; i < A.n_partials; i += 64) st_agent(reinterpret_cast<unsigned long long*>(A.mpart) + i, kSentinel);
     if (WD)
-      for (int i = lane; i < A.n_wave_partials; i += 64) st_agent(reinterpret_cast<unsigned long long*>(A.mpart_gd) + i, kMarchSentinel);
+      for (int i = lane; i < A.n_wave_partials; i += 64) st_agent(reinterpret_cast<unsigned long long*>(A.mpart_gd) + i, kSentinel);
     if (lane == 0) {
       const unsigned bad = ld_agent(&A.ctr[2]);
       if (bad || timed_out) v = __builtin_nan("");  // a wait timed out: the evaluation is not trustworthy
@@ -1183,11 +1175,9 @@ __global__ __launch_bounds__(64) void k_march_border(MArgs<T, B, NP> A) {
 
 // ---------------------------------------------------------------------------------------------------------
 // host side
-static int g_march_end_duty = 1;
-static int g_march_stagger = 0;
+static int g_march_end_duty = 1;  // development builds can switch the end-of-wave pick-up of border tasks off
 #ifdef SRMAP_DEV_INSTANCES
 extern "C" void srmap_dev_set_end_duty(int v) { g_march_end_duty = v; }
-extern "C" void srmap_dev_set_stagger(int v) { g_march_stagger = v; }
 static unsigned long long* g_march_dbg = nullptr;
 extern "C" void srmap_dev_set_march_dbg(void* p) { g_march_dbg = (unsigned long long*)p; }
 #endif
@@ -1217,7 +1207,7 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   }
   A.lambda = T(0);
   for (int i = 0; i < C::NP; ++i) A.powtab[i] = T(1);
-  if (REGK != 0) {
+  if (REGK != 0 && (terms & SRMAP_TERM_REG) && z.reg_index >= 0) {
     const RegSpec& rs = p->reg[z.reg_index];
     A.lambda = (T)rs.lambda;
     if (REGK == 2) for (int i = 0; i < C::NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
@@ -1289,7 +1279,6 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     A.nduty = (int)std::min<long long>(A.ntasks_total, cap);
   }
   A.one_round = simple ? 1 : 0;
-  A.stagger = g_march_stagger;
   A.n_wave_partials = nwaves;
   A.n_partials = nwaves + A.ntasks_total;
   const bool finish = finish_ok && z.d_mpart != nullptr && (size_t)A.n_partials <= z.mpart_cap;  // else the caller reduces the partials (two stages)
@@ -1331,42 +1320,37 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   return SRMAP_OK;
 }
 
-template <typename T, int S, int B>
-static int dispatch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
-                      const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, bool finish, bool* fin,
-                      hipStream_t st, const T* dv, double* pgd, bool publish) {
+// The instances compiled: the marching kernel is an opt-in implementation (SRMAP_IMPL_MARCH), built for the geometries of
+// the BASELINE configurations -- (scale, blur size, fused regulariser kind, BTV range).
 #ifdef SRMAP_DEV_INSTANCES
-  if (regk == 2 && regr == 3) return launch_m<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, finish, fin, st, dv, pgd, publish);
-  return set_error(p->ctx, SRMAP_EUNSUPPORTED, "development build: instance not compiled");
+#define SRMAP_MARCH_INSTANCES(X) X(4, 3, 2, 3)
 #else
-  if (regk == 1) return launch_m<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, finish, fin, st, dv, pgd, publish);
-  if (regk == 2 && regr == 1) return launch_m<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, finish, fin, st, dv, pgd, publish);
-  if (regk == 2 && regr == 2) return launch_m<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, finish, fin, st, dv, pgd, publish);
-  if (regk == 2 && regr == 3) return launch_m<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, finish, fin, st, dv, pgd, publish);
-  return launch_m<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, finish, fin, st, dv, pgd, publish);
+#define SRMAP_MARCH_INSTANCES(X) X(4, 3, 2, 3) X(4, 1, 2, 3) X(3, 1, 1, 0) X(2, 1, 1, 0)
 #endif
+
+bool march_has_instance(int S, int B, int regk, int regr) {
+#define X(s_, b_, k_, r_) if (S == s_ && B == b_ && (regk == 0 || (regk == k_ && regr == r_))) return true;
+  SRMAP_MARCH_INSTANCES(X)
+#undef X
+  return false;
 }
 
 // One launch: data term + the fused regulariser + border corrections (+ the cost reduction when `finish`).
-// *nblocks = partials written (the caller reduces them when !finish).
+// *nblocks = partials written (the caller reduces them when !*finished).
 template <typename T>
 int launch_eval_march(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g, const T* wts,
                       int regk, int regr, double* partials, int* nblocks, bool finish, bool* fin, hipStream_t st,
                       const T* dv, double* pgd, bool publish) {
   const ZPlan& z = *static_cast<const ZPlan*>(p->zplan);
   const int S = geo.s, B = geo.b;
-#ifdef SRMAP_DEV_INSTANCES
-  if (S == 4 && B == 3 && sizeof(T) == 8) return dispatch_m<T, 4, 3>(p, geo, obs_c0, terms, x, g, wts, z, regk, regr, partials, nblocks, finish, fin, st, dv, pgd, publish);
-  return set_error(p->ctx, SRMAP_EUNSUPPORTED, "development build: instance not compiled");
-#else
-  if (S == 2 && B == 1) return dispatch_m<T, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, regk, regr, partials, nblocks, finish, fin, st, dv, pgd, publish);
-  if (S == 2 && B == 3) return dispatch_m<T, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, regk, regr, partials, nblocks, finish, fin, st, dv, pgd, publish);
-  if (S == 3 && B == 1) return dispatch_m<T, 3, 1>(p, geo, obs_c0, terms, x, g, wts, z, regk, regr, partials, nblocks, finish, fin, st, dv, pgd, publish);
-  if (S == 3 && B == 3) return dispatch_m<T, 3, 3>(p, geo, obs_c0, terms, x, g, wts, z, regk, regr, partials, nblocks, finish, fin, st, dv, pgd, publish);
-  if (S == 4 && B == 1) return dispatch_m<T, 4, 1>(p, geo, obs_c0, terms, x, g, wts, z, regk, regr, partials, nblocks, finish, fin, st, dv, pgd, publish);
-  if (S == 4 && B == 3) return dispatch_m<T, 4, 3>(p, geo, obs_c0, terms, x, g, wts, z, regk, regr, partials, nblocks, finish, fin, st, dv, pgd, publish);
-  return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no marching kernel for scale %d blur %d", S, B);
-#endif
+  // regk == 0 (the fused regulariser is not part of this evaluation): any instance of the geometry serves, its
+  // regulariser switched off by `terms`
+#define X(s_, b_, k_, r_)                                                                                              \
+  if (S == s_ && B == b_ && (regk == 0 || (regk == k_ && regr == r_)))                                                  \
+    return launch_m<T, s_, b_, k_, r_>(p, geo, obs_c0, terms, x, g, wts, z, partials, nblocks, finish, fin, st, dv, pgd, publish);
+  SRMAP_MARCH_INSTANCES(X)
+#undef X
+  return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no marching kernel for scale %d blur %d regulariser %d/%d", S, B, regk, regr);
 }
 
 template int launch_eval_march<float>(srmap_problem*, const Geometry&, int, unsigned, const float*, float*, const float*,
@@ -1381,41 +1365,19 @@ static void preload_m() {
   hipFuncAttributes attr;
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false, false>));
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true, false>));
-  if (REGK != 0) {
-    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false, true>));
-    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true, true>));
-  }
-}
-template <typename T, int S, int B>
-static void preload_mreg(int regk, int regr) {
-#ifdef SRMAP_DEV_INSTANCES
-  if (regk == 2 && regr == 3) preload_m<T, S, B, 2, 3>();
-#else
-  preload_m<T, S, B, 0, 0>();
-  if (regk == 1) preload_m<T, S, B, 1, 0>();
-  if (regk == 2 && regr == 1) preload_m<T, S, B, 2, 1>();
-  if (regk == 2 && regr == 2) preload_m<T, S, B, 2, 2>();
-  if (regk == 2 && regr == 3) preload_m<T, S, B, 2, 3>();
-#endif
-}
-template <typename T>
-static void preload_msb(int S, int B, int regk, int regr) {
-#ifdef SRMAP_DEV_INSTANCES
-  if (S == 4 && B == 3 && sizeof(T) == 8) preload_mreg<T, 4, 3>(regk, regr);
-#else
-  if (S == 2 && B == 1) preload_mreg<T, 2, 1>(regk, regr);
-  else if (S == 2 && B == 3) preload_mreg<T, 2, 3>(regk, regr);
-  else if (S == 3 && B == 1) preload_mreg<T, 3, 1>(regk, regr);
-  else if (S == 3 && B == 3) preload_mreg<T, 3, 3>(regk, regr);
-  else if (S == 4 && B == 1) preload_mreg<T, 4, 1>(regk, regr);
-  else if (S == 4 && B == 3) preload_mreg<T, 4, 3>(regk, regr);
-#endif
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, false, true>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_march<T, S, B, REGK, R, true, true>));
 }
 void march_preload(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
-  if (!z || z->subpix) return;
-  if (p->dtype == SRMAP_F32) preload_msb<float>(z->S, z->B, z->regk, z->regr);
-  else preload_msb<double>(z->S, z->B, z->regk, z->regr);
+  if (!z || z->subpix || p->impl != SRMAP_IMPL_MARCH) return;
+#define X(s_, b_, k_, r_)                                                             \
+  if (z->S == s_ && z->B == b_ && z->regk == k_ && (k_ != 2 || z->regr == r_)) {       \
+    if (p->dtype == SRMAP_F32) preload_m<float, s_, b_, k_, r_>();                     \
+    else preload_m<double, s_, b_, k_, r_>();                                          \
+  }
+  SRMAP_MARCH_INSTANCES(X)
+#undef X
 }
 
 bool march_alloc(srmap_problem* p, ZPlan* z) {
@@ -1428,7 +1390,7 @@ bool march_alloc(srmap_problem* p, ZPlan* z) {
   // which the caller's two-stage reduction is used anyway
   const size_t cap = std::min<size_t>(march_partials_needed(p), (size_t)16384);
   if (hipMalloc((void**)&z->d_mpart, 2 * cap * sizeof(double)) != hipSuccess) return false;
-  if (hipMemsetD32((hipDeviceptr_t)z->d_mpart, (int)kMarchSentinel32, 4 * cap) != hipSuccess) return false;
+  if (hipMemsetD32((hipDeviceptr_t)z->d_mpart, (int)kSentinel32, 4 * cap) != hipSuccess) return false;
   z->mpart_cap = cap;
   return true;
 }

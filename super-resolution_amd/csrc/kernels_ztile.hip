@@ -82,8 +82,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);
     else if (threadIdx.x == 0) {
       const int nbb = A.nby * gridDim.x;
-      A.partials[(size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
-      if (WD) A.partials_gd[(size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx] = 0.0;
+      put_partial<WD>(A, (size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx, 0.0, 0.0);
     }
     return;
   }
@@ -324,8 +323,12 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 #pragma unroll
       for (int i = 0; i < C::NW; ++i) { c += red[0][i]; if (WD) d += red[1][i]; }
       const size_t b = ((size_t)blockIdx.z * nby_t + by) * gridDim.x + blockIdx.x;
-      A.partials[b] = c;
-      if (WD) A.partials_gd[b] = d;
+      put_partial<WD>(A, b, c, d);
+    }
+    // in-kernel finish: the last workgroup of the grid gathers the granules of the evaluation
+    if (A.mfinish && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) {
+      __syncthreads();
+      finish_block<WD, C::NT>(A, &red[0][0]);
     }
   }
 }
@@ -614,7 +617,7 @@ bool ztile_plan(srmap_problem* p) {
 
 bool ztile_covers_march(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
-  return z != nullptr && !z->subpix;
+  return z != nullptr && !z->subpix && march_has_instance(z->S, z->B, z->regk, z->regr);
 }
 
 size_t ztile_partials_needed(const srmap_problem* p) {
@@ -626,10 +629,12 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   return std::max(tiles + ring, march_partials_needed(p));
 }
 
+struct MFin { bool on, publish; };  // in-kernel finish of this launch; publish {cost, g.d} to the solver's host words
+
 template <typename T, int S, int B, int REGK, int R>
 static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                     const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st, const T* dvec,
-                    double* partials_gd) {
+                    double* partials_gd, MFin mfin) {
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
   A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
@@ -677,6 +682,15 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     grid.y += A.nby;
   }
   A.rbuf = nullptr; A.spw = z.d_spw; A.Dr = z.Dr;
+  A.mfinish = mfin.on ? 1 : 0;
+  A.n_partials = n_tile_partials + nbb * (int)grid.z;
+  A.mpart = z.d_mpart;
+  A.mpart_gd = z.d_mpart ? z.d_mpart + z.mpart_cap : nullptr;
+  A.cost_out = p->d_cost;
+  A.pub = mfin.publish ? p->eval_pub : nullptr;
+  A.tag_slot = p->eval_pub_tag_slot;
+  A.tag = p->eval_pub_tag;
+  if (mfin.on && (size_t)A.n_partials > z.mpart_cap) return set_error(p->ctx, SRMAP_EHIP, "granule capacity");
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
     A.rbuf = (const T*)p->d_resid;
     A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
@@ -719,7 +733,7 @@ static void preload_sb(int S, int B, int regk, int regr) {
 void ztile_preload(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   if (!z) return;
-  if (!z->subpix) march_preload(p);
+  march_preload(p);
   if (p->dtype == SRMAP_F32) preload_sb<float>(z->S, z->B, z->regk, z->regr);
   else preload_sb<double>(z->S, z->B, z->regk, z->regr);
 }
@@ -727,12 +741,12 @@ void ztile_preload(const srmap_problem* p) {
 template <typename T, int S, int B>
 static int dispatch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                       const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, hipStream_t st,
-                      const T* dv, double* pgd) {
-  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
-  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
-  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
-  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
-  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd);
+                      const T* dv, double* pgd, MFin mfin) {
+  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
 }
 
 template <typename T>
@@ -779,19 +793,25 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
   p->gd_valid = false;
   p->eval_published = false;
-  // marching waves (kernels_march.hip): everything but sub-pixel shifts; SRMAP_IMPL_TILED keeps the workgroup tiles
-  const bool march = !z.subpix && p->impl != SRMAP_IMPL_TILED;
+  // marching waves (kernels_march.hip): an opt-in implementation (SRMAP_IMPL_MARCH) of the integer-shift geometries
+  const bool march = p->impl == SRMAP_IMPL_MARCH && !z.subpix;
   bool march_finished = false;
+  // tiles: the cost reduction inside the kernel (no finish launch) when no in-image pixel of the border frame needs a
+  // correction, no further regulariser kernel follows and the granules suffice
+  MFin mfin;
+  mfin.on = !march && !z.subpix && !more_regs && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
+            (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0));
+  mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
   if (march) {
     rc = launch_eval_march<T>(p, geo, obs_c0, zterms, x, g, wts, regk, regr, partials, &nb, !more_regs, &march_finished, st,
                               dv, pgd, with_d && p->eval_pub != nullptr);
   }
-  else if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
-  else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
-  else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
-  else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
-  else if (S == 4 && B == 1) rc = dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
-  else if (S == 4 && B == 3) rc = dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd);
+  else if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+  else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+  else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+  else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+  else if (S == 4 && B == 1) rc = dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+  else if (S == 4 && B == 3) rc = dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
   else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
   if (rc) return rc;
   if (sp_data) {
@@ -831,6 +851,12 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
       return SRMAP_OK;
     }
     *nblocks = total;
+    return SRMAP_OK;
+  }
+  if (mfin.on) {  // reduced by the last workgroup of the tile kernel
+    p->gd_valid = with_d;  // d_cost[1] = g.d
+    p->eval_published = mfin.publish;
+    *nblocks = 0;
     return SRMAP_OK;
   }
   // finish: border corrections of g + the fixed-order cost reduction, one launch

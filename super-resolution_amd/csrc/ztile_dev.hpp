@@ -134,6 +134,93 @@ __device__ __forceinline__ int ring_index(int qr, int qc, int W, int H, const Ri
   return -1;
 }
 
+// A granule that has not been published yet holds this NaN pattern (both 32-bit halves equal: hipMemsetD32 writes it).
+constexpr unsigned kSentinel32 = 0x7FF9ABCDu;
+constexpr unsigned long long kSentinel = ((unsigned long long)kSentinel32 << 32) | kSentinel32;
+
+// device-scope relaxed accesses: write-through stores / L1-bypassing loads (MI355X_MICROARCH.md, inter-workgroup visibility)
+template <typename U>
+__device__ __forceinline__ U ld_agent(const U* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename U>
+__device__ __forceinline__ void st_agent(U* p, U v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// cost (and g.d) partial number idx of the evaluation
+template <bool WD, typename ArgsT>
+__device__ __forceinline__ void put_partial(const ArgsT& A, size_t idx, double c, double d) {
+  if (A.mfinish) {
+    st_agent(&A.mpart[idx], c);
+    if (WD) st_agent(&A.mpart_gd[idx], d);
+  } else {
+    A.partials[idx] = c;
+    if (WD) A.partials_gd[idx] = d;
+  }
+}
+
+// In-kernel finish, executed by ONE workgroup (the last of the grid: dispatched last, among the last to finish) after
+// its own work: poll until no granule holds the sentinel, add the granules in index order (deterministic), re-arm
+// them, publish the cost.  Every other workgroup just publishes and leaves: no ticket, no wait on its own stores.
+template <bool WD, int NT, typename ArgsT>
+__device__ __forceinline__ void finish_block(const ArgsT& A, double* red /* LDS, 2 * NT / 64 doubles */) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double tot[2] = {0.0, 0.0};
+  bool timed_out = false;
+  for (int pass = 0; pass < (WD ? 2 : 1); ++pass) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(pass == 0 ? A.mpart : A.mpart_gd);
+    double acc = 0.0;
+    for (int base = 0; base < A.n_partials; base += NT * 8) {
+      unsigned long long a[8];
+      unsigned spins = 0;
+      while (true) {
+        bool missing = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * NT + tid;
+          a[u] = ld_agent(&src[i < A.n_partials ? i : base]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * NT + tid;
+          missing |= (i < A.n_partials) && a[u] == kSentinel;
+        }
+        if (!__syncthreads_or(missing)) break;
+        if (++spins > (1u << 14)) { timed_out = true; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * NT + tid;
+        acc += (i < A.n_partials) ? __longlong_as_double((long long)a[u]) : 0.0;
+      }
+    }
+    acc = wave_sum_d(acc);
+    __syncthreads();
+    if (lane == 0) red[wid] = acc;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    tot[pass] = t;
+  }
+  // re-arm: the next evaluation finds every granule unpublished
+  for (int i = tid; i < A.n_partials; i += NT) {
+    st_agent(reinterpret_cast<unsigned long long*>(A.mpart) + i, kSentinel);
+    if (WD) st_agent(reinterpret_cast<unsigned long long*>(A.mpart_gd) + i, kSentinel);
+  }
+  if (tid == 0) {
+    double v = tot[0];
+    if (timed_out) v = __builtin_nan("");  // a granule never arrived: the evaluation is not trustworthy
+    A.cost_out[0] = v;
+    if (WD) {
+      A.cost_out[1] = tot[1];
+      if (A.pub != nullptr) {  // solver line search: {cost, g.d} straight to the host-mapped words, then the arrival tag
+        A.pub[0] = v;
+        A.pub[1] = tot[1];
+        __threadfence_system();
+        *(volatile double*)A.tag_slot = A.tag;
+      }
+    }
+  }
+}
+
 template <typename T> struct BorderArgs;
 
 template <typename T, int B, int NP>
@@ -174,6 +261,16 @@ struct ZArgs {
   const double* spw;     //   bilinear tap weight of every table entry, [MS][S][S]
   int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
   RingRects ring;        // border frame rectangles (border blocks / tasks, corrections)
+  // ---- in-kernel finish (no second launch): partials leave as write-through granules, the last block of the grid
+  // gathers them (see m_finish_block) ----
+  int mfinish;           // 1: granules + in-kernel reduction; 0: plain partials, reduced by k_finish_eval / the caller
+  int n_partials;        // granules of the evaluation
+  double* mpart;         // cost granules [n_partials]; the sentinel pattern = not yet published
+  double* mpart_gd;      // g.d granules [n_partials] (WD)
+  double* cost_out;      // [0] cost, [1] g.d
+  double* pub;           // solver line search: host-mapped {cost, g.d}, then the arrival tag
+  double* tag_slot;
+  double tag;
 };
 
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
@@ -781,7 +878,8 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
       double sum = 0.0;
       for (int i = 0; i < NT / 64; ++i) sum += red[i];
       const int nbb = A.nby * gridDim.x;
-      A.partials[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = (double)(S * S) * sum;
+      if (!WD) put_partial<false>(A, (size_t)A.n_tile_partials + (size_t)ch * nbb + bidx, (double)(S * S) * sum, 0.0);
+      else red[NT / 64] = (double)(S * S) * sum;
     }
     if (WD) {
       double w2 = gdc;
@@ -794,7 +892,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
         double sum = 0.0;
         for (int i = 0; i < NT / 64; ++i) sum += red[i];
         const int nbb = A.nby * gridDim.x;
-        A.partials_gd[(size_t)A.n_tile_partials + (size_t)ch * nbb + bidx] = sum;
+        put_partial<true>(A, (size_t)A.n_tile_partials + (size_t)ch * nbb + bidx, red[NT / 64], sum);
       }
     }
   }
@@ -843,5 +941,6 @@ int launch_eval_march(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
 size_t march_partials_needed(const srmap_problem* p);
 bool march_alloc(srmap_problem* p, ZPlan* z);   // counters and granules of the plan
 void march_preload(const srmap_problem* p);
+bool march_has_instance(int S, int B, int regk, int regr);  // compiled instances of the (opt-in) marching kernel
 
 }  // namespace srmap

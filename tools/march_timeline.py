@@ -30,9 +30,10 @@ d = d[d[:, 0] > 0]
 n = len(d)
 t0 = d[:, 0].min()
 tick = 1e-2  # s_memrealtime: 100 MHz -> 10 ns
-st = (d[:, 0] - t0) * tick; pro = (d[:, 1] - d[:, 0]) * tick; fill = (d[:, 2] - d[:, 1]) * tick
+st = (d[:, 0] - t0) * tick; twait = d[:, 1].astype(np.float64); pro = (d[:, 2] - d[:, 0]) * tick; fill = pro * 0
 loop = (d[:, 3] - d[:, 2]) * tick; tail = (d[:, 4] - d[:, 3]) * tick; end = (d[:, 4] - t0) * tick
 slow = (d[:, 5] & 1) == 1; duty = (d[:, 5] & 2) == 2; ring = (d[:, 5] & 4) == 4
+print("cycles waiting at B per wave: mean %.0f min %.0f max %.0f (of ~%.0f cycles of band time at 2.4 GHz)" % (twait.mean(), twait.min(), twait.max(), loop.mean() * 2400))
 print("waves %d, kernel span %.2f us (first start -> last end)" % (n, end.max()))
 def desc(name, m):
     if m.sum() == 0: return
