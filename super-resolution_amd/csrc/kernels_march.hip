@@ -668,12 +668,12 @@ __device__ __forceinline__ void m_put_x(T* __restrict__ row, int lane, const T (
   for (int pc = 0; pc < S; ++pc) row[pc * C::XC + lane] = va[pc] * ma;
   if (lane < EXTRA * S) row[(lane % S) * C::XC + C::CW + lane / S] = vb * mb;
 }
-template <typename T, int S, int DM, typename ArgsT>
+template <typename T, int S, int DM, bool SIMPLE, typename ArgsT>
 __device__ __forceinline__ void m_issue_w(const ArgsT& A, const MBand<T>& b, int gr, T (&wv)[S]) {
   constexpr bool SLOW = DM != 0;
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) wv[pc] = T(1);
-  if (b.wplane == nullptr) return;  // uniform
+  if (!SIMPLE && b.wplane == nullptr) return;  // uniform (SIMPLE: the weights exist)
   // SLOW: rows / lanes outside the image request element 0 (their values are never used): no branch around a load
   const bool ok = !SLOW || ((DM == 1 || (unsigned)gr < (unsigned)A.H) && b.gc0 < A.W);
   const T* wp = b.wplane + (ok ? (size_t)gr * A.W + b.gc0 : (size_t)0);
@@ -769,6 +769,9 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
     cw[i] = cs + sl * C::CROW + lane;
   }
 
+#ifdef SRMAP_DEV_INSTANCES
+  const unsigned long long ck0 = __builtin_readcyclecounter();
+#endif
   // ---------------- A ----------------
   T dreg[S], cq[S];
 #pragma unroll
@@ -786,7 +789,7 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
   T c2[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) c2[pc] = T(2) * (A.lambda * st.w[pc]);
-  if (reg_row) m_issue_w<T, S, DM>(A, b, t + 1, st.w);  // weights of the next row into the same registers
+  if (reg_row) m_issue_w<T, S, DM, SIMPLE>(A, b, t + 1, st.w);  // weights of the next row into the same registers
 
   T acc[S];
 #pragma unroll
@@ -823,6 +826,9 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
     if (B > 1) { m_pin(st.p1); m_pin(st.p2); }
   }
 
+#ifdef SRMAP_DEV_INSTANCES
+  const unsigned long long ck1 = __builtin_readcyclecounter();
+#endif
   // regulariser pass 1, row t
   if (reg_row) {
     T* csrow = cw[NRC > 0 ? NRC - 1 : 0];
@@ -853,6 +859,9 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
     m_pin(acc);
   }
 
+#ifdef SRMAP_DEV_INSTANCES
+  const unsigned long long ck2 = __builtin_readcyclecounter();
+#endif
   // row t: data gradient, pass 2
   if (OUT && outg) {
     if (want_reg && RU > 0) {
@@ -868,7 +877,13 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
     m_pin(acc);
   }
 
+#ifdef SRMAP_DEV_INSTANCES
+  const unsigned long long ck3 = __builtin_readcyclecounter();
+#endif
   // ---------------- B: every request so far has landed ----------------
+  // An explicit full drain the compiler accounts for: left to itself it waits here for the x row only and then, at the top
+  // of the next iteration, for the weights with a count that also drains the stores and requests issued a moment before.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   m_put_x<T, S, C>(xs + st.ph * C::XROW, lane, st.nva, st.nvb, st.nma, st.nmb);  // x row t+HD+1 replaces row t-RU
   if (OUT && outg) {
     if (FULLEDGE) {
@@ -891,6 +906,12 @@ __device__ __forceinline__ void m_step(const ArgsT& A, const MBand<T>& b, T* __r
   m_issue_x<T, S, C, DM>(A, b, t + HD + 2, st.nva, st.nvb, st.nma, st.nmb);
   if (want_data) m_issue_y<T, S, C, DM>(A, b, t + 2 + HB, PP ? st.yb : st.ya);  // into the buffer this row has consumed
 
+#ifdef SRMAP_DEV_INSTANCES
+  {
+    const unsigned long long ck4 = __builtin_readcyclecounter();
+    st.t_z += ck1 - ck0; st.t_pass1 += ck2 - ck1; st.t_p2 += ck3 - ck2; st.t_wait += ck4 - ck3;
+  }
+#endif
   st.ph = (st.ph + 1 == NRX) ? 0 : st.ph + 1;
   if (NRC > 0) st.phc = (st.phc + 1 == NRC) ? 0 : st.phc + 1;
 }
@@ -919,7 +940,7 @@ __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T*
   for (int v = 0; v < NV; ++v) { st.ya[v] = T(0); st.yb[v] = T(0); }
 #pragma unroll
   for (int k = 0; k <= HD; ++k) m_issue_x<T, S, C, DM>(A, b, b.t0 + k, pva[k], pvb[k], pma[k], pmb[k]);
-  if (want_reg) m_issue_w<T, S, DM>(A, b, b.t0, st.w);
+  if (want_reg) m_issue_w<T, S, DM, SIMPLE>(A, b, b.t0, st.w);
   if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + HB, st.ya);
   // ---- left halo columns of 2*lambda*w*r ----
   if (halo_on) {
@@ -942,7 +963,7 @@ __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T*
   st.ph = 0; st.phc = 0;
   st.cost_data = 0.0; st.cost_reg = 0.0; st.gd = 0.0;
 #ifdef SRMAP_DEV_INSTANCES
-  st.t_wait = 0;
+  st.t_wait = 0; st.t_z = 0; st.t_pass1 = 0; st.t_p2 = 0;
 #endif
   m_issue_x<T, S, C, DM>(A, b, b.t0 + HD + 1, st.nva, st.nvb, st.nma, st.nmb);  // "D" of a virtual iteration t0 - 1
   if (want_data) m_issue_y<T, S, C, DM>(A, b, b.t0 + 1 + HB, st.yb);
@@ -960,7 +981,10 @@ __device__ __forceinline__ void march_band(const ArgsT& A, const MBand<T>& b, T*
   if (t < b.tend) m_step<T, S, B, REGK, R, WD, DM, RBD, SIMPLE, true, (PRE & 1)>(A, b, xs, cs, csh, st, t);
   cost_data = st.cost_data; cost_reg = st.cost_reg; gd = st.gd;
 #ifdef SRMAP_DEV_INSTANCES
-  if (A.dbg != nullptr && lane == 0) A.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 1] = st.t_wait;
+  if (A.dbg != nullptr && lane == 0) {
+    unsigned long long* dd = A.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    dd[1] = st.t_wait; dd[6] = (st.t_z << 32) | (st.t_pass1 & 0xffffffffull); dd[7] = (st.t_p2 << 32) | (dd[7] & 0xffffffffull);
+  }
 #endif
 }
 
@@ -1060,10 +1084,10 @@ __global__ __launch_bounds__(64, 2) void k_eval_march(MArgs<T, B, MCfg<T, S, B, 
     unsigned long long* d = A.dbg + (size_t)gw * 8;
     d[0] = ts0; d[2] = ts2; d[3] = ts3; d[4] = __builtin_amdgcn_s_memrealtime();
     d[5] = (unsigned long long)slow | ((unsigned long long)0 << 1) | ((unsigned long long)b.has_ring << 2) | ((unsigned long long)reg_border << 3) | ((unsigned long long)dm << 4);
-    d[6] = ((unsigned long long)strip << 32) | (unsigned)band;
+    d[5] |= ((unsigned long long)strip << 40) | ((unsigned long long)band << 16);
     unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    d[7] = ((unsigned long long)xcc << 32) | hw;
+    d[7] = (d[7] & 0xffffffff00000000ull) | (hw & 0xfffffu) | ((unsigned long long)xcc << 24);
   }
 #endif
   if (A.finish) {
