@@ -4,40 +4,47 @@
 One "step" = one MAP gradient iteration = one ObjectiveFunction::ComputeAllTerms
 (data term over all K frames + IRLS-weighted regulariser, cost and gradient,
 reference src/optimization/objective_function.cpp:5-20) on device-resident
-synthetic inputs.
+synthetic inputs (SURVEY.md section 8d).
 
-N = 1 workload: BASELINE.json configs[1] -- 16-frame grayscale, 4x upscale to
-2048x2048 HR, Gaussian blur (3, sigma 1) + BTV (range 3, decay 0.5, lambda 0.01).
-N > 1 (one process per GPU, torch.distributed over RCCL): the path shards by
-channel (the reference's split_channels semantics, irls_map_solver.cpp:200-262):
-rank r owns channel r of an N-channel problem of the same per-channel geometry,
-so per-GPU work is fixed ("weak" scaling) and -- these being the reference's
-independent per-channel solves -- there is no collective in the timed region.
-`value` counts channel-iterations per second summed over ranks (at N = 1 this is
-plain iterations per second).  `--shard frames` runs the north-star's
-frame-sharded variant instead (each rank K/N frames of the SAME image + RCCL
-all-reduce of the HR gradient), `--shard rows` the row-band variant (halo rows of
-x exchanged with ncclSend / ncclRecv); both go through the library's own
-sharded evaluation (srmap_eval_sharded_device: the exchange is issued by the C
-ABI on the evaluation's stream) and are reported as strong scaling.
+Workload (--config): cfg2 = BASELINE.json configs[1], the configuration the metric
+is quoted on -- 16-frame grayscale, 4x upscale to 2048x2048 HR, Gaussian blur
+(3, sigma 1) + BTV (range 3, decay 0.5, lambda 0.01); cfg3 = configs[2] -- 16-frame
+RGB, 4x upscale to 4096x4096, BTV.  The SAME workload at every N ("strong" scaling).
 
-Timing: W untimed warm-up steps, then exactly K timed steps between barriers
-(defaults K = 2000, W = 200).  Before the warm-up the GPU is driven for
---clock-ramp-ms (default 100 ms) of untimed evaluations: an MI355X reaches its
-sustained clocks only after ~50 ms of load, and a 0.06 ms step measured in the
-first few hundred launches reads ~10 % slower than the same step in a running
-solver (the count is reported as config.clock_ramp_steps_before_warmup).
+N > 1 -- one process per GPU, torch.distributed over RCCL.  `python bench.py --gpus N`
+without a launcher re-executes itself under torch.distributed.run.  The path shards
+inside the C ABI (srmap_eval_sharded_device: the exchanges are issued by the library
+on the evaluation's stream):
+  * rows (default, the scaling path): rank r owns a band of HR rows; before every
+    evaluation the boundary rows of x travel to the two neighbours (ncclSend/ncclRecv,
+    both directions in one group);
+  * frames (the north-star's exchange, timed in the same run and reported under
+    "frames_variant"): rank r owns frames k = r (mod N) and a replica of x; the
+    HR gradient and the cost are all-reduced (ncclAllReduce, one group) after the
+    local evaluation (reference: alglib_objective.cpp:142-152 is where the gradient
+    of all frames meets).
+  * --shard channels: N independent channels (the reference's split_channels
+    semantics), no collective -- an explicit option only, weak scaling.
+
+Timing: W untimed warm-up steps, then K timed steps between barriers, max over
+ranks.  A timed region shorter than --min-timed-ms (50 ms) is extended to whole
+multiples of K steps (config.timed_steps); before the warm-up the GPU is driven
+for --clock-ramp-ms of untimed evaluations (an MI355X reaches its sustained
+clocks only after ~50 ms of load).
 
 Prints ONE JSON line on rank 0 (see the task contract), including
-  "roofline":     algorithmic bytes of one step / mean step time vs 8 TB/s HBM
-  "cpu_baseline": the CPU oracle (a port of the reference, oracle/) timed on
-                  this host on a bounded sample of the same workload.
+  "roofline":     algorithmic bytes of one step / mean device time per step vs 8 TB/s
+  "cpu_baseline": the CPU oracle (a port of the reference, oracle/) timed on this
+                  host on a bounded sample of the same workload: 1 core (the
+                  reference is single-threaded) and all cores.
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -46,6 +53,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CONFIGS = {
+    # name: HR size, channels, frames, scale, blur (ksize, sigma; 0 = none), BTV (range, decay), lambda
+    "cfg2": dict(hr=2048, C=1, K=16, s=4, blur=(3, 1.0), btv=(3, 0.5), lam=0.01,
+                 label="configs[1]: 16-frame grayscale, 4x upscale to %dx%d, Gaussian blur 3/1.0 + BTV(3,0.5) lambda 0.01, IRLS weights from x0"),
+    "cfg3": dict(hr=4096, C=3, K=16, s=4, blur=(0, 0.0), btv=(3, 0.5), lam=0.01,
+                 label="configs[2]: 16-frame RGB, 4x upscale to %dx%d, BTV(3,0.5) lambda 0.01, IRLS weights from x0"),
+}
 
 
 def synth_ground_truth(W, H, C):
@@ -65,46 +80,92 @@ def bilinear_upsample(img, s):
 
 
 def pmc_traffic(dtype):
-    """HBM bytes per launch of the fused kernel from the committed PMC profile
-    of this same command (bench.py cannot run rocprofv3 on itself)."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_hbm_pmc.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)[dtype]
-        return (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
+    """HBM-side bytes per step from the committed PMC profile of this same command (bench.py cannot run rocprofv3
+    on itself): the newest profiles/rNN_bench_hbm_pmc.json."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_hbm_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)[dtype]
+            return (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(cfg, lr, x0, wts, budget_s=12.0):
-    """Oracle (CPU restatement of the reference, 1 thread like the reference) on
-    a bounded crop of the same workload, scaled by pixel count."""
+def cpu_baseline(cfg, lr, x0, wts, budget_s=7.0):
+    """Oracle (CPU restatement of the reference) on a bounded crop of the same workload, scaled by pixel count:
+    1 thread (the reference is single-threaded), then one independent crop per core (the image split in tiles)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
-    s, K = cfg["scale"], cfg["frames"]
-    crop_lr = 256  # LR crop 256x256 -> HR 1024x1024: 1/4 of the cfg2 pixels (~0.65 s per evaluation)
-    crop_lr = min(crop_lr, lr.shape[-1])
-    ch = crop_lr * s
-    model = orc.ImageModel(scale=s, shifts=cfg["shifts"], blur_ksize=cfg["blur"][0], blur_sigma=cfg["blur"][1])
-    prob = orc.Problem(model, lr[:, :1, :crop_lr, :crop_lr])
-    prob.add_regularizer(orc.REG_BTV, cfg["lambda"], cfg["btv"][0], cfg["btv"][1])
-    prob.set_irls_weights(0, wts[:1, :ch, :ch])
-    x = np.ascontiguousarray(x0[:1, :ch, :ch])
+    s, K = cfg["s"], cfg["K"]
+    W = H = cfg["hr"]
+    shifts = [[k % s, (k // s) % s] for k in range(K)]
+
+    def make(crop_lr, c0, r0):
+        ch = crop_lr * s
+        model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=cfg["blur"][0], blur_sigma=cfg["blur"][1])
+        prob = orc.Problem(model, lr[:, :1, r0:r0 + crop_lr, c0:c0 + crop_lr])
+        prob.add_regularizer(orc.REG_BTV, cfg["lam"], cfg["btv"][0], cfg["btv"][1])
+        prob.set_irls_weights(0, wts[:1, r0 * s:r0 * s + ch, c0 * s:c0 * s + ch])
+        return prob, np.ascontiguousarray(x0[:1, r0 * s:r0 * s + ch, c0 * s:c0 * s + ch])
+
+    # ---- one core ----
+    crop_lr = min(256, lr.shape[-1])  # LR crop 256x256 -> HR 1024x1024 (~0.65 s per evaluation)
+    prob, x = make(crop_lr, 0, 0)
     t0 = time.perf_counter()
     n = 0
     while True:
         prob.objective(x)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 40:  # about 10-15 s of CPU work
+        if el > budget_s or n >= 40:
             break
     per_eval_crop = el / n
-    frac = (ch * ch) / float(cfg["W"] * cfg["H"])
+    ch = crop_lr * s
+    frac = (ch * ch) / float(W * H * cfg["C"])
     per_eval_full = per_eval_crop / frac
-    return {"value": 1.0 / per_eval_full, "unit": "MAP gradient iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d evaluations of a %dx%d HR crop (%d frames, same blur/BTV), %.2f s each, scaled by "
-                      "pixel count x%.0f to the full %dx%d" % (n, ch, ch, K, per_eval_crop, 1 / frac, cfg["W"], cfg["H"]),
-            "ms_per_step": per_eval_full * 1e3}
+    out = {"value": 1.0 / per_eval_full, "unit": "MAP gradient iterations/s", "cores": 1, "kind": "port",
+           "sample": "%d evaluations of a %dx%d HR crop (%d frames, same blur/BTV), %.2f s each, scaled by pixel count "
+                     "x%.0f to the full workload" % (n, ch, ch, K, per_eval_crop, 1 / frac),
+           "ms_per_step": per_eval_full * 1e3}
+    # ---- all cores: one tile of the image per thread (ctypes releases the GIL inside the C oracle) ----
+    cores = os.cpu_count() or 1
+    tile_lr = min(128, lr.shape[-1])
+    per_row = max(1, lr.shape[-1] // tile_lr)
+    jobs = [make(tile_lr, (i % per_row) * tile_lr, ((i // per_row) % per_row) * tile_lr) for i in range(cores)]
+    counts = [0] * cores
+    stop = time.perf_counter() + budget_s
+
+    def work(i):
+        pr, xx = jobs[i]
+        while time.perf_counter() < stop:
+            pr.objective(xx)
+            counts[i] += 1
+
+    t1 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t1
+    tiles_per_s = sum(counts) / el
+    tch = tile_lr * s
+    full_per_s = tiles_per_s * (tch * tch) / float(W * H * cfg["C"])
+    out["all_cores"] = {"value": full_per_s, "unit": "MAP gradient iterations/s", "cores": cores,
+                        "sample": "%d threads, each evaluating its own %dx%d HR tile of the image for %.1f s (%d tile "
+                                  "evaluations in all), scaled by pixel count to the full workload" % (cores, tch, tch, el, sum(counts)),
+                        "ms_per_step": 1e3 / full_per_s if full_per_s > 0 else None}
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -112,31 +173,38 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="a timed region shorter than this is extended to whole multiples of --steps")
     ap.add_argument("--clock-ramp-ms", type=float, default=100.0,
                     help="untimed evaluations for this many milliseconds BEFORE the W warm-up steps: the GPU reaches its "
-                         "sustained clocks only after ~50 ms of load (a 0.06 ms step measured cold reads 10 %% slower than "
-                         "the same step 1000 steps later); 0 disables")
+                         "sustained clocks only after ~50 ms of load; 0 disables")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
-                    help="arithmetic/storage type on device (the reference is f64)")
-    ap.add_argument("--shard", choices=["channels", "frames", "rows"], default="channels",
-                    help="N > 1: channels = one cfg2 channel per GPU, no collective (weak, default); frames = frame shards + "
-                         "RCCL all-reduce of the gradient (strong); rows = HR row bands + halo exchange of x (strong)")
-    ap.add_argument("--impl", choices=["auto", "direct", "tiled"], default="auto")
-    ap.add_argument("--hr", type=int, default=2048)
+                    help="arithmetic/storage type on device (the reference is f64; f32 is not the parity mode)")
+    ap.add_argument("--shard", choices=["rows", "frames", "channels"], default="rows",
+                    help="N > 1: rows = HR row bands + halo exchange of x (default, strong scaling; the frame variant is timed "
+                         "in the same run); frames = only the frame variant; channels = N independent channels, no "
+                         "collective (weak scaling, the reference's split_channels semantics)")
+    ap.add_argument("--impl", choices=["auto", "direct", "tiled", "march"], default="auto")
+    ap.add_argument("--hr", type=int, default=0, help="override the HR size of the configuration (testing)")
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
                     help="ablation only: evaluate a subset of the objective terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--test-single-device", action="store_true",
-                    help="testing aid for 1-GPU boxes: all ranks share GPU 0 and talk over gloo (exercises the N > 1 code "
-                         "paths; the numbers mean nothing)")
-    ap.add_argument("--joint-scalars", action="store_true",
-                    help="channel sharding only: also all-reduce the scalar cost every step, as ONE joint solve over "
-                         "all channels would (srmap_solve_sharded). Default: the reference's split_channels semantics "
-                         "(irls_map_solver.cpp:200-210), independent per-channel solves, no collective in the timed region")
+                    help="testing aid for 1-GPU boxes: all ranks share GPU 0 and talk over gloo through the library's "
+                         "host-callback communicator (exercises the N > 1 code paths; the numbers mean nothing)")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: become one (one process per GPU, rendezvous on 127.0.0.1) ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import srmap
+    import srmap_dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,62 +217,33 @@ def main():
         if args.test_single_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    s, K = 4, 16
-    W = H = args.hr
+    cfg = dict(CONFIGS[args.config])
+    if args.hr:
+        cfg["hr"] = args.hr
+    s, K, C = cfg["s"], cfg["K"], cfg["C"]
+    W = H = cfg["hr"]
     w, h = W // s, H // s
     shifts_all = [[k % s, (k // s) % s] for k in range(K)]
-    cfg = {"W": W, "H": H, "scale": s, "frames": K, "shifts": shifts_all, "blur": (3, 1.0),
-           "btv": (3, 0.5), "lambda": 0.01}
+    blur_k, blur_s = cfg["blur"]  # 0 = no blur module
     dtype = srmap.F64 if args.dtype == "f64" else srmap.F32
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     E = 8 if args.dtype == "f64" else 4
-
-    import srmap_dist
-    frame_ids = list(range(K))
-    units_per_step = 1.0
-    if world > 1 and args.shard == "frames":
-        frame_ids = srmap_dist.frame_shard(K, world, rank)
-    shifts = [shifts_all[k] for k in frame_ids]
-    Kloc = len(frame_ids)
-
-    # row bands: this rank's problem lives on its owned HR rows + halo rows
-    band = None
-    Hloc, e0, e1, r0, r1 = H, 0, H, 0, H
-    if world > 1 and args.shard == "rows":
-        halo = srmap_dist.band_halo(s, 3, s - 1, 3)
-        bands = [srmap_dist.row_band(H, s, world, r, halo) for r in range(world)]
-        (r0, r1), (e0, e1) = bands[rank]
-        Hloc = e1 - e0
-
+    terms = {"all": srmap.TERM_ALL, "data": srmap.TERM_DATA, "reg": srmap.TERM_REG}[args.terms]
+    impl = {"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED, "march": srmap.IMPL_MARCH}[args.impl]
     ctx = srmap.Context(local_rank)
-    prob = srmap.Problem(ctx, W, Hloc, 1, Kloc, s, shifts, 3, 1.0, dtype)
-    prob.set_impl({"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED}[args.impl])
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
 
-    # ---- synthetic data, seeded; channel = rank under channel sharding
-    rng = np.random.default_rng(20240607 + (rank if args.shard == "channels" else 0))
-    gt = synth_ground_truth(W, H, max(world, 1) if args.shard == "channels" else 1)
-    gt = gt[rank:rank + 1] if args.shard == "channels" and world > 1 else gt[:1]
-    gt = gt[:, e0:e1, :]
-    lr = np.stack([prob.apply(gt, i) for i in range(Kloc)])
-    noise_rng = np.random.default_rng(777 + rank)
-    lr = lr + (5.0 / 255.0) * noise_rng.standard_normal(lr.shape)
-    prob.set_observations(lr)
-    reg = prob.add_regularizer(srmap.REG_BTV, cfg["lambda"], 3, 0.5)
-    x0 = bilinear_upsample(lr[0], s)
-    rv0 = prob.reg_values(reg, x0)
-    wts = 1.0 / np.maximum(1e-5, rv0)
-    prob.set_irls_weights(reg, wts)
-
-    # ---- the library's communicator and shard description (N > 1, frames / rows): the exchanges run inside the C ABI
-    comm, sd = None, None
-    if world > 1 and args.shard in ("frames", "rows"):
+    # the library's communicator (N > 1): RCCL, or the host callbacks when every rank shares GPU 0
+    comm = None
+    comm_info = None
+    if world > 1 and args.shard != "channels":
         if args.test_single_device:
             comm = srmap.Comm(ctx, rank, world, backend="host", dist=dist)
         else:
@@ -213,36 +252,7 @@ def main():
                 uid = torch.frombuffer(bytearray(srmap.Comm.unique_id(ctx)), dtype=torch.uint8).to(dev)
             dist.broadcast(uid, 0)
             comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=bytes(uid.cpu().numpy().tobytes()))
-        sd = srmap.ShardDesc()
-        if args.shard == "frames":
-            sd.mode, sd.reg_rank = srmap.SHARD_FRAMES, 0
-        else:
-            prob.set_cost_rows(r0 - e0, r1 - e0)
-            sd.mode = srmap.SHARD_ROWS
-            sd.own_row0, sd.own_row1 = r0 - e0, r1 - e0
-            if rank + 1 < world:
-                (n0, n1), (ne0, ne1) = bands[rank + 1]
-                sd.send_down_rows = n0 - ne0
-            if rank > 0:
-                (u0, u1), (ue0, ue1) = bands[rank - 1]
-                sd.send_up_rows = ue1 - u1
-
-    x_dev = torch.from_numpy(x0).to(dev, tdtype).contiguous()
-    g_dev = torch.empty_like(x_dev)
-    stream = torch.cuda.Stream(device=dev)
-    sh = stream.cuda_stream
-    cost_buf = torch.zeros(1, dtype=torch.float64, device=dev)
-    terms = {"all": srmap.TERM_ALL, "data": srmap.TERM_DATA, "reg": srmap.TERM_REG}[args.terms]
-
-    def step():
-        if comm is not None:
-            # halo rows of x (rows) / gradient + cost all-reduce (frames): issued by the library on `sh`
-            prob.eval_sharded_device(comm, sd, x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
-        else:
-            prob.eval_device(x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
-            if dist is not None and args.joint_scalars:
-                with torch.cuda.stream(stream):
-                    dist.all_reduce(cost_buf)
+        comm_info = comm.info()
 
     def barrier():
         stream.synchronize()
@@ -251,75 +261,155 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ramp_steps = 0
-    if args.clock_ramp_ms > 0:  # untimed: bring the GPU to its sustained clock state (see --clock-ramp-ms)
-        t_r = time.perf_counter()
-        while (time.perf_counter() - t_r) * 1e3 < args.clock_ramp_ms:
-            for _ in range(50):
-                step()
-            stream.synchronize()
-            ramp_steps += 50
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    with torch.cuda.stream(stream):
-        ev1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
+    def run(shard):
+        """Build this rank's part of the workload under `shard` and time it.  Returns (seconds per step on the
+        wall clock, max over ranks; device ms per step on this rank; timed steps; ramp steps; extras for rank 0)."""
+        frame_ids = list(range(K))
+        if shard == "frames":
+            frame_ids = srmap_dist.frame_shard(K, world, rank)
+        shifts = [shifts_all[k] for k in frame_ids]
+        Hloc, e0, e1, r0, r1 = H, 0, H, 0, H
+        bands = None
+        if shard == "rows":
+            halo = srmap_dist.band_halo(s, max(blur_k, 1), s - 1, cfg["btv"][0])
+            bands = [srmap_dist.row_band(H, s, world, r, halo) for r in range(world)]
+            (r0, r1), (e0, e1) = bands[rank]
+            Hloc = e1 - e0
+        Cloc = 1 if shard == "channels" and world > 1 else C
+        prob = srmap.Problem(ctx, W, Hloc, Cloc, len(frame_ids), s, shifts, blur_k, blur_s, dtype)
+        prob.set_impl(impl)
+        # synthetic data (SURVEY 8d), seeded; channel = rank under channel sharding
+        gt = synth_ground_truth(W, H, max(C, world if shard == "channels" else 1))
+        gt = gt[rank:rank + 1] if (shard == "channels" and world > 1) else gt[:C]
+        gt = gt[:, e0:e1, :]
+        lr = np.stack([prob.apply(gt, i) for i in range(len(frame_ids))])
+        lr = lr + (5.0 / 255.0) * np.random.default_rng(777 + rank).standard_normal(lr.shape)
+        prob.set_observations(lr)
+        reg = prob.add_regularizer(srmap.REG_BTV, cfg["lam"], cfg["btv"][0], cfg["btv"][1])
+        x0 = np.stack([bilinear_upsample(lr[0, c:c + 1], s)[0] for c in range(Cloc)])
+        wts = 1.0 / np.maximum(1e-5, prob.reg_values(reg, x0))
+        prob.set_irls_weights(reg, wts)
+        sd = None
+        if comm is not None and shard in ("rows", "frames"):
+            sd = srmap.ShardDesc()
+            if shard == "frames":
+                sd.mode, sd.reg_rank = srmap.SHARD_FRAMES, 0
+            else:
+                prob.set_cost_rows(r0 - e0, r1 - e0)
+                sd.mode = srmap.SHARD_ROWS
+                sd.own_row0, sd.own_row1 = r0 - e0, r1 - e0
+                if rank + 1 < world:
+                    (n0, n1), (ne0, ne1) = bands[rank + 1]
+                    sd.send_down_rows = n0 - ne0
+                if rank > 0:
+                    (u0, u1), (ue0, ue1) = bands[rank - 1]
+                    sd.send_up_rows = ue1 - u1
+        x_dev = torch.from_numpy(x0).to(dev, tdtype).contiguous()
+        g_dev = torch.empty_like(x_dev)
 
-    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax.item())
-    ms_per_step = wall / args.steps * 1e3
-    if world > 1 and args.shard == "channels":
-        units_per_step = float(world)
-    value = units_per_step * args.steps / wall
+        def step():
+            if sd is not None:
+                prob.eval_sharded_device(comm, sd, x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
+            else:
+                prob.eval_device(x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
+
+        ramp_steps = 0
+        if args.clock_ramp_ms > 0:  # untimed: bring the GPU to its sustained clock state
+            t_r = time.perf_counter()
+            while (time.perf_counter() - t_r) * 1e3 < args.clock_ramp_ms:
+                for _ in range(20):
+                    step()
+                stream.synchronize()
+                ramp_steps += 20
+        barrier()
+        t_w = time.perf_counter()
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        est = (time.perf_counter() - t_w) / max(1, args.warmup)  # seconds per step, from the warm-up
+        reps = 1
+        if args.min_timed_ms > 0 and est > 0:
+            reps = max(1, int(np.ceil(args.min_timed_ms * 1e-3 / (est * args.steps))))
+        if dist is not None:  # every rank times the same number of steps
+            t = torch.tensor([reps], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            reps = int(t.item())
+        n_timed = reps * args.steps
+        barrier()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            ev0.record(stream)
+        for _ in range(n_timed):
+            step()
+        with torch.cuda.stream(stream):
+            ev1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
+        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return dict(wall_per_step=float(tmax.item()) / n_timed, dev_ms_per_step=dev_ms / n_timed, timed_steps=n_timed,
+                    ramp_steps=ramp_steps, lr=lr, x0=x0, wts=wts)
+
+    if world == 1:
+        main_shard, res = "none", run("none")
+        second = None
+    elif args.shard == "channels":
+        main_shard, res, second = "channels", run("channels"), None
+    elif args.shard == "frames":
+        main_shard, res, second = "frames", run("frames"), None
+    else:
+        main_shard, res = "rows", run("rows")
+        second = run("frames")
 
     if rank == 0:
-        C_total = world if (world > 1 and args.shard == "channels") else 1
+        units = float(world) if main_shard == "channels" else 1.0
         N, n = W * H, w * h
         rho = 1
-        b_alg = E * C_total * ((2 + rho) * N + K * n)  # x, y, w read once, g written once
-        step_dev_s = dev_ms / args.steps * 1e-3
-        achieved = (b_alg / max(C_total, 1)) / step_dev_s / 1e9  # per GPU
+        c_unit = 1 if main_shard == "channels" else C
+        b_alg = E * c_unit * ((2 + rho) * N + K * n)  # SURVEY 8(d): x, y, w read once, g written once (per unit)
+        step_dev_s = res["dev_ms_per_step"] * 1e-3
+        share = 1.0 if main_shard in ("none", "channels") else 1.0 / world  # bytes this GPU moves per step
+        achieved = b_alg * share / step_dev_s / 1e9
+        traffic, traffic_src = pmc_traffic(args.dtype)
+        collective = {"none": "none",
+                      "rows": "ncclSend/ncclRecv of the halo rows of x (both directions in one group) inside srmap_eval_sharded_device",
+                      "frames": "ncclAllReduce(g, C*N) + ncclAllReduce(cost) in one group inside srmap_eval_sharded_device",
+                      "channels": "none (split_channels: independent per-channel solves)"}
         out = {
             "metric": "MAP gradient iterations/sec at fixed HR size",
-            "value": value,
-            "unit": "MAP gradient iterations/s" if C_total == 1 else "channel-iterations/s (one 16-frame %dx%d channel per GPU)" % (W, H),
+            "value": units / res["wall_per_step"],
+            "unit": "MAP gradient iterations/s" if main_shard != "channels" else "channel-iterations/s (one %d-frame %dx%d channel per GPU)" % (K, W, H),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and args.shard in ("frames", "rows")) else "weak",
+            "ms_per_step": res["wall_per_step"] * 1e3, "higher_is_better": True,
+            "scaling": "weak" if (world == 1 or main_shard == "channels") else "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: 16-frame grayscale, 4x upscale to %dx%d, Gaussian blur 3/1.0 + BTV(3,0.5) "
-                                   "lambda 0.01, IRLS weights from x0" % (W, H),
-                       "frames": K, "scale": s, "channels": C_total, "shard": args.shard if world > 1 else "none",
-                       "collective_per_step": ("none" if world == 1 else
-                                               "ncclAllReduce(g, C*N) + ncclAllReduce(cost) inside srmap_eval_sharded_device" if args.shard == "frames" else
-                                               "ncclSend/ncclRecv of the halo rows of x inside srmap_eval_sharded_device" if args.shard == "rows" else
-                                               "all-reduce(cost)" if args.joint_scalars else
-                                               "none (split_channels: independent per-channel solves)"),
-                       "impl": args.impl, "device_ms_per_step": dev_ms / args.steps,
-                       "clock_ramp_steps_before_warmup": ramp_steps},
+            "config": {"workload": cfg["label"] % (W, H), "frames": K, "scale": s, "channels": C,
+                       "shard": main_shard, "collective_per_step": collective[main_shard],
+                       "rccl_ranks": (comm_info[1] if comm_info else (world if world > 1 else 1)),
+                       "comm_backend": (None if comm_info is None else ("rccl" if comm_info[2] == 1 else "host callbacks (test)")),
+                       "impl": args.impl, "device_ms_per_step": res["dev_ms_per_step"],
+                       "timed_steps": res["timed_steps"], "clock_ramp_steps_before_warmup": res["ramp_steps"],
+                       "parity_mode": args.dtype == "f64"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.dtype),
-                         "traffic_source": "profiles/r02_bench_hbm_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                           "(separate passes) of this command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
-                                           "the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md",
-                         "algorithmic_bytes_per_step": b_alg / max(C_total, 1),
-                         "kernel": "whole evaluation (k_eval_z + k_finish_eval: all kernels of one step), HIP events on "
-                                   "the launch stream; the dominant kernel alone is in profiles/r02_bench_*_kernel_stats.csv"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (traffic_src + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this "
+                                            "command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2 being the gfx950 "
+                                            "FETCH_SIZE correction of MI355X_MICROARCH.md") if traffic_src else None,
+                         "algorithmic_bytes_per_step": b_alg * share,
+                         "kernel": "whole evaluation (every kernel of one step: k_eval_z with its in-kernel reduction), HIP "
+                                   "events on the launch stream; the dominant kernel alone is in profiles/r03_bench_*_kernel_stats.csv"},
         }
+        if second is not None:
+            out["frames_variant"] = {"value": 1.0 / second["wall_per_step"], "unit": "MAP gradient iterations/s",
+                                     "ms_per_step": second["wall_per_step"] * 1e3, "scaling": "strong",
+                                     "device_ms_per_step": second["dev_ms_per_step"], "timed_steps": second["timed_steps"],
+                                     "collective_per_step": collective["frames"]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, lr, x0, wts)
+            out["cpu_baseline"] = cpu_baseline(cfg, res["lr"], res["x0"], res["wts"])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

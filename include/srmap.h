@@ -274,6 +274,12 @@ int srmap_comm_create_host(srmap_ctx* ctx, int rank, int world,
                            srmap_host_allreduce_fn allreduce,
                            srmap_host_sendrecv_fn sendrecv, void* user, srmap_comm** out);
 void srmap_comm_destroy(srmap_comm* comm);
+/* What the communicator itself reports: rank, size (ncclCommCount for RCCL), backend (1 = RCCL, 0 = host
+ * callbacks).  Any out pointer may be NULL.  No reference counterpart (the reference is single-process). */
+int srmap_comm_info(srmap_comm* comm, int* rank, int* world, int* backend);
+/* ncclCommSplit: ranks passing the same color form a new communicator ordered by key; the caller states its rank
+ * and size in it (RCCL backend; host-callback harnesses build the sub-communicator themselves).  Collective. */
+int srmap_comm_split(srmap_comm* comm, int color, int key, int new_rank, int new_world, srmap_comm** out);
 /* In-place all-reduce of a device buffer (op 0 = sum, 1 = max) on `hip_stream`: what the sharded evaluation
  * and solver use internally, exposed for harnesses. */
 int srmap_comm_allreduce(srmap_comm* comm, void* dev_buf, size_t count, int dtype, int op,
@@ -287,9 +293,17 @@ typedef enum {
   SRMAP_SHARD_ROWS = 2,     /* rank owns a band of HR rows; its problem is the band + halo
                                rows; halo rows of x are exchanged with the two neighbours
                                before every evaluation, scalars all-reduced */
-  SRMAP_SHARD_CHANNELS = 3  /* rank owns a channel block (+ one halo channel plane per
+  SRMAP_SHARD_CHANNELS = 3, /* rank owns a channel block (+ one halo channel plane per
                                neighbour when a 3-D TV regulariser couples them,
                                tv_regularizer.cpp:205-222); scalars all-reduced */
+  SRMAP_SHARD_GRID = 4      /* frames x channels (BASELINE configs[4]): world rank =
+                               channel_block * frame_groups + frame_group.  The rank owns a
+                               channel block (as CHANNELS) and a frame subset (as FRAMES) of
+                               it: the gradient of the block is all-reduced over the
+                               frame_groups ranks that share the block (frame_comm), halo
+                               planes travel between ranks rank +- frame_groups, the
+                               regulariser terms are evaluated by frame group 0, scalars
+                               are all-reduced over the world communicator */
 } srmap_shard_mode;
 
 typedef struct {
@@ -298,6 +312,9 @@ typedef struct {
   int send_up_rows, send_down_rows;/* ROWS: owned boundary rows the upper / lower neighbour's halo holds */
   int own_ch0, own_ch1;            /* CHANNELS: channels of THIS problem the rank owns (others: halo planes) */
   int reg_rank;                    /* FRAMES: the rank whose evaluation carries the regulariser terms */
+  int frame_groups;                /* GRID: ranks per channel block (0 / 1 elsewhere) */
+  srmap_comm* frame_comm;          /* GRID: communicator of the frame_groups ranks sharing this rank's channel
+                                      block (srmap_comm_split, or a host communicator of that group) */
 } srmap_shard_desc;
 
 /* One ObjectiveFunction::ComputeAllTerms of the JOINT objective on device buffers of

@@ -17,6 +17,8 @@
 #include <cstring>
 #include <new>
 
+#include <mutex>
+
 #include "comm.hpp"
 
 namespace srmap {
@@ -34,13 +36,14 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;                       // optional
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;     // optional (RCCL >= 2.18)
 };
 
 RcclApi* rccl_api(srmap_ctx* ctx) {
   static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] {  // one thread loads the library; every later caller sees the finished table
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
       api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -58,9 +61,11 @@ RcclApi* rccl_api(srmap_ctx* ctx) {
       api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
       api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
       api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+      api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+      api.CommSplit = (decltype(api.CommSplit))dlsym(api.lib, "ncclCommSplit");
       if (!ok) { dlclose(api.lib); api.lib = nullptr; }
     }
-  }
+  });
   if (!api.lib) { set_error(ctx, SRMAP_EUNSUPPORTED, "librccl.so.1 could not be loaded"); return nullptr; }
   return &api;
 }
@@ -140,11 +145,14 @@ int comm_exchange(srmap_comm* c, const void* const* send, int dst, void* const* 
   if (c->kind == 1) {
     const ncclDataType_t t = dtype == SRMAP_F32 ? ncclFloat32 : ncclFloat64;
     SRMAP_NCCL(c, c->api->GroupStart());
-    for (int i = 0; i < nseg; ++i) {
-      if (dst >= 0) SRMAP_NCCL(c, c->api->Send(send[i], send_seg, t, dst, c->nccl, st));
-      if (src >= 0) SRMAP_NCCL(c, c->api->Recv(recv[i], recv_seg, t, src, c->nccl, st));
+    ncclResult_t first = ncclSuccess;  // the group is ALWAYS closed: a dangling group swallows every later collective
+    for (int i = 0; i < nseg && first == ncclSuccess; ++i) {
+      if (dst >= 0) first = c->api->Send(send[i], send_seg, t, dst, c->nccl, st);
+      if (src >= 0 && first == ncclSuccess) first = c->api->Recv(recv[i], recv_seg, t, src, c->nccl, st);
     }
-    SRMAP_NCCL(c, c->api->GroupEnd());
+    const ncclResult_t end = c->api->GroupEnd();
+    if (first != ncclSuccess) return set_error(c->ctx, SRMAP_EHIP, "ncclSend / ncclRecv failed: %s", c->api->GetErrorString(first));
+    if (end != ncclSuccess) return set_error(c->ctx, SRMAP_EHIP, "ncclGroupEnd failed: %s", c->api->GetErrorString(end));
     return SRMAP_OK;
   }
   const size_t sbytes = (size_t)nseg * send_seg * esz, rbytes = (size_t)nseg * recv_seg * esz;
@@ -161,6 +169,50 @@ int comm_exchange(srmap_comm* c, const void* const* send, int dst, void* const* 
       SRMAP_HIP(c->ctx, hipMemcpyAsync(recv[i], (char*)c->h_recv + (size_t)i * recv_seg * esz, recv_seg * esz, hipMemcpyHostToDevice, st));
     SRMAP_HIP(c->ctx, hipStreamSynchronize(st));
   }
+  return SRMAP_OK;
+}
+
+// Both directions of a halo exchange in ONE RCCL group (one launch on the stream instead of two): `a` travels towards
+// rank `down` / arrives from `up`, `b` the other way.  Host backend: the two one-directional exchanges in turn.
+int comm_exchange2(srmap_comm* c, const void* const* send_a, void* const* recv_a, size_t send_a_seg, size_t recv_a_seg,
+                   const void* const* send_b, void* const* recv_b, size_t send_b_seg, size_t recv_b_seg, int up, int down,
+                   int nseg, int dtype, hipStream_t st) {
+  if (!c || c->world <= 1 || nseg == 0) return SRMAP_OK;
+  if (c->kind != 1) {
+    int rc = comm_exchange(c, send_a, down, recv_a, up, nseg, down >= 0 ? send_a_seg : 0, up >= 0 ? recv_a_seg : 0, dtype, st);
+    if (rc) return rc;
+    return comm_exchange(c, send_b, up, recv_b, down, nseg, up >= 0 ? send_b_seg : 0, down >= 0 ? recv_b_seg : 0, dtype, st);
+  }
+  const ncclDataType_t t = dtype == SRMAP_F32 ? ncclFloat32 : ncclFloat64;
+  SRMAP_NCCL(c, c->api->GroupStart());
+  ncclResult_t first = ncclSuccess;
+  auto chk = [&](ncclResult_t r) { if (first == ncclSuccess) first = r; };
+  for (int i = 0; i < nseg; ++i) {
+    if (down >= 0 && send_a_seg) chk(c->api->Send(send_a[i], send_a_seg, t, down, c->nccl, st));
+    if (up >= 0 && recv_a_seg) chk(c->api->Recv(recv_a[i], recv_a_seg, t, up, c->nccl, st));
+    if (up >= 0 && send_b_seg) chk(c->api->Send(send_b[i], send_b_seg, t, up, c->nccl, st));
+    if (down >= 0 && recv_b_seg) chk(c->api->Recv(recv_b[i], recv_b_seg, t, down, c->nccl, st));
+  }
+  const ncclResult_t end = c->api->GroupEnd();
+  if (first != ncclSuccess) return set_error(c->ctx, SRMAP_EHIP, "ncclSend / ncclRecv failed: %s", c->api->GetErrorString(first));
+  if (end != ncclSuccess) return set_error(c->ctx, SRMAP_EHIP, "ncclGroupEnd failed: %s", c->api->GetErrorString(end));
+  return SRMAP_OK;
+}
+
+// Gradient (count elements of dtype) and cost (one double) summed over the ranks of `c` as ONE RCCL group.
+int comm_allreduce_grad_cost(srmap_comm* c, void* g, size_t count, int dtype, double* cost, hipStream_t st) {
+  if (!c || c->world <= 1) return SRMAP_OK;
+  if (c->kind != 1) {
+    if (g && count) { int rc = comm_allreduce(c, g, count, dtype, 0, st); if (rc) return rc; }
+    return cost ? comm_allreduce(c, cost, 1, SRMAP_F64, 0, st) : SRMAP_OK;
+  }
+  SRMAP_NCCL(c, c->api->GroupStart());
+  ncclResult_t first = ncclSuccess;
+  if (g && count) first = c->api->AllReduce(g, g, count, dtype == SRMAP_F32 ? ncclFloat32 : ncclFloat64, ncclSum, c->nccl, st);
+  if (cost && first == ncclSuccess) first = c->api->AllReduce(cost, cost, 1, ncclFloat64, ncclSum, c->nccl, st);
+  const ncclResult_t end = c->api->GroupEnd();
+  if (first != ncclSuccess) return set_error(c->ctx, SRMAP_EHIP, "ncclAllReduce failed: %s", c->api->GetErrorString(first));
+  if (end != ncclSuccess) return set_error(c->ctx, SRMAP_EHIP, "ncclGroupEnd failed: %s", c->api->GetErrorString(end));
   return SRMAP_OK;
 }
 
@@ -226,6 +278,42 @@ int srmap_comm_allreduce(srmap_comm* c, void* dev_buf, size_t count, int dtype, 
     return SRMAP_OK;
   }
   return comm_allreduce(c, dev_buf, count, dtype, op, st);
+}
+
+/* What the communicator itself reports: its rank, its size (ncclCommCount for RCCL) and its backend (1 = RCCL, 0 = host
+ * callbacks).  Any out pointer may be NULL. */
+int srmap_comm_info(srmap_comm* c, int* rank, int* world, int* backend) {
+  if (!c) return SRMAP_EINVAL;
+  int w = c->world;
+  if (c->kind == 1 && c->api->CommCount) {
+    int n = 0;
+    SRMAP_NCCL(c, c->api->CommCount(c->nccl, &n));
+    w = n;
+  }
+  if (rank) *rank = c->rank;
+  if (world) *world = w;
+  if (backend) *backend = c->kind;
+  return SRMAP_OK;
+}
+
+/* ncclCommSplit: the ranks that pass the same `color` form a new communicator, ordered by `key` (RCCL backend only;
+ * host-callback harnesses create the sub-communicator themselves).  Collective over `c`. */
+int srmap_comm_split(srmap_comm* c, int color, int key, int new_rank, int new_world, srmap_comm** out) {
+  if (!c || !out || new_world < 1 || new_rank < 0 || new_rank >= new_world) return SRMAP_EINVAL;
+  *out = nullptr;
+  if (c->kind != 1) return set_error(c->ctx, SRMAP_EUNSUPPORTED, "srmap_comm_split needs the RCCL backend");
+  if (!c->api->CommSplit) return set_error(c->ctx, SRMAP_EUNSUPPORTED, "this librccl has no ncclCommSplit");
+  SRMAP_HIP(c->ctx, hipSetDevice(c->ctx->device));
+  srmap_comm* n = new (std::nothrow) srmap_comm();
+  if (!n) return SRMAP_ENOMEM;
+  n->ctx = c->ctx; n->rank = new_rank; n->world = new_world; n->kind = 1; n->api = c->api;
+  const ncclResult_t r = c->api->CommSplit(c->nccl, color, key, &n->nccl, nullptr);
+  if (r != ncclSuccess || n->nccl == nullptr) {
+    delete n;
+    return set_error(c->ctx, SRMAP_EHIP, "ncclCommSplit failed: %s", c->api->GetErrorString(r));
+  }
+  *out = n;
+  return SRMAP_OK;
 }
 
 void srmap_comm_destroy(srmap_comm* c) {

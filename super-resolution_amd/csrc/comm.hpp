@@ -15,6 +15,13 @@ int comm_allreduce(srmap_comm* c, void* dev, size_t count, int dtype, int op, hi
 int comm_exchange(srmap_comm* c, const void* const* send, int dst, void* const* recv, int src, int nseg,
                   size_t send_seg, size_t recv_seg, int dtype, hipStream_t st);
 
+// Both directions of a halo exchange in one RCCL group: `a` travels to rank `down` / arrives from `up`, `b` the other way.
+int comm_exchange2(srmap_comm* c, const void* const* send_a, void* const* recv_a, size_t send_a_seg, size_t recv_a_seg,
+                   const void* const* send_b, void* const* recv_b, size_t send_b_seg, size_t recv_b_seg, int up, int down,
+                   int nseg, int dtype, hipStream_t st);
+// Gradient and cost summed over the ranks of `c` in one RCCL group.
+int comm_allreduce_grad_cost(srmap_comm* c, void* g, size_t count, int dtype, double* cost, hipStream_t st);
+
 // Halo refresh of x for the shard (rows: boundary rows with the two row neighbours; channels: one plane with each
 // channel neighbour when the problem carries halo planes).  x is this rank's [C][H][W] device buffer.
 int shard_exchange_x(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, void* x_dev, hipStream_t st);

@@ -220,36 +220,36 @@ int shard_exchange_x(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd
     if ((up >= 0 && hu == 0) || (down >= 0 && hd == 0) || sd->send_down_rows > sd->own_row1 - sd->own_row0 ||
         sd->send_up_rows > sd->own_row1 - sd->own_row0)
       return set_error(p->ctx, SRMAP_EINVAL, "row shard: halo description inconsistent");
-    std::vector<const void*> s(g.C);
-    std::vector<void*> r(g.C);
-    // downward traffic: my last owned rows -> lower neighbour's top halo; my top halo <- upper neighbour
+    if ((up >= 0 && sd->send_up_rows <= 0) || (down >= 0 && sd->send_down_rows <= 0))
+      return set_error(p->ctx, SRMAP_EINVAL, "row shard: a neighbour exists but no rows are sent to it (it would wait for them)");
+    std::vector<const void*> sa(g.C), sb(g.C);
+    std::vector<void*> ra(g.C), rb(g.C);
     for (int ch = 0; ch < g.C; ++ch) {
-      s[ch] = x + ((size_t)ch * N + (size_t)(sd->own_row1 - sd->send_down_rows) * g.W) * es;
-      r[ch] = x + ((size_t)ch * N) * es;
+      // downward traffic: my last owned rows -> lower neighbour's top halo; my top halo <- upper neighbour
+      sa[ch] = x + ((size_t)ch * N + (size_t)(sd->own_row1 - sd->send_down_rows) * g.W) * es;
+      ra[ch] = x + ((size_t)ch * N) * es;
+      // upward traffic: my first owned rows -> upper neighbour's bottom halo; my bottom halo <- lower neighbour
+      sb[ch] = x + ((size_t)ch * N + (size_t)sd->own_row0 * g.W) * es;
+      rb[ch] = x + ((size_t)ch * N + (size_t)sd->own_row1 * g.W) * es;
     }
-    int rc = comm_exchange(c, s.data(), down, r.data(), up, g.C, down >= 0 ? (size_t)sd->send_down_rows * g.W : 0,
-                           up >= 0 ? (size_t)hu * g.W : 0, p->dtype, st);
-    if (rc) return rc;
-    // upward traffic: my first owned rows -> upper neighbour's bottom halo; my bottom halo <- lower neighbour
-    for (int ch = 0; ch < g.C; ++ch) {
-      s[ch] = x + ((size_t)ch * N + (size_t)sd->own_row0 * g.W) * es;
-      r[ch] = x + ((size_t)ch * N + (size_t)sd->own_row1 * g.W) * es;
-    }
-    return comm_exchange(c, s.data(), up, r.data(), down, g.C, up >= 0 ? (size_t)sd->send_up_rows * g.W : 0,
-                         down >= 0 ? (size_t)hd * g.W : 0, p->dtype, st);
+    // both directions in ONE group (one launch on the stream)
+    return comm_exchange2(c, sa.data(), ra.data(), (size_t)sd->send_down_rows * g.W, (size_t)hu * g.W, sb.data(), rb.data(),
+                          (size_t)sd->send_up_rows * g.W, (size_t)hd * g.W, up, down, g.C, p->dtype, st);
   }
-  if (sd->mode == SRMAP_SHARD_CHANNELS) {
+  if (sd->mode == SRMAP_SHARD_CHANNELS || sd->mode == SRMAP_SHARD_GRID) {
     const bool lo = sd->own_ch0 > 0, hi = sd->own_ch1 < g.C;  // halo planes present (3-D TV coupling)
     if (!lo && !hi) return SRMAP_OK;
+    // GRID: the channel neighbours are the ranks of the same frame group in the adjacent channel blocks
+    const int stride = sd->mode == SRMAP_SHARD_GRID ? (sd->frame_groups > 0 ? sd->frame_groups : 1) : 1;
+    const int cup = rank - stride >= 0 ? rank - stride : -1, cdown = rank + stride < world ? rank + stride : -1;
     // downward: my last owned plane -> lower neighbour's low halo plane; my low halo <- upper neighbour
     const void* s1 = x + (size_t)(sd->own_ch1 - 1) * N * es;
     void* r1 = x + (size_t)(sd->own_ch0 - 1) * N * es;
-    int rc = comm_exchange(c, &s1, (down >= 0 && hi) ? down : -1, &r1, (up >= 0 && lo) ? up : -1, 1, N, N, p->dtype, st);
-    if (rc) return rc;
     // upward: my first owned plane -> upper neighbour's high halo plane; my high halo <- lower neighbour
     const void* s2 = x + (size_t)sd->own_ch0 * N * es;
     void* r2 = x + (size_t)sd->own_ch1 * N * es;
-    return comm_exchange(c, &s2, (up >= 0 && lo) ? up : -1, &r2, (down >= 0 && hi) ? down : -1, 1, N, N, p->dtype, st);
+    return comm_exchange2(c, &s1, &r1, hi ? N : 0, lo ? N : 0, &s2, &r2, lo ? N : 0, hi ? N : 0, lo ? cup : -1, hi ? cdown : -1, 1,
+                          p->dtype, st);
   }
   return SRMAP_OK;
 }
@@ -271,19 +271,32 @@ int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsi
       rc = srmap_eval_device(p, t, x_dev, g_dev, nullptr, st);
       if (rc) return rc;
     }
-    if (g_dev) {
-      rc = comm_allreduce(c, g_dev, p->hr_count(), p->dtype, 0, st);  // the north-star's gradient all-reduce
-      if (rc) return rc;
-    }
-    return comm_allreduce(c, p->d_cost, 1, SRMAP_F64, 0, st);
+    // the north-star's gradient all-reduce, with the cost in the same group (one launch)
+    return comm_allreduce_grad_cost(c, g_dev, g_dev ? p->hr_count() : 0, p->dtype, p->d_cost, st);
   }
-  if (mode == SRMAP_SHARD_CHANNELS) {
+  if (mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) {
+    const int fgs = (mode == SRMAP_SHARD_GRID && sd->frame_groups > 1) ? sd->frame_groups : 1;
+    const int fg = comm_rank(c) % fgs;
+    // GRID: the regulariser terms of a channel block are evaluated once, by its frame group 0
+    const unsigned t = (fg == 0) ? terms : (terms & SRMAP_TERM_DATA);
     const int saved_c0 = p->view_c0, saved_C = p->view_C;
     const bool saved_cp = p->view_coupled;
     p->view_c0 = sd->own_ch0; p->view_C = sd->own_ch1 - sd->own_ch0; p->view_coupled = true;
-    rc = srmap_eval_device(p, terms, (char*)x_dev + (size_t)sd->own_ch0 * N * es,
-                           g_dev ? (char*)g_dev + (size_t)sd->own_ch0 * N * es : nullptr, nullptr, st);
+    char* gown = g_dev ? (char*)g_dev + (size_t)sd->own_ch0 * N * es : nullptr;
+    if (t == 0) {
+      rc = SRMAP_OK;
+      SRMAP_HIP(p->ctx, hipMemsetAsync(p->d_cost, 0, sizeof(double), st));
+      if (gown) SRMAP_HIP(p->ctx, hipMemsetAsync(gown, 0, (size_t)p->view_C * N * es, st));
+    } else {
+      rc = srmap_eval_device(p, t, (char*)x_dev + (size_t)sd->own_ch0 * N * es, gown, nullptr, st);
+    }
+    const size_t cnt = (size_t)p->view_C * N;
     p->view_c0 = saved_c0; p->view_C = saved_C; p->view_coupled = saved_cp;
+    if (rc) return rc;
+    if (fgs > 1 && gown) {  // sum of the frame groups' data-term gradients of this channel block
+      if (!sd->frame_comm) return set_error(p->ctx, SRMAP_EINVAL, "grid shard: frame_comm missing");
+      rc = comm_allreduce(sd->frame_comm, gown, cnt, p->dtype, 0, st);
+    }
     return rc;
   }
   return srmap_eval_device(p, terms, x_dev, g_dev, nullptr, st);  // rows: cost rows were set on the problem
@@ -398,7 +411,7 @@ struct DeviceCG {
   int evaluate(const T* dir = nullptr) {
     evaluations++;
     const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
-    p->eval_dvec = (mode == SRMAP_SHARD_FRAMES || mode == SRMAP_SHARD_CHANNELS) ? nullptr : dir;
+    p->eval_dvec = (mode == SRMAP_SHARD_FRAMES || mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) ? nullptr : dir;
     p->gd_valid = false;
     p->eval_published = false;
     // without a scalar all-reduce the evaluation's finish kernel can publish {f, g.d} and the arrival tag itself
@@ -733,8 +746,14 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
       (shard->own_row0 < 0 || shard->own_row1 > geo.H || shard->own_row0 >= shard->own_row1 ||
        shard->own_row0 != geo.cr0 || shard->own_row1 != geo.cr1))
     return set_error(p->ctx, SRMAP_EINVAL, "row shard: owned rows must equal the problem's cost rows");
-  if (mode == SRMAP_SHARD_CHANNELS && (shard->own_ch0 < 0 || shard->own_ch1 > C || shard->own_ch0 >= shard->own_ch1))
+  if ((mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) &&
+      (shard->own_ch0 < 0 || shard->own_ch1 > C || shard->own_ch0 >= shard->own_ch1))
     return set_error(p->ctx, SRMAP_EINVAL, "channel shard: bad owned channel range");
+  if (mode == SRMAP_SHARD_GRID && (shard->frame_groups < 1 || comm_world(comm) % shard->frame_groups != 0 ||
+                                   (shard->frame_groups > 1 && !shard->frame_comm)))
+    return set_error(p->ctx, SRMAP_EINVAL, "grid shard: frame_groups must divide the world size and frame_comm must be given");
+  // GRID: the unknowns of a channel block are replicated over its frame groups; group 0 counts them in the reductions
+  const bool grid_replica = mode == SRMAP_SHARD_GRID && shard->frame_groups > 1 && (comm_rank(comm) % shard->frame_groups) != 0;
   const int per_split = opt->split_channels ? 1 : C;
   const int rounds = C / per_split;
   const size_t npts = (size_t)per_split * N;
@@ -743,9 +762,9 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
   for (int r = 0; r < p->nreg; ++r) lambda_sum += p->reg[r].lambda;
   {  // AdjustThresholdsAdaptively (map_solver.cpp:16-26, irls_map_solver.cpp:161-171) on the JOINT problem size
     double params = (double)(int)npts;
-    if (mode == SRMAP_SHARD_ROWS || mode == SRMAP_SHARD_CHANNELS) {
+    if (mode == SRMAP_SHARD_ROWS || mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) {
       double own = mode == SRMAP_SHARD_ROWS ? (double)C * geo.W * (shard->own_row1 - shard->own_row0)
-                                            : (double)(shard->own_ch1 - shard->own_ch0) * N;
+                                            : (grid_replica ? 0.0 : (double)(shard->own_ch1 - shard->own_ch0) * N);
       // every rank must derive the same thresholds: total parameter count = sum of the owned counts
       double* tmp = nullptr;
       SRMAP_HIP(p->ctx, hipMalloc((void**)&tmp, sizeof(double)));
@@ -773,8 +792,9 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
   cg.p = p; cg.st = st; cg.n = npts; cg.comm = comm; cg.shard = shard;
   cg.ow.on = 0; cg.ow.e0 = 0; cg.ow.e1 = npts; cg.ow.W = geo.W; cg.ow.H = geo.H; cg.ow.r0 = 0; cg.ow.r1 = geo.H;
   if (mode == SRMAP_SHARD_ROWS) { cg.ow.on = 1; cg.ow.r0 = shard->own_row0; cg.ow.r1 = shard->own_row1; cg.reduce_scalars = true; }
-  if (mode == SRMAP_SHARD_CHANNELS) {
-    cg.ow.on = 1; cg.ow.e0 = (size_t)shard->own_ch0 * N; cg.ow.e1 = (size_t)shard->own_ch1 * N; cg.reduce_scalars = true;
+  if (mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) {
+    cg.ow.on = 1; cg.ow.e0 = (size_t)shard->own_ch0 * N; cg.ow.e1 = grid_replica ? cg.ow.e0 : (size_t)shard->own_ch1 * N;
+    cg.reduce_scalars = true;
   }
   int rc = cg.alloc();
   // IRLS weights live in the problem's RegSpec (full [C][H][W]); make sure they exist.
@@ -895,7 +915,7 @@ int srmap_eval_sharded_device(srmap_problem* p, srmap_comm* comm, const srmap_sh
   if (rc) return rc;
   if (cost) {
     const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
-    if (mode == SRMAP_SHARD_ROWS || mode == SRMAP_SHARD_CHANNELS) {
+    if (mode == SRMAP_SHARD_ROWS || mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) {
       rc = comm_allreduce(comm, p->d_cost, 1, SRMAP_F64, 0, st);
       if (rc) return rc;
     }

@@ -52,10 +52,11 @@ class SolveReport(C.Structure):
 class ShardDesc(C.Structure):
     _fields_ = [("mode", C.c_int), ("own_row0", C.c_int), ("own_row1", C.c_int),
                 ("send_up_rows", C.c_int), ("send_down_rows", C.c_int),
-                ("own_ch0", C.c_int), ("own_ch1", C.c_int), ("reg_rank", C.c_int)]
+                ("own_ch0", C.c_int), ("own_ch1", C.c_int), ("reg_rank", C.c_int),
+                ("frame_groups", C.c_int), ("frame_comm", C.c_void_p)]
 
 
-SHARD_NONE, SHARD_FRAMES, SHARD_ROWS, SHARD_CHANNELS = 0, 1, 2, 3
+SHARD_NONE, SHARD_FRAMES, SHARD_ROWS, SHARD_CHANNELS, SHARD_GRID = 0, 1, 2, 3, 4
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 HOST_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
@@ -99,6 +100,8 @@ _SIGNATURES = [
     ("srmap_comm_create_rccl", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("srmap_comm_create_host", C.c_int, [C.c_void_p, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_SENDRECV_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("srmap_comm_destroy", None, [C.c_void_p]),
+    ("srmap_comm_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("srmap_comm_split", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("srmap_comm_allreduce", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     ("srmap_eval_sharded_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ShardDesc), C.c_uint, C.c_void_p, C.c_void_p, c_double_p, C.c_void_p]),
     ("srmap_solve_sharded", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ShardDesc), C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
@@ -358,7 +361,7 @@ class Problem:
 class Comm:
     """srmap_comm: RCCL (ranks on different GPUs) or host callbacks over a torch.distributed group (gloo / any)."""
 
-    def __init__(self, ctx, rank, world, backend="rccl", unique_id=None, dist=None, group=None):
+    def __init__(self, ctx, rank, world, backend="rccl", unique_id=None, dist=None, group=None, group_ranks=None):
         self.ctx, self.rank, self.world = ctx, rank, world
         self._h = C.c_void_p()
         self._keep = None
@@ -386,11 +389,11 @@ class Comm:
                     reqs = []
                     if dst >= 0 and sbytes:
                         ts = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(sbytes,)).copy())
-                        reqs.append(dist.isend(ts, dst, group=group))
+                        reqs.append(dist.isend(ts, group_ranks[dst] if group_ranks else dst, group=group))
                     tr = None
                     if src >= 0 and rbytes:
                         tr = torch.empty(rbytes, dtype=torch.uint8)
-                        reqs.append(dist.irecv(tr, src, group=group))
+                        reqs.append(dist.irecv(tr, group_ranks[src] if group_ranks else src, group=group))
                     for r in reqs:
                         r.wait()
                     if tr is not None:
@@ -406,6 +409,20 @@ class Comm:
     def allreduce(self, dev_ptr, count, dtype=F64, op=0, stream=None):
         self.ctx.check(load().srmap_comm_allreduce(self._h, C.c_void_p(dev_ptr), count, dtype, op,
                                                    C.c_void_p(stream) if stream else None))
+
+    def info(self):
+        """(rank, size, backend) as the communicator itself reports them (size = ncclCommCount for RCCL; backend 1 = RCCL)."""
+        r, w, b = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(load().srmap_comm_info(self._h, C.byref(r), C.byref(w), C.byref(b)))
+        return r.value, w.value, b.value
+
+    def split(self, color, key, new_rank, new_world):
+        """ncclCommSplit (RCCL backend): the ranks passing the same color form a new communicator."""
+        c = Comm.__new__(Comm)
+        c.ctx, c.rank, c.world, c._keep = self.ctx, new_rank, new_world, None
+        c._h = C.c_void_p()
+        self.ctx.check(load().srmap_comm_split(self._h, color, key, new_rank, new_world, C.byref(c._h)))
+        return c
 
     @staticmethod
     def unique_id(ctx):

@@ -37,13 +37,13 @@ def main():
     s, b, sigma = 4, 3, 1.0
     K = 8
     shifts = [[k % s, (k * 3) % s] for k in range(K)]
-    C = 4 if mode == "channels" else 2
+    C = 4 if mode in ("channels", "grid") else 2
     W, H = 80, 96
     w, h = W // s, H // s
     gt = rng.random((C, H, W))
     lr = rng.random((K, C, h, w))
     x0 = rng.random((C, H, W))
-    regs = [(srmap.REG_BTV, 0.02, 3, 0.5)] + ([(srmap.REG_TV3D, 0.03, 0, 0.0)] if mode == "channels" else [])
+    regs = [(srmap.REG_BTV, 0.02, 3, 0.5)] + ([(srmap.REG_TV3D, 0.03, 0, 0.0)] if mode in ("channels", "grid") else [])
     opts = srmap.default_irls_options()
     opts.max_num_irls_iterations = 2
     opts.max_num_solver_iterations = 6
@@ -90,6 +90,29 @@ def main():
             x_loc[:, r1 - e0:, :] = -7.0
         own = (slice(None), slice(r0, r1))
         loc_rows = (r0 - e0, r1 - e0)
+    elif mode == "grid":  # frames x channels (BASELINE configs[4]): rank = channel block * frame_groups + frame group
+        FG = 2
+        nblocks = world // FG
+        cb, fg = rank // FG, rank % FG
+        c0, c1 = srmap_dist.channel_shard(C, nblocks, cb)
+        lo, hi = (1 if c0 > 0 else 0), (1 if c1 < C else 0)
+        ids = srmap_dist.frame_shard(K, FG, fg)
+        p = srmap.Problem(ctx, W, H, (c1 - c0) + lo + hi, len(ids), s, [shifts[k] for k in ids], b, sigma, srmap.F64)
+        p.set_observations(lr[ids][:, c0 - lo:c1 + hi])
+        for r in regs:
+            p.add_regularizer(*r)
+        groups = [dist.new_group([blk * FG + f for f in range(FG)]) for blk in range(nblocks)]  # collective: every rank creates all
+        fcomm = srmap.Comm(ctx, fg, FG, backend="host", dist=dist, group=groups[cb], group_ranks=[cb * FG + f for f in range(FG)])
+        sd.mode = srmap.SHARD_GRID
+        sd.own_ch0, sd.own_ch1 = lo, lo + (c1 - c0)
+        sd.frame_groups = FG
+        sd.frame_comm = fcomm._h
+        x_loc = x0[c0 - lo:c1 + hi].copy()
+        if lo:
+            x_loc[0] = -7.0
+        if hi:
+            x_loc[-1] = -7.0
+        own = (slice(c0, c1), slice(None))
     else:  # channels, coupled by the 3-D TV regulariser: one halo plane per neighbour
         c0, c1 = srmap_dist.channel_shard(C, world, rank)
         lo, hi = (1 if c0 > 0 else 0), (1 if c1 < C else 0)
@@ -140,6 +163,11 @@ def main():
             res["replicas_equal"] = all(np.array_equal(gathered_x[0], gx) for gx in gathered_x)
         elif mode == "rows":
             g_all, x_all = np.concatenate(gathered_g, axis=1), np.concatenate(gathered_x, axis=1)
+        elif mode == "grid":  # one replica per channel block (frame group 0); the replicas of a block must agree
+            g_all = np.concatenate(gathered_g[0::2], axis=0)
+            x_all = np.concatenate(gathered_x[0::2], axis=0)
+            res["replicas_equal"] = all(np.array_equal(gathered_x[i], gathered_x[i + 1]) and
+                                        np.array_equal(gathered_g[i], gathered_g[i + 1]) for i in range(0, world, 2))
         else:
             g_all, x_all = np.concatenate(gathered_g, axis=0), np.concatenate(gathered_x, axis=0)
         res.update(cost_err=abs(f - f_ref) / max(1.0, abs(f_ref)), grad_err=relerr(g_all, g_ref),

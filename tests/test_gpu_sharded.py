@@ -25,9 +25,10 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("mode", ["frames", "rows", "channels"])
+@pytest.mark.parametrize("mode", ["frames", "rows", "channels", "grid"])
 def test_two_ranks_on_one_gpu(tmp_path, mode):
-    world, port = 2, _free_port()
+    """2 ranks (grid: 4 = 2 channel blocks x 2 frame groups, the frames x channels sharding of BASELINE configs[4])."""
+    world, port = (4 if mode == "grid" else 2), _free_port()
     out = str(tmp_path / "res.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(r), str(world),
@@ -47,10 +48,33 @@ def test_two_ranks_on_one_gpu(tmp_path, mode):
     print(res)
     assert res["cost_err"] <= 1e-12 and res["grad_err"] <= 1e-11
     # same decisions on every rank and as the single-process solve; iterates equal up to reduction order
-    assert res["cg"][0] == res["cg"][1] and res["irls"][0] == res["irls"][1] and res["evals"][0] == res["evals"][1]
+    assert len(set(res["cg"])) == 1 and len(set(res["irls"])) == 1 and len(set(res["evals"])) == 1
     assert res["solve_err"] <= 1e-9
-    if mode == "frames":
+    if mode in ("frames", "grid"):
         assert res["replicas_equal"]
+
+
+@pytest.mark.parametrize("shard", ["rows", "channels"])
+def test_bench_spawns_its_ranks(shard):
+    """`python bench.py --gpus 2` as a bare subprocess (no launcher, no WORLD_SIZE): the bench re-executes itself under
+    torch.distributed.run, one rank per process; here both ranks share GPU 0 over the host-callback communicator."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-single-device", "--steps", "5",
+                        "--warmup", "2", "--clock-ramp-ms", "0", "--min-timed-ms", "0", "--hr", "512", "--shard", shard],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
+    assert out["config"]["shard"] == shard
+    if shard == "rows":
+        assert out["scaling"] == "strong" and out["config"]["rccl_ranks"] == 2
+        assert out["frames_variant"]["value"] > 0 and "ncclAllReduce" in out["frames_variant"]["collective_per_step"]
+        assert "ncclSend" in out["config"]["collective_per_step"]
+    else:
+        assert out["scaling"] == "weak" and out["config"]["collective_per_step"].startswith("none")
 
 
 def test_rccl_backend_world_one():
