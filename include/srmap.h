@@ -22,6 +22,37 @@
  *     host thread at a time.
  *   - there is no CPU fallback: without a usable HIP device every entry point
  *     that computes fails with SRMAP_EHIP.
+ *
+ * Streams (the ordering contract of every entry point that takes a DEVICE pointer)
+ *   - a context owns one NON-BLOCKING HIP stream: it is not ordered against the
+ *     legacy default stream or any other stream.  Every *_device entry point
+ *     takes `hip_stream` (a hipStream_t; NULL = the context's stream) and
+ *     enqueues ALL its work there, so a device buffer the caller produced on
+ *     stream S is ordered by passing S -- or by completing S first.  Nothing the
+ *     library enqueues runs on the legacy stream.
+ *   - entry points that take HOST pointers (srmap_eval, srmap_solve*,
+ *     srmap_cg_trace, srmap_apply*, srmap_reg_values*, srmap_set_observations,
+ *     srmap_set_irls_weights, srmap_channel_map, srmap_channel_pca,
+ *     srmap_register_translational, srmap_upload / srmap_download) run on the
+ *     context's stream and are complete when they return.
+ *   - the problem's device state (observations, IRLS weights) is ordered by the
+ *     library itself: a write through srmap_update_irls_weights_device on one
+ *     stream is waited for (an event) by evaluations on another, and a writer
+ *     first drains the stream of the last evaluation when it is a different one.
+ *     srmap_set_observations_device is complete when it returns.
+ *   - srmap_eval_device / srmap_eval_sharded_device with cost == NULL return
+ *     right after enqueueing; x_dev / g_dev must stay alive and untouched by
+ *     other streams until the stream reaches that point.
+ *
+ * Input domain
+ *   - pixel values, observations and weights are finite IEEE numbers.  The tile
+ *     kernels stage x multiplied by 2^512 (f64) / 2^64 (f32) (an exact scaling
+ *     that turns the regulariser's sign() into a clamp):
+ *     results equal the reference's for |x| < 2^508 (f64) / 2^60 (f32) and for
+ *     pixel differences that are 0 or >= 2^-512 (f64) / 2^-64 (f32) in
+ *     magnitude.  (Beyond 2^511 the reference's own cost, a sum of squared
+ *     residuals, overflows.)  Inputs outside that range: force
+ *     SRMAP_IMPL_DIRECT, which has no such scaling.
  */
 #ifndef SRMAP_H_
 #define SRMAP_H_
@@ -95,6 +126,10 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* desc,
                          srmap_problem** out);
 void srmap_problem_destroy(srmap_problem* p);
 int srmap_problem_set_impl(srmap_problem* p, int impl /* srmap_impl */);
+/* The family the next evaluation will run (SRMAP_IMPL_DIRECT / TILED / MARCH): how a caller learns that AUTO fell
+ * back to the direct kernels (geometry outside the tile kernels' coverage, or a sub-pixel shift on a 1/32-px
+ * rounding tie, whose per-row table only the direct kernels read). */
+int srmap_problem_active_impl(const srmap_problem* p, int* impl);
 
 /* Row-band sharding (no reference counterpart: the reference is single-process).
  * A rank that owns HR rows [r0, r1) of a larger image creates its problem on the
@@ -114,8 +149,9 @@ int srmap_problem_lr_size(const srmap_problem* p, int* lr_width, int* lr_height)
  * keeps LR and accounts for the s*s replication arithmetically.)  Requires
  * hr size == lr size * scale. */
 int srmap_set_observations(srmap_problem* p, const double* lr_host);
-/* Same from a device buffer holding the problem dtype. */
-int srmap_set_observations_device(srmap_problem* p, const void* lr_dev);
+/* Same from a device buffer holding the problem dtype, copied on hip_stream
+ * (NULL = the context's stream); complete on return. */
+int srmap_set_observations_device(srmap_problem* p, const void* lr_dev, void* hip_stream);
 
 /* MapSolver::AddRegularizer(regularizer, regularization_parameter)
  * map_solver.cpp:88-94; constructors tv_regularizer.h / btv_regularizer.cpp
@@ -127,8 +163,10 @@ int srmap_clear_regularizers(srmap_problem* p);
 /* The irls_weights_ vector an ObjectiveIRLSRegularizationTerm holds
  * (objective_irls_regularization_term.h:40); NULL = all ones. */
 int srmap_set_irls_weights(srmap_problem* p, int reg, const double* w_host);
-/* w = 1 / max(1e-5, regularizer(x)) on device, irls_map_solver.cpp:128-143. */
-int srmap_update_irls_weights_device(srmap_problem* p, int reg, const void* x_dev);
+/* w = 1 / max(1e-5, regularizer(x)) on device, irls_map_solver.cpp:128-143.
+ * Enqueued on hip_stream (NULL = the context's stream) and NOT waited for:
+ * later evaluations on any stream are ordered after it by the library. */
+int srmap_update_irls_weights_device(srmap_problem* p, int reg, const void* x_dev, void* hip_stream);
 
 /* ------------------------------------------------------- operators (host) */
 /* ImageModel::ApplyToImage(ImageData*, index) image_model.cpp:86-91:
@@ -198,10 +236,11 @@ int srmap_channel_map_device(srmap_ctx* ctx, int rows_out, int rows_in, size_t n
 int srmap_channel_pca(srmap_ctx* ctx, int rows, size_t count, const double* samples_host,
                       double* mean_out, double* eigenvalues_out, double* basis_out);
 /* The same on a device-resident planar f64 cube in_dev [rows][n]: the samples are the pixels
- * first + j * stride, j < count. */
+ * first + j * stride, j < count.  Enqueued on hip_stream (NULL = the context's stream); returns when the
+ * (host) results are complete. */
 int srmap_channel_pca_device(srmap_ctx* ctx, int rows, size_t n, const double* in_dev,
                              size_t first, size_t stride, size_t count, double* mean_out,
-                             double* eigenvalues_out, double* basis_out);
+                             double* eigenvalues_out, double* basis_out, void* hip_stream);
 
 /* ------------------------------------------------------- registration */
 /* registration::TranslationalRegistration (src/motion/registration.h:19-22, registration.cpp:161-201): the
@@ -214,6 +253,17 @@ int srmap_channel_pca_device(srmap_ctx* ctx, int rows, size_t n, const double* i
  * can be determined (the reference CHECK-fails, registration.cpp:193-194). */
 int srmap_register_translational(srmap_ctx* ctx, int num_images, int width, int height,
                                  const double* images_host, double* shifts_xy_out);
+/* What this estimator is NOT: the reference finds features (BRISK), fits a RANSAC homography / rigid transform and
+ * keeps its translation, so it tolerates some rotation, scale and outliers.  This one assumes a PURE TRANSLATION
+ * of at most a quarter of the frame (16 pixels of the coarsest pyramid level), has no outlier rejection, and its
+ * sub-pixel step stays within +-1 px of the integer search.  On periodic texture it can lock onto a wrong period;
+ * rotation / scale between frames bias the result.  The _ex form reports how trustworthy each shift is --
+ * quality_out (optional, 2 doubles per image): [2i] separation = 1 - best / runner-up mean squared difference of
+ * the coarsest search (runner-up at least 2 coarse pixels away; near 1 = one clear minimum, near 0 = ambiguous),
+ * [2i + 1] the root mean squared residual at the returned shift.  Callers with real (non-synthetic) stacks
+ * should check both, or supply shifts from their own registration (MotionShiftSequence accepts any). */
+int srmap_register_translational_ex(srmap_ctx* ctx, int num_images, int width, int height,
+                                    const double* images_host, double* shifts_xy_out, double* quality_out);
 
 /* ------------------------------------------------------------- solver */
 /* IRLSMapSolverOptions (irls_map_solver.h:14-36) + MapSolverOptions

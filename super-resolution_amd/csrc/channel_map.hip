@@ -120,13 +120,13 @@ extern "C" int srmap_channel_map_device(srmap_ctx* ctx, int rows_out, int rows_i
 // rows x rows, row k = k-th eigenvector, sign: its largest-magnitude component is positive).
 extern "C" int srmap_channel_pca_device(srmap_ctx* ctx, int rows, size_t n, const double* in_dev, size_t first,
                                         size_t stride, size_t count, double* mean_out, double* eigenvalues_out,
-                                        double* basis_out) {
+                                        double* basis_out, void* hip_stream) {
   if (!ctx || !in_dev || !mean_out || !eigenvalues_out || !basis_out || rows <= 0 || count == 0 || stride == 0)
     return SRMAP_EINVAL;
   if (first + (count - 1) * stride >= n) return set_error(ctx, SRMAP_EINVAL, "PCA samples outside the cube");
   if (count > (size_t)0x7fffffff) return set_error(ctx, SRMAP_EUNSUPPORTED, "more than 2^31 samples");
   SRMAP_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   rocblas_handle handle;
   int rc = blas_handle(ctx, st, &handle);
   if (rc) return rc;
@@ -189,7 +189,7 @@ extern "C" int srmap_channel_pca(srmap_ctx* ctx, int rows, size_t count, const d
   hipError_t e = hipMemcpy(d, samples_host, (size_t)rows * count * sizeof(double), hipMemcpyHostToDevice);
   int rc = SRMAP_OK;
   if (e != hipSuccess) rc = set_error(ctx, SRMAP_EHIP, "upload of the PCA samples failed");
-  if (rc == SRMAP_OK) rc = srmap_channel_pca_device(ctx, rows, count, d, 0, 1, count, mean_out, eigenvalues_out, basis_out);
+  if (rc == SRMAP_OK) rc = srmap_channel_pca_device(ctx, rows, count, d, 0, 1, count, mean_out, eigenvalues_out, basis_out, nullptr);
   (void)hipFree(d);
   return rc;
 }

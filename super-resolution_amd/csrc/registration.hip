@@ -112,6 +112,16 @@ using namespace srmap;
 
 extern "C" int srmap_register_translational(srmap_ctx* ctx, int num_images, int width, int height,
                                             const double* images_host, double* shifts_xy_out) {
+  return srmap_register_translational_ex(ctx, num_images, width, height, images_host, shifts_xy_out, nullptr);
+}
+
+// quality_out (optional): 2 doubles per image --
+//   [2i]     separation = 1 - best / runner-up of the coarsest search, the runner-up being the smallest mean squared
+//            difference among candidates at least 2 coarse pixels away from the best one: near 1 = one clear minimum,
+//            near 0 = ambiguous (periodic texture, no texture, motion that is not a translation);
+//   [2i + 1] root mean squared residual I_i(p + d) - I_0(p) at the returned shift (same units as the pixels).
+extern "C" int srmap_register_translational_ex(srmap_ctx* ctx, int num_images, int width, int height,
+                                               const double* images_host, double* shifts_xy_out, double* quality_out) {
   if (!ctx || !shifts_xy_out || num_images < 0) return SRMAP_EINVAL;
   if (num_images == 0) return SRMAP_OK;  // registration.cpp:165-168: empty sequence
   if (!images_host || width < 8 || height < 8) return set_error(ctx, SRMAP_EINVAL, "registration needs images of at least 8 x 8");
@@ -119,6 +129,7 @@ extern "C" int srmap_register_translational(srmap_ctx* ctx, int num_images, int 
   hipStream_t st = ctx->stream;
   const size_t npx = (size_t)width * height;
   shifts_xy_out[0] = 0.0; shifts_xy_out[1] = 0.0;  // registration.cpp:170-172
+  if (quality_out) { quality_out[0] = 1.0; quality_out[1] = 0.0; }
   if (num_images == 1) return SRMAP_OK;
 
   // level sizes
@@ -168,20 +179,30 @@ extern "C" int srmap_register_translational(srmap_ctx* ctx, int num_images, int 
       if (hipMemcpyAsync(h_part.data(), d_part, (size_t)ncand * chunks * 2 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
           hipStreamSynchronize(st) != hipSuccess) { fail(SRMAP_EHIP, "candidate search failed"); break; }
       double best = 0.0; int bi = -1;
+      std::vector<double> msd(ncand, -1.0);
       for (int cnd = 0; cnd < ncand; ++cnd) {
         double s = 0.0, n = 0.0;
         for (int k = 0; k < chunks; ++k) { s += h_part[((size_t)cnd * chunks + k) * 2]; n += h_part[((size_t)cnd * chunks + k) * 2 + 1]; }
         if (n < 0.25 * lw[l] * lh[l]) continue;  // overlap too small to mean anything
         const double m = s / n;
+        msd[cnd] = m;
         if (bi < 0 || m < best) { best = m; bi = cnd; }
       }
       if (bi < 0) { fail(SRMAP_EINVAL, "Could not determine motion shift between images."); break; }  // registration.cpp:193-194
+      if (l == L - 1 && quality_out) {
+        double runner = -1.0;
+        for (int cnd = 0; cnd < ncand; ++cnd) {
+          if (msd[cnd] < 0 || std::max(std::abs(cnd % n1 - bi % n1), std::abs(cnd / n1 - bi / n1)) < 2) continue;
+          if (runner < 0 || msd[cnd] < runner) runner = msd[cnd];
+        }
+        quality_out[2 * i] = runner > 0 ? 1.0 - best / runner : 0.0;
+      }
       sx = sx - R + bi % n1;
       sy = sy - R + bi / n1;
     }
     if (rc != SRMAP_OK) break;
     // ---- sub-pixel refinement at full resolution ----
-    double dx = sx, dy = sy;
+    double dx = sx, dy = sy, rms = -1.0;
     for (int it = 0; it < 20; ++it) {
       const int margin = (int)std::ceil(std::max(std::fabs(dx), std::fabs(dy))) + 2;
       const int rows = height - 2 * margin;
@@ -192,6 +213,7 @@ extern "C" int srmap_register_translational(srmap_ctx* ctx, int num_images, int 
       double S[6] = {0, 0, 0, 0, 0, 0};
       for (int r = 0; r < rows; ++r)
         for (int q = 0; q < 6; ++q) S[q] += h_part[(size_t)r * 6 + q];
+      rms = std::sqrt(S[5] / ((double)rows * (width - 2 * margin)));  // at the (dx, dy) this pass evaluated
       const double det = S[0] * S[2] - S[1] * S[1];
       if (!(det > 1e-12 * (S[0] * S[2] + 1e-300))) break;  // no texture: integer estimate stands
       const double ux = -(S[2] * S[3] - S[1] * S[4]) / det, uy = -(S[0] * S[4] - S[1] * S[3]) / det;
@@ -202,6 +224,7 @@ extern "C" int srmap_register_translational(srmap_ctx* ctx, int num_images, int 
     }
     shifts_xy_out[2 * i] = dx;
     shifts_xy_out[2 * i + 1] = dy;
+    if (quality_out) quality_out[2 * i + 1] = rms;
   }
   if (d_a) (void)hipFree(d_a);
   if (d_b) (void)hipFree(d_b);

@@ -216,6 +216,11 @@ int shard_exchange_x(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd
   const int up = rank > 0 ? rank - 1 : -1, down = rank + 1 < world ? rank + 1 : -1;
   char* x = (char*)x_dev;
   if (sd->mode == SRMAP_SHARD_ROWS) {
+    // a frame whose warpAffine y coordinate sits on a 1/32-px rounding tie carries a per-row table built from the row
+    // index of THIS problem (srmap_api.hip make_warp): a band problem would evaluate the tie at its local rows, not
+    // the joint image's
+    if (!p->d_ytabs.empty())
+      return set_error(p->ctx, SRMAP_EUNSUPPORTED, "row shard: a sub-pixel shift on a 1/32-px rounding tie needs the joint image's row index; shard such problems by frames or channels");
     const int hu = sd->own_row0, hd = g.H - sd->own_row1;  // my halo rows above / below
     if ((up >= 0 && hu == 0) || (down >= 0 && hd == 0) || sd->send_down_rows > sd->own_row1 - sd->own_row0 ||
         sd->send_up_rows > sd->own_row1 - sd->own_row0)
@@ -352,6 +357,10 @@ struct DeviceCG {
     SRMAP_HIP(p->ctx, hipMalloc((void**)&part, sizeof(double) * 3 * kRedBlocks));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&dscal, sizeof(double) * 8));
     SRMAP_HIP(p->ctx, hipMemsetAsync(dscal, 0, sizeof(double) * 8, st));
+    // sharded evaluations write only the owned part of g: the vector kernels run over all n elements, so everything
+    // they combine starts defined (the halo values never enter a reduction, and x halos are re-exchanged)
+    T* z[] = {g, dn, d, dk, yk};
+    for (T* q : z) SRMAP_HIP(p->ctx, hipMemsetAsync(q, 0, n * sizeof(T), st));
     int rc = ensure_staging(p->ctx);
     if (rc) return rc;
     hs = p->ctx->h_scal;

@@ -78,7 +78,7 @@ static int make_warp(srmap_ctx* ctx, int W, int H, double dx, double dy,
     // (cvRound((y + b) * 1024) evaluated in double) lands on either side of the tie depending on the row.  The
     // kernels then read the source row and fraction of every destination row from a table.
     ytab->resize(H);
-    for (int y = 0; y < H; ++y) (*ytab)[y] = Y[y] + 0 * 32 * y;  // absolute: source row << 5 | fraction
+    for (int y = 0; y < H; ++y) (*ytab)[y] = Y[y];  // absolute: source row << 5 | fraction
     out->ntaps = 4;
   }
   return SRMAP_OK;
@@ -301,8 +301,33 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
   return launch_reduce_partials(p, p->d_partials, nparts, p->d_cost, st);
 }
 
+// ---- stream ordering of the problem's device state (include/srmap.h, "Streams") ----
+// before overwriting observations / weights: the last evaluation may still be reading them on another stream
+static int state_begin_write(srmap_problem* p, hipStream_t st) {
+  if (p->use_stream && p->use_stream != st) SRMAP_HIP(p->ctx, hipStreamSynchronize(p->use_stream));
+  return SRMAP_OK;
+}
+// after an ASYNCHRONOUS write on st: later evaluations on other streams wait for this event
+static int state_end_write(srmap_problem* p, hipStream_t st) {
+  if (!p->state_ev) SRMAP_HIP(p->ctx, hipEventCreateWithFlags(&p->state_ev, hipEventDisableTiming));
+  SRMAP_HIP(p->ctx, hipEventRecord(p->state_ev, st));
+  p->state_stream = st;
+  p->state_seen = nullptr;
+  return SRMAP_OK;
+}
+// an evaluation on st: ordered after the last asynchronous state write (nothing to do on the same stream)
+static inline int state_read(srmap_problem* p, hipStream_t st) {
+  if (p->state_stream && p->state_stream != st && p->state_seen != st) {
+    SRMAP_HIP(p->ctx, hipStreamWaitEvent(st, p->state_ev, 0));
+    p->state_seen = st;
+  }
+  p->use_stream = st;
+  return SRMAP_OK;
+}
+
 static int eval_dispatch(srmap_problem* p, unsigned terms, const void* x, void* g,
                          hipStream_t st) {
+  if (int rc = state_read(p, st)) return rc;
   if (p->dtype == SRMAP_F32) return eval_typed<float>(p, terms, (const float*)x, (float*)g, st);
   return eval_typed<double>(p, terms, (const double*)x, (double*)g, st);
 }
@@ -469,7 +494,10 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
     return fail(set_error(ctx, SRMAP_ENOMEM, "hipMalloc failed"));
   (void)hipMemcpy(p->d_col_map, cmap.data(), sizeof(int) * g.w, hipMemcpyHostToDevice);
   (void)hipMemcpy(p->d_row_map, rmap.data(), sizeof(int) * g.h, hipMemcpyHostToDevice);
-  (void)hipMemset(p->d_cost, 0, sizeof(double) * 8);
+  // everything above used blocking copies; d_cost is first touched by kernels on caller streams: clear it on the
+  // context's (non-blocking) stream and wait, so no legacy-stream work is left behind the creation
+  if (hipMemsetAsync(p->d_cost, 0, sizeof(double) * 8, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return fail(set_error(ctx, SRMAP_EHIP, "clearing the cost scalars failed"));
   if (ztile_plan(p)) ztile_preload(p);
   *out = p;
   return SRMAP_OK;
@@ -483,6 +511,7 @@ void srmap_problem_destroy(srmap_problem* p) {
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) (void)hipFree(p->reg[r].weights);
   for (int* t : p->d_ytabs) (void)hipFree(t);
+  if (p->state_ev) (void)hipEventDestroy(p->state_ev);
   delete p;
 }
 
@@ -491,6 +520,14 @@ int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_MARCH) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
   if (impl == SRMAP_IMPL_MARCH) ztile_preload(p);  // its code objects load now, not inside the first evaluation
+  return SRMAP_OK;
+}
+
+int srmap_problem_active_impl(const srmap_problem* p, int* impl) {
+  if (!p || !impl) return SRMAP_EINVAL;
+  const bool ztile = p->impl != SRMAP_IMPL_DIRECT && p->zplan != nullptr;
+  if (p->impl == SRMAP_IMPL_MARCH && ztile && ztile_covers_march(p)) *impl = SRMAP_IMPL_MARCH;
+  else *impl = ztile ? SRMAP_IMPL_TILED : SRMAP_IMPL_DIRECT;
   return SRMAP_OK;
 }
 
@@ -526,6 +563,8 @@ int srmap_set_observations(srmap_problem* p, const double* lr_host) {
   int rc = need_solver_geometry(p);
   if (rc) return rc;
   SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
+  rc = state_begin_write(p, p->ctx->stream);
+  if (rc) return rc;
   rc = ensure(p, &p->d_obs, p->lr_count() * p->elem());
   if (rc) return rc;
   rc = convert_upload(p, lr_host, p->d_obs, p->lr_count(), p->ctx->stream);
@@ -534,15 +573,18 @@ int srmap_set_observations(srmap_problem* p, const double* lr_host) {
   return SRMAP_OK;
 }
 
-int srmap_set_observations_device(srmap_problem* p, const void* lr_dev) {
+int srmap_set_observations_device(srmap_problem* p, const void* lr_dev, void* hip_stream) {
   if (!p || !lr_dev) return SRMAP_EINVAL;
   int rc = need_solver_geometry(p);
   if (rc) return rc;
   SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : p->ctx->stream;
+  rc = state_begin_write(p, st);
+  if (rc) return rc;
   rc = ensure(p, &p->d_obs, p->lr_count() * p->elem());
   if (rc) return rc;
-  SRMAP_HIP(p->ctx, hipMemcpyAsync(p->d_obs, lr_dev, p->lr_count() * p->elem(), hipMemcpyDeviceToDevice, p->ctx->stream));
-  SRMAP_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
+  SRMAP_HIP(p->ctx, hipMemcpyAsync(p->d_obs, lr_dev, p->lr_count() * p->elem(), hipMemcpyDeviceToDevice, st));
+  SRMAP_HIP(p->ctx, hipStreamSynchronize(st));  // complete on return: lr_dev may be reused, any stream may evaluate
   p->have_obs = true;
   return SRMAP_OK;
 }
@@ -583,32 +625,39 @@ int srmap_set_irls_weights(srmap_problem* p, int reg, const double* w_host) {
   if (!p || reg < 0 || reg >= p->nreg) return SRMAP_EINVAL;
   SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
   RegSpec& rs = p->reg[reg];
+  int rc = state_begin_write(p, p->ctx->stream);
+  if (rc) return rc;
   if (!w_host) {
     if (rs.weights) { (void)hipFree(rs.weights); rs.weights = nullptr; }
     return SRMAP_OK;
   }
-  int rc = ensure(p, &rs.weights, p->hr_count() * p->elem());
+  rc = ensure(p, &rs.weights, p->hr_count() * p->elem());
   if (rc) return rc;
   return convert_upload(p, w_host, rs.weights, p->hr_count(), p->ctx->stream);
 }
 
-int srmap_update_irls_weights_device(srmap_problem* p, int reg, const void* x_dev) {
+int srmap_update_irls_weights_device(srmap_problem* p, int reg, const void* x_dev, void* hip_stream) {
   if (!p || reg < 0 || reg >= p->nreg || !x_dev) return SRMAP_EINVAL;
   SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
   RegSpec& rs = p->reg[reg];
-  hipStream_t st = p->ctx->stream;
-  int rc = ensure(p, &rs.weights, p->hr_count() * p->elem());
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : p->ctx->stream;
+  int rc = state_begin_write(p, st);
+  if (rc) return rc;
+  rc = ensure(p, &rs.weights, p->hr_count() * p->elem());
   if (rc) return rc;
   rc = ensure(p, &p->d_regvals, p->hr_count() * p->elem());
   if (rc) return rc;
   if (p->dtype == SRMAP_F32) {
     rc = launch_reg_values<float>(p, p->geo, rs, (const float*)x_dev, (float*)p->d_regvals, st);
     if (rc) return rc;
-    return launch_irls_weights<float>(p, (const float*)p->d_regvals, (float*)rs.weights, p->hr_count(), st);
+    rc = launch_irls_weights<float>(p, (const float*)p->d_regvals, (float*)rs.weights, p->hr_count(), st);
+  } else {
+    rc = launch_reg_values<double>(p, p->geo, rs, (const double*)x_dev, (double*)p->d_regvals, st);
+    if (rc) return rc;
+    rc = launch_irls_weights<double>(p, (const double*)p->d_regvals, (double*)rs.weights, p->hr_count(), st);
   }
-  rc = launch_reg_values<double>(p, p->geo, rs, (const double*)x_dev, (double*)p->d_regvals, st);
   if (rc) return rc;
-  return launch_irls_weights<double>(p, (const double*)p->d_regvals, (double*)rs.weights, p->hr_count(), st);
+  return state_end_write(p, st);  // asynchronous: evaluations on other streams wait for this event
 }
 
 // ---- operators on host buffers ----

@@ -107,6 +107,11 @@ struct srmap_problem {
   double* eval_pub_tag_slot = nullptr;
   double eval_pub_tag = 0.0;
   bool eval_published = false;
+  // stream ordering of the device STATE an evaluation reads (observations, IRLS weights): state_ev is recorded on the
+  // stream that last wrote it asynchronously (state_stream); an evaluation on another stream waits for it once
+  // (state_seen); a writer on another stream than the last evaluation's (use_stream) drains that stream first
+  hipEvent_t state_ev = nullptr;
+  hipStream_t state_stream = nullptr, state_seen = nullptr, use_stream = nullptr;
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
   void* zplan = nullptr;          // srmap::ZPlan of the z-tile kernels (kernels_ztile.hip), owned; nullptr = not covered

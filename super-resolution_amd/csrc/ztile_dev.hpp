@@ -276,15 +276,17 @@ struct ZArgs {
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
 // true difference times 2^Q, large enough that sgn(d) * pw is just a clamp to [-pw, pw] (no ldexp per tap), and
 // the scale drops out of the sums exactly (r = r' * 2^-Q, B x = (B x') * 2^-Q).  Exact for |d| >= 2^-Q and pixel
-// magnitudes below 2^(Emax - Q - 3): Q = 1000 (f64), 100 (f32).
+// magnitudes below 2^(Emax - Q - 3).  Q sits in the MIDDLE of the exponent range -- 512 (f64), 64 (f32) -- so the
+// input domain is |x| < 2^508 (f64; the reference's own cost, a sum of r^2, overflows beyond 2^511) / 2^60 (f32), and
+// differences down to 2^-512 / 2^-64 are still told from 0 (include/srmap.h, "Input domain").
 template <typename T> struct Pre;
 template <> struct Pre<double> {
-  static constexpr int Q = 1000;
+  static constexpr int Q = 512;
   static __device__ __forceinline__ double up(double v) { return __builtin_ldexp(v, Q); }
   static __device__ __forceinline__ double down(double v) { return __builtin_ldexp(v, -Q); }
 };
 template <> struct Pre<float> {
-  static constexpr int Q = 100;
+  static constexpr int Q = 64;
   static __device__ __forceinline__ float up(float v) { return __builtin_ldexpf(v, Q); }
   static __device__ __forceinline__ float down(float v) { return __builtin_ldexpf(v, -Q); }
 };

@@ -72,11 +72,12 @@ _SIGNATURES = [
     ("srmap_problem_set_impl", C.c_int, [C.c_void_p, C.c_int]),
     ("srmap_problem_lr_size", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("srmap_set_observations", C.c_int, [C.c_void_p, c_double_p]),
-    ("srmap_set_observations_device", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("srmap_problem_active_impl", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    ("srmap_set_observations_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("srmap_add_regularizer", C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int)]),
     ("srmap_clear_regularizers", C.c_int, [C.c_void_p]),
     ("srmap_set_irls_weights", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
-    ("srmap_update_irls_weights_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    ("srmap_update_irls_weights_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("srmap_apply", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
     ("srmap_apply_transpose", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
     ("srmap_reg_values", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
@@ -91,8 +92,9 @@ _SIGNATURES = [
     ("srmap_channel_map", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("srmap_channel_map_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("srmap_register_translational", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
+    ("srmap_register_translational_ex", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     ("srmap_channel_pca", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p]),
-    ("srmap_channel_pca_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, c_double_p, c_double_p, c_double_p]),
+    ("srmap_channel_pca_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     ("srmap_synchronize", C.c_int, [C.c_void_p]),
     ("srmap_irls_options_default", None, [C.POINTER(IrlsOptions)]),
     ("srmap_solve", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
@@ -170,13 +172,19 @@ class Context:
         self.check(load().srmap_channel_map_device(self._h, ro, ri, n, pM, oi[1], oo[1], C.c_void_p(in_ptr),
                                                    C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
 
-    def register_translational(self, images):
-        """registration::TranslationalRegistration: images [n][H][W] -> shifts [n][2] (dx, dy) relative to image 0."""
+    def register_translational(self, images, with_quality=False):
+        """registration::TranslationalRegistration: images [n][H][W] -> shifts [n][2] (dx, dy) relative to image 0
+        (with_quality: also [n][2] = separation of the coarse minimum, RMS residual -- srmap.h)."""
         a, pa = _d(images)
         n, H, W = a.shape
         out = np.zeros((n, 2))
-        self.check(load().srmap_register_translational(self._h, n, W, H, pa, out.ctypes.data_as(c_double_p)))
-        return out
+        if not with_quality:
+            self.check(load().srmap_register_translational(self._h, n, W, H, pa, out.ctypes.data_as(c_double_p)))
+            return out
+        q = np.zeros((n, 2))
+        self.check(load().srmap_register_translational_ex(self._h, n, W, H, pa, out.ctypes.data_as(c_double_p),
+                                                          q.ctypes.data_as(c_double_p)))
+        return out, q
 
     def pca(self, samples):
         """PCA of planar samples [rows][count] on the GPU: (mean, eigenvalues descending, basis rows = eigenvectors)."""
@@ -187,11 +195,11 @@ class Context:
                                             ev.ctypes.data_as(c_double_p), basis.ctypes.data_as(c_double_p)))
         return mean, ev, basis
 
-    def pca_device(self, in_ptr, rows, n, first, stride, count):
+    def pca_device(self, in_ptr, rows, n, first, stride, count, stream=None):
         mean, ev, basis = np.empty(rows), np.empty(rows), np.empty((rows, rows))
         self.check(load().srmap_channel_pca_device(self._h, rows, n, C.c_void_p(in_ptr), first, stride, count,
                                                    mean.ctypes.data_as(c_double_p), ev.ctypes.data_as(c_double_p),
-                                                   basis.ctypes.data_as(c_double_p)))
+                                                   basis.ctypes.data_as(c_double_p), C.c_void_p(stream or 0)))
         return mean, ev, basis
 
     def __del__(self):
@@ -248,8 +256,13 @@ class Problem:
         assert a.size == self.K * self.C * self.h * self.w, (a.shape, self.K, self.C, self.h, self.w)
         self.ctx.check(load().srmap_set_observations(self._h, pa))
 
-    def set_observations_device(self, ptr):
-        self.ctx.check(load().srmap_set_observations_device(self._h, C.c_void_p(ptr)))
+    def active_impl(self):
+        v = C.c_int(-1)
+        self.ctx.check(load().srmap_problem_active_impl(self._h, C.byref(v)))
+        return v.value
+
+    def set_observations_device(self, ptr, stream=None):
+        self.ctx.check(load().srmap_set_observations_device(self._h, C.c_void_p(ptr), C.c_void_p(stream or 0)))
 
     def add_regularizer(self, kind, lam, btv_range=0, btv_decay=0.0):
         idx = C.c_int(-1)
@@ -269,8 +282,8 @@ class Problem:
             assert a.size == self.C * self.H * self.W
             self.ctx.check(load().srmap_set_irls_weights(self._h, reg, pa))
 
-    def update_irls_weights_device(self, reg, x_ptr):
-        self.ctx.check(load().srmap_update_irls_weights_device(self._h, reg, C.c_void_p(x_ptr)))
+    def update_irls_weights_device(self, reg, x_ptr, stream=None):
+        self.ctx.check(load().srmap_update_irls_weights_device(self._h, reg, C.c_void_p(x_ptr), C.c_void_p(stream or 0)))
 
     def apply(self, hr, k):
         a, pa = _d(hr)
