@@ -306,12 +306,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_reg_values(const T* __restrict__ x,
                                                    T* __restrict__ values, int W, int H,
                                                    int C, int kind, int range,
-                                                   PowTable pw, int zhi) {
+                                                   PowTable pw, int zhi, int as_weights) {
   const int hp = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
   if (hp >= W * H) return;
   const int r = hp / W, col = hp - r * W;
-  values[(size_t)c * W * H + hp] = reg_value_at(x, W, H, C, c, r, col, kind, range, pw, zhi);
+  T v = reg_value_at(x, W, H, C, c, r, col, kind, range, pw, zhi);
+  if (as_weights) {  // w = 1 / max(1e-5, r) in the same pass (k_irls_weights' arithmetic)
+    const T m = v > (T)0.00001 ? v : (T)0.00001;
+    v = T(1) / m;
+  }
+  values[(size_t)c * W * H + hp] = v;
 }
 
 static PowTable make_pow(const RegSpec& rs) {
@@ -325,7 +330,18 @@ int launch_reg_values(srmap_problem* p, const Geometry& g, const RegSpec& rs,
                       const T* x, T* values, hipStream_t st) {
   dim3 grid((g.W * g.H + 255) / 256, g.C);
   hipLaunchKernelGGL(k_reg_values<T>, grid, dim3(256), 0, st, x, values, g.W, g.H, g.C,
-                     rs.kind, rs.range, make_pow(rs), g.zhi);
+                     rs.kind, rs.range, make_pow(rs), g.zhi, 0);
+  SRMAP_HIP(p->ctx, hipGetLastError());
+  return SRMAP_OK;
+}
+
+// The IRLS weights 1 / max(1e-5, regularizer(x)) of irls_map_solver.cpp:128-143 in one pass over x.
+template <typename T>
+int launch_reg_weights(srmap_problem* p, const Geometry& g, const RegSpec& rs,
+                       const T* x, T* weights, hipStream_t st) {
+  dim3 grid((g.W * g.H + 255) / 256, g.C);
+  hipLaunchKernelGGL(k_reg_values<T>, grid, dim3(256), 0, st, x, weights, g.W, g.H, g.C,
+                     rs.kind, rs.range, make_pow(rs), g.zhi, 1);
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
 }
@@ -798,7 +814,8 @@ int launch_reduce_partials(srmap_problem* p, const double* partials, int n, doub
                                              const RegSpec&, const T*, const T*, double,   \
                                              const T*, T*, bool, double*, int*,            \
                                              hipStream_t);                                  \
-  template int launch_irls_weights<T>(srmap_problem*, const T*, T*, size_t, hipStream_t);
+  template int launch_irls_weights<T>(srmap_problem*, const T*, T*, size_t, hipStream_t);       \
+  template int launch_reg_weights<T>(srmap_problem*, const Geometry&, const RegSpec&, const T*, T*, hipStream_t);
 INSTANTIATE(float)
 INSTANTIATE(double)
 

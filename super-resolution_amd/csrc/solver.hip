@@ -11,12 +11,16 @@
 // order.  Per CG iteration the host waits for the device 2 + nfev times: once
 // for (g.d, d.d, direction norms), once per trial point for (f, g.d), once for
 // the beta dot products; the n-vector work is three fused passes:
-//   k_direction      dn = -g + beta dk, yk = -g, partials of max|dn| and dn.dn
-//   k_normalize_dots d = (dn / max|dn|) / ||dn / max|dn|||, partials of g.d, d.d
+//   k_direction      dn = -g + beta dk, max|dn| and dn.dn
+//   k_normalize_dots d = (dn / max|dn|) / ||dn / max|dn|||, g.d, d.d
 //                    (the two scale factors are computed on the device from
 //                    the reduced norms: no host round trip in between)
-//   k_beta_dots      yk += g, partials of yk.dk, g.g, g.yk
-// plus x = xk + stp d and g.d per trial point.
+//   k_beta_dots      y = g - g_prev on the fly (the gradient buffers ping-pong,
+//                    mincg's yk vector is never stored), y.dk, g.g, g.y
+// plus x = xk + stp d and g.d per trial point.  Each pass reduces its sums in
+// the SAME launch: every block publishes its partials as write-through
+// granules, the last block of the grid adds them in index order and hands the
+// results (and the arrival tag) to the host -- no one-block second kernel.
 //
 // Sharding.  Reductions run over the elements a rank OWNS (row band or channel
 // block; everything for frame shards) and are all-reduced through the
@@ -59,8 +63,37 @@ struct Owned {
   }
 };
 
-// block partials of up to 3 sums: part[k * gridDim.x + blockIdx.x]
-__device__ __forceinline__ void block_partials3(double s0, double s1, double s2, double* __restrict__ part, bool max0) {
+// ---- one-launch reductions -------------------------------------------------------------------------------
+// A granule that has not been published yet holds this NaN pattern (both halves equal: hipMemsetD32 arms it).
+constexpr unsigned kArm32 = 0x7FF9ABCDu;
+constexpr unsigned long long kArm = ((unsigned long long)kArm32 << 32) | kArm32;
+__device__ __forceinline__ unsigned long long ld_dev(const unsigned long long* q) {
+  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_dev(unsigned long long* q, unsigned long long v) {
+  __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Where a pass leaves its reduced sums.  gran == nullptr: the two-launch scheme (block partials in `part`, k_finish
+// follows; sharded solves, whose sums go through an all-reduce first).  Otherwise the last block of the grid reduces:
+// out[0 .. rows) (device or host-mapped), the evaluation's cost forwarded from cost_src to out[rows], pub_n further
+// device scalars copied to pub_dst (host-mapped), then the arrival tag behind a system-scope fence.
+struct Fin {
+  unsigned long long* gran;
+  double* out;
+  const double* cost_src;
+  const double* pub_src;
+  double* pub_dst;
+  int pub_n;
+  double* tag_slot;
+  double tag;
+};
+
+// Block partials of up to 3 sums (row 0 a max when max0).  Two-launch scheme: part[k * gridDim.x + blockIdx.x].
+// One-launch scheme: granules, and the grid's last block adds all of them -- per thread i = tid, tid + 256, ... in
+// ascending order, then the wave and the four-wave combination of k_finish: the same additions in the same order as
+// the two-launch scheme.  Returns true in the one thread that wrote out[] (it still owes fin_tag()).
+__device__ __forceinline__ bool block_partials3(double s0, double s1, double s2, double* __restrict__ part, bool max0,
+                                                int rows, const Fin& fin) {
   __shared__ double red[3][4];
   s0 = max0 ? wmax(s0) : wsum(s0);
   s1 = wsum(s1);
@@ -68,28 +101,72 @@ __device__ __forceinline__ void block_partials3(double s0, double s1, double s2,
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { red[0][wid] = s0; red[1][wid] = s1; red[2][wid] = s2; }
   __syncthreads();
+  const int nbk = gridDim.x;
   if (threadIdx.x < 3) {
     const double* r = red[threadIdx.x];
     const double v = (threadIdx.x == 0 && max0) ? fmax(fmax(r[0], r[1]), fmax(r[2], r[3])) : (r[0] + r[1]) + (r[2] + r[3]);
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+    if (fin.gran == nullptr) part[(size_t)threadIdx.x * nbk + blockIdx.x] = v;
+    else if ((int)threadIdx.x < rows) st_dev(fin.gran + (size_t)threadIdx.x * nbk + blockIdx.x, (unsigned long long)__double_as_longlong(v));
+  }
+  if (fin.gran == nullptr || (int)blockIdx.x != nbk - 1) return false;
+  __syncthreads();  // red[] is reused below
+  double v0 = 0, v1 = 0, v2 = 0;
+  for (int i = threadIdx.x; i < nbk; i += 256) {
+    unsigned long long a0 = 0, a1 = 0, a2 = 0;  // +0.0 for absent rows
+    for (;;) {
+      if (rows > 0) a0 = ld_dev(fin.gran + i);
+      if (rows > 1) a1 = ld_dev(fin.gran + (size_t)nbk + i);
+      if (rows > 2) a2 = ld_dev(fin.gran + (size_t)2 * nbk + i);
+      if (a0 != kArm && a1 != kArm && a2 != kArm) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (rows > 0) st_dev(fin.gran + i, kArm);  // re-armed for the next pass
+    if (rows > 1) st_dev(fin.gran + (size_t)nbk + i, kArm);
+    if (rows > 2) st_dev(fin.gran + (size_t)2 * nbk + i, kArm);
+    const double d0 = __longlong_as_double((long long)a0), d1 = __longlong_as_double((long long)a1), d2 = __longlong_as_double((long long)a2);
+    v0 = max0 ? fmax(v0, d0) : v0 + d0;
+    v1 += d1;
+    v2 += d2;
+  }
+  v0 = max0 ? wmax(v0) : wsum(v0);
+  v1 = wsum(v1);
+  v2 = wsum(v2);
+  if (lane == 0) { red[0][wid] = v0; red[1][wid] = v1; red[2][wid] = v2; }
+  __syncthreads();
+  if (threadIdx.x != 0) return false;
+  if (rows > 0) fin.out[0] = max0 ? fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))
+                                  : (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  if (rows > 1) fin.out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  if (rows > 2) fin.out[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  if (fin.cost_src != nullptr) fin.out[rows] = fin.cost_src[0];
+  for (int i = 0; i < fin.pub_n; ++i) fin.pub_dst[i] = fin.pub_src[i];
+  return true;
+}
+__device__ __forceinline__ void fin_tag(const Fin& fin) {
+  if (fin.tag_slot != nullptr) {
+    __threadfence_system();
+    *(volatile double*)fin.tag_slot = fin.tag;
   }
 }
 
-// dn = -g + beta * dk ; yk = -g ; partials: [0] max |dn| (owned), [1] dn.dn (owned)
+// dn = -g + beta * dk ; sums: [0] max |dn| (owned), [1] dn.dn (owned).  When the finishing thread publishes to the
+// host (fin.pub_dst), the two sums follow the pub_n copied scalars: pub_dst[pub_n], pub_dst[pub_n + 1].
 template <typename T>
-__global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, T* __restrict__ yk, const T* __restrict__ g,
+__global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, const T* __restrict__ g,
                                                   const T* __restrict__ dk, T beta, size_t n, Owned ow,
-                                                  double* __restrict__ part) {
+                                                  double* __restrict__ part, Fin fin) {
   double mx = 0, ss = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const T gi = g[i];
     T v = -gi;
     if (dk != nullptr) v += beta * dk[i];
     dn[i] = v;
-    yk[i] = -gi;
     if (ow.has(i)) { mx = fmax(mx, fabs((double)v)); ss += (double)v * (double)v; }
   }
-  block_partials3(mx, ss, 0.0, part, true);
+  if (block_partials3(mx, ss, 0.0, part, true, 2, fin)) {
+    if (fin.pub_dst != nullptr) { fin.pub_dst[fin.pub_n] = fin.out[0]; fin.pub_dst[fin.pub_n + 1] = fin.out[1]; }
+    fin_tag(fin);
+  }
 }
 
 // Second stage: rows (<= 3) x nb partials -> out[rows] in fixed order; row 0 is a max when max0.  extra_src, when
@@ -156,7 +233,7 @@ __global__ void k_publish(double* __restrict__ dst, const double* __restrict__ s
 template <typename T>
 __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const T* __restrict__ dn, const T* __restrict__ g,
                                                        const double* __restrict__ norms, size_t n, Owned ow,
-                                                       double* __restrict__ part, double* __restrict__ scal_out) {
+                                                       double* __restrict__ part, double* __restrict__ scal_out, Fin fin) {
   const double mx = norms[0], ss = norms[1];
   double s1 = 1.0, s2 = 1.0;
   if (mx != 0.0) { s1 = 1.0 / mx; s2 = 1.0 / sqrt(ss * s1 * s1); }
@@ -167,31 +244,36 @@ __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const
     d[i] = v;
     if (ow.has(i)) { gd += (double)g[i] * (double)v; dd += (double)v * (double)v; }
   }
-  block_partials3(gd, dd, 0.0, part, false);
+  if (block_partials3(gd, dd, 0.0, part, false, 2, fin)) {
+    // {max|dn|, dn.dn, s1, s2} for the host's step scaling (block 0 may not have stored scal_out yet: derived here)
+    if (fin.pub_dst != nullptr) { fin.pub_dst[0] = mx; fin.pub_dst[1] = ss; fin.pub_dst[2] = s1; fin.pub_dst[3] = s2; }
+    fin_tag(fin);
+  }
 }
 
-// yk += g ; partials: [0] yk.dk, [1] g.g, [2] g.yk   (mincg's DY / HS betas, optimization.cpp:17700-17760)
+// y = g - gp (mincg: yk = -g_k, then yk += g_{k+1}: the same rounding) ; sums: [0] y.dk, [1] g.g, [2] g.y   (the DY / HS
+// betas, optimization.cpp:17700-17760)
 template <typename T>
-__global__ __launch_bounds__(256) void k_beta_dots(T* __restrict__ yk, const T* __restrict__ g, const T* __restrict__ dk,
-                                                  size_t n, Owned ow, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_beta_dots(const T* __restrict__ gp, const T* __restrict__ g, const T* __restrict__ dk,
+                                                  size_t n, Owned ow, double* __restrict__ part, Fin fin) {
   double a = 0, b = 0, c = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (!ow.has(i)) continue;
     const T gi = g[i];
-    const T y = yk[i] + gi;
-    yk[i] = y;
-    if (ow.has(i)) { a += (double)y * (double)dk[i]; b += (double)gi * (double)gi; c += (double)gi * (double)y; }
+    const T y = -gp[i] + gi;
+    a += (double)y * (double)dk[i]; b += (double)gi * (double)gi; c += (double)gi * (double)y;
   }
-  block_partials3(a, b, c, part, false);
+  if (block_partials3(a, b, c, part, false, 3, fin)) fin_tag(fin);
 }
 
 // partial of a.b over the owned elements: [0]
 template <typename T>
 __global__ __launch_bounds__(256) void k_dot(const T* __restrict__ a, const T* __restrict__ b, size_t n, Owned ow,
-                                            double* __restrict__ part) {
+                                            double* __restrict__ part, Fin fin) {
   double s = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
     if (ow.has(i)) s += (double)a[i] * (double)b[i];
-  block_partials3(s, 0.0, 0.0, part, false);
+  if (block_partials3(s, 0.0, 0.0, part, false, 1, fin)) fin_tag(fin);
 }
 
 // dst = a + alpha * b
@@ -319,9 +401,11 @@ struct DeviceCG {
   bool reduce_scalars = false;  // row / channel shards: the owned-element sums are all-reduced
   bool published = false;       // the last evaluation's finish kernel published {f, g.d} + tag (fetch_f_gd just waits)
   // x, g: current point and gradient; xk/dk: accepted point and direction; dn: next direction;
-  // d: normalised direction; yk = -g (then g_{k+1} - g_k).  The line-search base is xk itself.
-  T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr, *yk = nullptr;
-  double* part = nullptr;   // [3][kRedBlocks]
+  // d: normalised direction; gp: the gradient at xk while the line search writes its trial gradients to g (the two
+  // buffers swap; mincg's yk = g_{k+1} - g_k is formed on the fly).  The line-search base is xk itself.
+  T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr, *gp = nullptr;
+  double* part = nullptr;   // [3][kRedBlocks] block partials (two-launch reductions: sharded solves)
+  unsigned long long* gran = nullptr;  // [3][kRedBlocks] granules of the one-launch reductions (armed)
   double* dscal = nullptr;  // device scalars: [0..3] reduction results, [4..5] direction norms
   double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal): results [0..11], arrival tag [15]
   double tag = 0;           // last tag handed to a publishing kernel
@@ -352,14 +436,16 @@ struct DeviceCG {
   int nb() const { size_t b = (n + 255) / 256; return (int)(b < (size_t)kRedBlocks ? b : kRedBlocks); }
 
   int alloc() {
-    T** v[] = {&x, &g, &xk, &dk, &dn, &d, &yk};
+    T** v[] = {&x, &g, &xk, &dk, &dn, &d, &gp};
     for (T** q : v) SRMAP_HIP(p->ctx, hipMalloc((void**)q, n * sizeof(T)));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&part, sizeof(double) * 3 * kRedBlocks));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&dscal, sizeof(double) * 8));
     SRMAP_HIP(p->ctx, hipMemsetAsync(dscal, 0, sizeof(double) * 8, st));
+    SRMAP_HIP(p->ctx, hipMalloc((void**)&gran, sizeof(double) * 3 * kRedBlocks));
+    SRMAP_HIP(p->ctx, hipMemsetD32Async((hipDeviceptr_t)gran, (int)kArm32, 2 * 3 * kRedBlocks, st));
     // sharded evaluations write only the owned part of g: the vector kernels run over all n elements, so everything
     // they combine starts defined (the halo values never enter a reduction, and x halos are re-exchanged)
-    T* z[] = {g, dn, d, dk, yk};
+    T* z[] = {g, dn, d, dk, gp};
     for (T* q : z) SRMAP_HIP(p->ctx, hipMemsetAsync(q, 0, n * sizeof(T), st));
     int rc = ensure_staging(p->ctx);
     if (rc) return rc;
@@ -369,30 +455,35 @@ struct DeviceCG {
     return SRMAP_OK;
   }
   void release() {
-    T* v[] = {x, g, xk, dk, dn, d, yk};
+    T* v[] = {x, g, xk, dk, dn, d, gp};
     for (T* q : v) if (q) (void)hipFree(q);
     if (part) (void)hipFree(part);
+    if (gran) (void)hipFree(gran);
     if (dscal) (void)hipFree(dscal);
   }
   int copy(T* dst, const T* src) {
     SRMAP_HIP(p->ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice, st));
     return SRMAP_OK;
   }
-  // Reduce the `rows` partial rows (+ the evaluation's cost when with_cost) and bring them to the host:
-  // out[0..rows) (+ out[rows] = cost).  One stream synchronisation.
+  // One-launch reductions (struct Fin) whenever the sums need no all-reduce.
+  bool fused() const { return !reduce_scalars; }
+  // the pass about to be launched reduces to the host: out = hs[0 .. rows) (+ the cost at hs[rows]), then the tag
+  Fin fin_host(bool with_cost, const double* pub_src = nullptr, double* pub_dst = nullptr, int pub_n = 0) {
+    Fin f{};
+    if (fused()) {
+      tag += 1.0;
+      f.gran = gran; f.out = hs; f.cost_src = with_cost ? (const double*)p->d_cost : nullptr;
+      f.pub_src = pub_src; f.pub_dst = pub_dst; f.pub_n = pub_n;
+      f.tag_slot = hs + 15; f.tag = tag;
+    }
+    return f;
+  }
+  // Bring the sums of the pass just launched to the host: out[0..rows) (+ out[rows] = cost).  One wait.  Two-launch
+  // scheme: reduces the `rows` partial rows here (k_finish), all-reduces them, publishes.
   int finish(int rows, bool max0, bool with_cost, double* out, int extra_n = 0) {
     const int cnt = rows + (with_cost ? 1 : 0);
-    tag += 1.0;
-    if (!reduce_scalars) {
-      if (extra_n > 0) {
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, hs,
-                           with_cost ? (const double*)p->d_cost : (const double*)nullptr, (double*)nullptr, 0.0);
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, hs + 8, (const double*)(dscal + 4), extra_n, hs + 15, tag);
-      } else {
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, hs,
-                           with_cost ? (const double*)p->d_cost : (const double*)nullptr, hs + 15, tag);
-      }
-    } else {
+    if (!fused()) {
+      tag += 1.0;
       hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), rows, max0 ? 1 : 0, dscal,
                          with_cost ? (const double*)p->d_cost : (const double*)nullptr, (double*)nullptr, 0.0);
       int rc = SRMAP_OK;
@@ -437,7 +528,7 @@ struct DeviceCG {
   // f and g.d of the evaluation just made, with one wait: out[0] = g.d, out[1] = f
   int fetch_f_gd(double* out) {
     if (!p->gd_valid) {
-      hipLaunchKernelGGL(k_dot<T>, dim3(nb()), dim3(256), 0, st, (const T*)g, (const T*)d, n, ow, part);
+      hipLaunchKernelGGL(k_dot<T>, dim3(nb()), dim3(256), 0, st, (const T*)g, (const T*)d, n, ow, part, fin_host(true));
       return finish(1, false, true, out);
     }
     if (published) {  // the evaluation's own finish kernel carries the tag
@@ -464,12 +555,22 @@ struct DeviceCG {
     out[1] = hs[0];
     return SRMAP_OK;
   }
-  // dn = -g + beta dk (dk may be null), yk = -g; direction norms -> dscal[4..5] (device, all-reduced)
-  int direction(const T* dk_or_null, double beta) {
-    hipLaunchKernelGGL(k_direction<T>, dim3(nb()), dim3(256), 0, st, dn, yk, (const T*)g, dk_or_null, (T)beta, n, ow, part);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr,
-                       (double*)nullptr, 0.0);
-    if (reduce_scalars) {
+  // dn = -g + beta dk (dk may be null); direction norms -> dscal[4..5] (device, all-reduced).  publish_cost: the
+  // first pass of a CG run also hands {f -> hs[0], norms -> hs[8..9]} to the host (fetched by finish(0, ..., 2)).
+  int direction(const T* dk_or_null, double beta, bool publish_cost = false) {
+    Fin f{};
+    if (fused()) {
+      f.gran = gran; f.out = dscal + 4;
+      if (publish_cost) {
+        tag += 1.0;
+        f.pub_src = (const double*)p->d_cost; f.pub_dst = hs; f.pub_n = 1;  // hs[0] = f, then hs[1..2] = the norms
+        f.tag_slot = hs + 15; f.tag = tag;
+      }
+    }
+    hipLaunchKernelGGL(k_direction<T>, dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f);
+    if (!fused()) {
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr,
+                         (double*)nullptr, 0.0);
       int rc = comm_allreduce(comm, dscal + 4, 1, SRMAP_F64, 1, st);
       if (rc) return rc;
       rc = comm_allreduce(comm, dscal + 5, 1, SRMAP_F64, 0, st);
@@ -663,10 +764,15 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
   if (rc) return rc;
   rc = cg.evaluate();
   if (rc) return rc;
-  // dk = -g (written as dn, swapped below), yk = -g, norms of dk; g.g = dk.dk comes with them
-  rc = cg.direction(nullptr, 0.0);
+  // dk = -g (written as dn, swapped below), norms of dk; g.g = dk.dk comes with them
+  rc = cg.direction(nullptr, 0.0, true);
   if (rc) return rc;
-  {
+  if (cg.fused()) {  // the direction pass published {f, max|dk|, dk.dk} itself
+    rc = cg.wait_tag();
+    if (rc) return rc;
+    f = cg.hs[0];
+    gg = cg.hs[2];
+  } else {
     // fetch f and g.g (= dn.dn, already reduced on the device) with one wait
     double h[1];
     rc = cg.finish(0, false, true, h, 2);
@@ -687,7 +793,8 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     double stp = 1.0, dginit = 0, dd = 0;
     {
       hipLaunchKernelGGL(k_normalize_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
-                         (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6);
+                         (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
+                         cg.fin_host(false, nullptr, cg.hs + 8, 0));
       double h[2];
       rc = cg.finish(2, false, false, h, 4);  // + {max|dk|, dk.dk, s1, s2} -> hs[8..11]
       if (rc) return rc;
@@ -698,13 +805,15 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     }
     if (lastgoodstep != 0) stp = lastgoodstep;
     int mcinfo = 0, nfev = 0;
+    std::swap(cg.g, cg.gp);  // gp = gradient at xk; the trial evaluations write g
     rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace);
     if (rc) return rc;
+    if (nfev == 0) std::swap(cg.g, cg.gp);  // nothing was evaluated: g stays the gradient at xk, as in mcsrch
     double betak = 0;
     if (mcinfo == 1) {
-      // yk += g ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv
-      hipLaunchKernelGGL(k_beta_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, cg.yk, (const T*)cg.g, (const T*)cg.dk, n,
-                         cg.ow, cg.part);
+      // yk = g - gp ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv
+      hipLaunchKernelGGL(k_beta_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g, (const T*)cg.dk, n,
+                         cg.ow, cg.part, cg.fin_host(false));
       double h[3];
       rc = cg.finish(3, false, false, h);
       if (rc) return rc;
@@ -712,7 +821,8 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
       betak = dmax(0.0, dmin(h[1] / vv, h[2] / vv));
       gg = h[1];
     } else {
-      hipLaunchKernelGGL(k_dot<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow, cg.part);
+      hipLaunchKernelGGL(k_dot<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow, cg.part,
+                         cg.fin_host(false));
       double h[1];
       rc = cg.finish(1, false, false, h);
       if (rc) return rc;
@@ -720,7 +830,7 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     }
     if (res.its > 0 && res.its % (3 + (long long)n) == 0) betak = 0;
     if (mcinfo == 1 || mcinfo == 5) rstimer = rscountdownlen; else rstimer -= 1;
-    rc = cg.direction(cg.dk, betak);  // dn, yk = -g, norms of dn (device)
+    rc = cg.direction(cg.dk, betak);  // dn, norms of dn (device)
     if (rc) return rc;
     const double lastscaledstep = stp * std::sqrt(dd);
     if (mcinfo == 1) lastgoodstep = stp * std::sqrt(dd);
@@ -813,9 +923,6 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
       if (e != hipSuccess) rc = set_error(p->ctx, SRMAP_ENOMEM, "hipMalloc failed");
     }
   }
-  T* regvals = nullptr;
-  if (rc == SRMAP_OK && p->nreg > 0 && hipMalloc((void**)&regvals, npts * sizeof(T)) != hipSuccess)
-    rc = set_error(p->ctx, SRMAP_ENOMEM, "hipMalloc failed");
   const int saved_c0 = p->view_c0, saved_C = p->view_C;
   for (int round = 0; round < rounds && rc == SRMAP_OK; ++round) {
     const int c0 = round * per_split;
@@ -846,9 +953,7 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
       rc = shard_exchange_x(p, comm, mode == SRMAP_SHARD_NONE ? nullptr : shard, cg.x, st);
       if (rc) break;
       for (int r = 0; r < p->nreg; ++r) {
-        rc = launch_reg_values<T>(p, vg, p->reg[r], (const T*)cg.x, regvals, st);
-        if (rc) break;
-        rc = launch_irls_weights<T>(p, (const T*)regvals, (T*)p->reg[r].weights + (size_t)c0 * N, npts, st);
+        rc = launch_reg_weights<T>(p, vg, p->reg[r], (const T*)cg.x, (T*)p->reg[r].weights + (size_t)c0 * N, st);
         if (rc) break;
       }
       if (rc) break;
@@ -870,7 +975,6 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
   rep.waits = cg.waits;
   p->view_c0 = saved_c0;
   p->view_C = saved_C;
-  if (regvals) (void)hipFree(regvals);
   cg.release();
   if (report) *report = rep;
   return rc;

@@ -645,17 +645,8 @@ int srmap_update_irls_weights_device(srmap_problem* p, int reg, const void* x_de
   if (rc) return rc;
   rc = ensure(p, &rs.weights, p->hr_count() * p->elem());
   if (rc) return rc;
-  rc = ensure(p, &p->d_regvals, p->hr_count() * p->elem());
-  if (rc) return rc;
-  if (p->dtype == SRMAP_F32) {
-    rc = launch_reg_values<float>(p, p->geo, rs, (const float*)x_dev, (float*)p->d_regvals, st);
-    if (rc) return rc;
-    rc = launch_irls_weights<float>(p, (const float*)p->d_regvals, (float*)rs.weights, p->hr_count(), st);
-  } else {
-    rc = launch_reg_values<double>(p, p->geo, rs, (const double*)x_dev, (double*)p->d_regvals, st);
-    if (rc) return rc;
-    rc = launch_irls_weights<double>(p, (const double*)p->d_regvals, (double*)rs.weights, p->hr_count(), st);
-  }
+  if (p->dtype == SRMAP_F32) rc = launch_reg_weights<float>(p, p->geo, rs, (const float*)x_dev, (float*)rs.weights, st);
+  else rc = launch_reg_weights<double>(p, p->geo, rs, (const double*)x_dev, (double*)rs.weights, st);
   if (rc) return rc;
   return state_end_write(p, st);  // asynchronous: evaluations on other streams wait for this event
 }

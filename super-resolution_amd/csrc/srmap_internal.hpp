@@ -164,6 +164,9 @@ int launch_reg_gradient_direct(srmap_problem* p, const Geometry& geo, const RegS
 template <typename T>
 int launch_irls_weights(srmap_problem* p, const T* values, T* weights, size_t n,
                         hipStream_t st);
+template <typename T>
+int launch_reg_weights(srmap_problem* p, const Geometry& geo, const RegSpec& rs,
+                       const T* x, T* weights, hipStream_t st);
 int reduce_scratch_slots(size_t n);
 int launch_reduce_partials(srmap_problem* p, const double* partials, int n,
                            double* out, hipStream_t st);
