@@ -338,8 +338,12 @@ int srmap_comm_allreduce(srmap_comm* comm, void* dev_buf, size_t count, int dtyp
 typedef enum {
   SRMAP_SHARD_NONE = 0,
   SRMAP_SHARD_FRAMES = 1,   /* rank owns a frame subset + a replica of x: all-reduce of the
-                               gradient (C*N elements) and of the cost after every
-                               evaluation (objective_data_term.cpp:98-116 summed over ranks) */
+                               gradient (C*N elements) and of the cost (one group) after every
+                               evaluation (objective_data_term.cpp:98-116 summed over ranks).
+                               The regulariser is split over the ranks by HR row band (whole
+                               tile rows) when the tile kernels produce it in their one pass;
+                               otherwise (3-D TV, a second regulariser, direct kernels) rank
+                               reg_rank evaluates it */
   SRMAP_SHARD_ROWS = 2,     /* rank owns a band of HR rows; its problem is the band + halo
                                rows; halo rows of x are exchanged with the two neighbours
                                before every evaluation, scalars all-reduced */
@@ -361,7 +365,8 @@ typedef struct {
   int own_row0, own_row1;          /* ROWS: HR rows of THIS problem the rank owns (the rest is halo) */
   int send_up_rows, send_down_rows;/* ROWS: owned boundary rows the upper / lower neighbour's halo holds */
   int own_ch0, own_ch1;            /* CHANNELS: channels of THIS problem the rank owns (others: halo planes) */
-  int reg_rank;                    /* FRAMES: the rank whose evaluation carries the regulariser terms */
+  int reg_rank;                    /* FRAMES: the rank whose evaluation carries the regulariser terms when they
+                                      cannot be split by row band (see SRMAP_SHARD_FRAMES) */
   int frame_groups;                /* GRID: ranks per channel block (0 / 1 elsewhere) */
   srmap_comm* frame_comm;          /* GRID: communicator of the frame_groups ranks sharing this rank's channel
                                       block (srmap_comm_split, or a host communicator of that group) */

@@ -93,9 +93,22 @@ struct srmap_comm {
   srmap_host_sendrecv_fn sr = nullptr;
   void* user = nullptr;
   void* h_send = nullptr; void* h_recv = nullptr; size_t h_cap = 0;  // pinned staging (host backend)
+  // row shards: the halo exchange runs on this side stream, under the tiles that read no halo row (solver.hip)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_x = nullptr, ev_halo = nullptr;
 };
 
 namespace srmap {
+
+int comm_side(srmap_comm* c, hipStream_t* side, hipEvent_t* ev_x, hipEvent_t* ev_halo) {
+  if (!c->side) {
+    SRMAP_HIP(c->ctx, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    SRMAP_HIP(c->ctx, hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
+    SRMAP_HIP(c->ctx, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  }
+  *side = c->side; *ev_x = c->ev_x; *ev_halo = c->ev_halo;
+  return SRMAP_OK;
+}
 
 int comm_rank(const srmap_comm* c) { return c ? c->rank : 0; }
 int comm_world(const srmap_comm* c) { return c ? c->world : 1; }
@@ -321,6 +334,9 @@ void srmap_comm_destroy(srmap_comm* c) {
   if (c->kind == 1 && c->nccl && c->api) (void)c->api->CommDestroy(c->nccl);
   if (c->h_send) (void)hipHostFree(c->h_send);
   if (c->h_recv) (void)hipHostFree(c->h_recv);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->ev_x) (void)hipEventDestroy(c->ev_x);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   delete c;
 }
 

@@ -6,6 +6,8 @@
 namespace srmap {
 
 int comm_rank(const srmap_comm* c);
+// The communicator's side stream (non-blocking) and its two events, created on first use.
+int comm_side(srmap_comm* c, hipStream_t* side, hipEvent_t* ev_x, hipEvent_t* ev_halo);
 int comm_world(const srmap_comm* c);
 // In-place all-reduce of a device buffer (op 0 = sum, 1 = max), enqueued on `st` (RCCL) or staged through the
 // caller's host callback (synchronises `st`).  No-op for world 1 / null communicator.

@@ -1222,6 +1222,7 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.E = z.E;
   A.ring = z.ring;
   A.cr0 = geo.cr0; A.cr1 = geo.cr1;
+  A.rr0 = 0; A.rr1 = geo.H;
   A.terms = (int)terms;
   if (B == 1) { A.blur3[0] = A.blur3[1] = A.blur3[2] = T(1); A.k1s[0] = A.k1s[1] = T(1); }
   else {

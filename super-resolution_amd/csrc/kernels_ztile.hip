@@ -77,6 +77,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // own L2; with the tile ROW on blockIdx.x and launch index n -> row band (n mod 8) the workgroups an XCD runs at
   // the same time are vertical neighbours and share their x halo rows in that L2.  Bijective for any row count.
   if ((int)blockIdx.y < A.nby) {  // border blocks come first in dispatch order (uniform branch)
+    if (A.sel_mode == 1) return;
     const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
     const BorderArgs<T>& Bd = *A.bd;
     if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);
@@ -95,6 +96,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     // launch's last generation
     tbx = (by == 0) ? 0 : (by == 1 ? nby_t - 1 : by - 1);
   }
+  if (A.sel_mode != 0 && ((A.sel_mode == 1) != (tby >= A.sel0 && tby < A.sel1))) return;  // uniform; before any barrier
   const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;
   const int ch = blockIdx.z;
   const size_t N = (size_t)A.W * A.H;
@@ -104,7 +106,8 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const int gc0 = C0 + S * lane;   // first global HR column of this thread
   const int cellg = CJ0 + lane;
   const bool want_data = (A.terms & SRMAP_TERM_DATA) != 0;
-  const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0;
+  // frame shards evaluate the regulariser of their own row band only (whole tiles: the band is tile aligned)
+  const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0 && R0 >= A.rr0 && R0 < A.rr1;
   const T* ybase = A.y + (size_t)ch * nl;
 
   // ---------------- global loads whose addresses are known now: x tile, observations, IRLS weights ----------------
@@ -615,6 +618,23 @@ bool ztile_plan(srmap_problem* p) {
   return true;  // the caller preloads the kernel instance (ztile_preload)
 }
 
+// Frame sharding may split the regulariser by row band when the tile kernel alone produces it: one active
+// regulariser, the one fused into the plan (no 3-D TV / second regulariser / wide BTV pass of the direct kernels).
+bool ztile_overlaps_halo(const srmap_problem* p) {
+  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
+  return z != nullptr && p->impl != SRMAP_IMPL_DIRECT && p->impl != SRMAP_IMPL_MARCH && !z->subpix;
+}
+
+bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms) {
+  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
+  if (!z || p->impl == SRMAP_IMPL_DIRECT || p->impl == SRMAP_IMPL_MARCH) return false;
+  if (!(terms & SRMAP_TERM_REG)) return false;
+  int active = 0;
+  for (int r = 0; r < p->nreg; ++r)
+    if (p->reg[r].lambda > 0.0) { if (!(z->regk != 0 && r == z->reg_index)) return false; active++; }
+  return active == 1;
+}
+
 bool ztile_covers_march(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   return z != nullptr && !z->subpix && march_has_instance(z->S, z->B, z->regk, z->regr);
@@ -649,6 +669,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.E = z.E;
   A.ring = z.ring;
   A.cr0 = geo.cr0; A.cr1 = geo.cr1;
+  A.rr0 = geo.rr0; A.rr1 = geo.rr1;
   A.terms = (int)terms;
   if (B == 1) { A.blur3[0] = A.blur3[1] = A.blur3[2] = T(1); A.k1s[0] = A.k1s[1] = T(1); }
   else {
@@ -691,12 +712,32 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.tag_slot = p->eval_pub_tag_slot;
   A.tag = p->eval_pub_tag;
   if (mfin.on && (size_t)A.n_partials > z.mpart_cap) return set_error(p->ctx, SRMAP_EHIP, "granule capacity");
+  A.sel_mode = 0; A.sel0 = 0; A.sel1 = 0;
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
     A.rbuf = (const T*)p->d_resid;
     A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
     hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), 0, st, A);
-  } else if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), 0, st, A);
-  else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
+  } else {
+    auto launch = [&]() {
+      if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), 0, st, A);
+      else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
+    };
+    if (p->ov_hook != nullptr) {
+      // Row shard: a tile row [8 t, 8 t + 8) reads x rows within the halo width of itself, so the tile rows t with
+      // 8 t >= 2 * ov_top and 8 t + 8 <= H - 2 * ov_bot touch no halo row.  They run first, the halo exchange is
+      // posted on its own stream under them, and the boundary tile rows (and the border blocks) follow the event.
+      const int th = C::TH;
+      A.sel0 = (2 * p->ov_top + th - 1) / th;
+      A.sel1 = (geo.H - 2 * p->ov_bot) / th;
+      if (A.sel1 > A.sel0) { A.sel_mode = 1; launch(); }
+      const int rch = p->ov_hook(p->ov_arg);
+      if (rch) return rch;
+      SRMAP_HIP(p->ctx, hipStreamWaitEvent(st, p->ov_event, 0));
+      if (A.sel1 > A.sel0) { A.sel_mode = 2; launch(); } else { A.sel_mode = 0; launch(); }
+    } else {
+      launch();
+    }
+  }
   *nblocks = n_tile_partials + nbb * (int)grid.z;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
@@ -799,7 +840,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   // tiles: the cost reduction inside the kernel (no finish launch) when no in-image pixel of the border frame needs a
   // correction, no further regulariser kernel follows and the granules suffice
   MFin mfin;
-  mfin.on = !march && !z.subpix && !more_regs && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
+  mfin.on = !march && !z.subpix && !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
             (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0));
   mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
   if (march) {

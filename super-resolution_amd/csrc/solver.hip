@@ -26,6 +26,7 @@
 // block; everything for frame shards) and are all-reduced through the
 // communicator (sum, and max for the max-norm), so every rank takes the same
 // decisions; x halos are refreshed before every evaluation (comm.hpp).
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -345,19 +346,58 @@ int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsi
                hipStream_t st) {
   const int mode = (c && sd && comm_world(c) > 1) ? sd->mode : SRMAP_SHARD_NONE;
   if (mode == SRMAP_SHARD_NONE) return srmap_eval_device(p, terms, x_dev, g_dev, nullptr, st);
+  const size_t N = (size_t)p->geo.W * p->geo.H, es = p->elem();
+  if (mode == SRMAP_SHARD_ROWS) {
+    // The halo rows of x travel on the communicator's side stream while the evaluation's stream runs the tile rows
+    // that read none of them; the boundary tile rows wait for the event (kernels_ztile.hip launch_z; paths without
+    // that split exchange first).  x is ready when `st` reaches this point; the next exchange cannot start before
+    // this evaluation (which reads the halos) is behind the next ev_x.
+    struct Hook { srmap_problem* p; srmap_comm* c; const srmap_shard_desc* sd; void* x; hipStream_t side; hipEvent_t ev; };
+    hipStream_t side; hipEvent_t ev_x, ev_halo;
+    int rc = comm_side(c, &side, &ev_x, &ev_halo);
+    if (rc) return rc;
+    SRMAP_HIP(p->ctx, hipEventRecord(ev_x, st));
+    SRMAP_HIP(p->ctx, hipStreamWaitEvent(side, ev_x, 0));
+    Hook h{p, c, sd, x_dev, side, ev_halo};
+    p->ov_hook = [](void* a) -> int {
+      Hook* k = static_cast<Hook*>(a);
+      int r = shard_exchange_x(k->p, k->c, k->sd, k->x, k->side);
+      if (r) return r;
+      SRMAP_HIP(k->p->ctx, hipEventRecord(k->ev, k->side));
+      return SRMAP_OK;
+    };
+    p->ov_arg = &h;
+    p->ov_event = ev_halo;
+    p->ov_top = sd->own_row0;
+    p->ov_bot = p->geo.H - sd->own_row1;
+    rc = srmap_eval_device(p, terms, x_dev, g_dev, nullptr, st);  // cost rows were set on the problem
+    p->ov_hook = nullptr; p->ov_arg = nullptr; p->ov_event = nullptr;
+    return rc;
+  }
   int rc = shard_exchange_x(p, c, sd, x_dev, st);
   if (rc) return rc;
-  const size_t N = (size_t)p->geo.W * p->geo.H, es = p->elem();
   if (mode == SRMAP_SHARD_FRAMES) {
-    // the regulariser terms are evaluated once, on reg_rank; every rank adds its frames' data term
-    const unsigned t = (comm_rank(c) == sd->reg_rank) ? terms : (terms & SRMAP_TERM_DATA);
+    // Every rank adds its frames' data term.  The regulariser is evaluated once over the ranks: split by row band
+    // (whole tile rows, balanced) when the tile kernel alone produces it -- at cfg2-class mixes it is more than half of
+    // the arithmetic, so leaving it to one rank would make that rank the critical path -- else on reg_rank.
+    const int rank = comm_rank(c), world = comm_world(c);
+    unsigned t = terms;
+    const bool band = ztile_reg_band_ok(p, terms);
+    if (band) {
+      const int tiles = (p->geo.H + 7) / 8, per = (tiles + world - 1) / world;
+      p->geo.rr0 = std::min(p->geo.H, rank * per * 8);
+      p->geo.rr1 = std::min(p->geo.H, (rank + 1) * per * 8);
+    } else if (rank != sd->reg_rank) {
+      t = terms & SRMAP_TERM_DATA;
+    }
     if (t == 0) {
       SRMAP_HIP(p->ctx, hipMemsetAsync(p->d_cost, 0, sizeof(double), st));
       if (g_dev) SRMAP_HIP(p->ctx, hipMemsetAsync(g_dev, 0, p->hr_count() * es, st));
     } else {
       rc = srmap_eval_device(p, t, x_dev, g_dev, nullptr, st);
-      if (rc) return rc;
     }
+    p->geo.rr0 = 0; p->geo.rr1 = p->geo.H;
+    if (rc) return rc;
     // the north-star's gradient all-reduce, with the cost in the same group (one launch)
     return comm_allreduce_grad_cost(c, g_dev, g_dev ? p->hr_count() : 0, p->dtype, p->d_cost, st);
   }

@@ -247,6 +247,14 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
   if ((terms & SRMAP_TERM_DATA) && !p->have_obs)
     return set_error(p->ctx, SRMAP_EINVAL, "data term requested but no observations set");
   const bool ztile = p->impl != SRMAP_IMPL_DIRECT && p->zplan != nullptr;
+  if (p->ov_hook != nullptr && !(ztile && ztile_overlaps_halo(p))) {
+    // row shard on a path that cannot run under the halo exchange: exchange first
+    int (*hook)(void*) = p->ov_hook;
+    p->ov_hook = nullptr;
+    rc = hook(p->ov_arg);
+    if (rc) return rc;
+    SRMAP_HIP(p->ctx, hipStreamWaitEvent(st, p->ov_event, 0));
+  }
   if (p->impl == SRMAP_IMPL_TILED && !ztile)
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "tiled kernels do not cover this geometry");
   if (p->impl == SRMAP_IMPL_MARCH && !(ztile && ztile_covers_march(p)))
@@ -411,6 +419,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   g.b = blur ? d->blur_ksize : 1;
   g.hb = (g.b - 1) / 2;
   g.cr0 = 0; g.cr1 = g.H;
+  g.rr0 = 0; g.rr1 = g.H;
   g.zlo = 0; g.zhi = 0;
   // Gaussian kernel: cv::getGaussianKernel (sigma > 0) and k * k^T, blur_module.cpp:20-22
   p->blur2d.assign((size_t)g.b * g.b, 1.0);

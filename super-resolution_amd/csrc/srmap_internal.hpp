@@ -36,6 +36,9 @@ struct Geometry {
   int w, h;        // LR size
   int s;           // scale
   int b, hb;       // blur kernel size (1 = none) and (b-1)/2
+  int rr0, rr1;    // HR rows [rr0, rr1) whose regulariser terms (gradient AND cost) this evaluation produces: frame
+                   // sharding splits the regulariser over the ranks by row band (multiples of 8, the tile height;
+                   // tile kernels only; default 0, H)
   int cr0, cr1;    // HR rows [cr0, cr1) whose cost terms are counted (row-band sharding; default 0, H):
                    // regulariser pixels of those rows, data residuals of LR rows [cr0/s, cr1/s)
   int zlo, zhi;    // channel sharding: a halo plane exists before channel 0 / after channel C-1 of this view
@@ -112,6 +115,14 @@ struct srmap_problem {
   // (state_seen); a writer on another stream than the last evaluation's (use_stream) drains that stream first
   hipEvent_t state_ev = nullptr;
   hipStream_t state_stream = nullptr, state_seen = nullptr, use_stream = nullptr;
+  // set by the row-sharded evaluation around one evaluation: ov_hook(ov_arg) posts the halo exchange of x (on another
+  // stream) and records ov_event when the halo rows [0, ov_top) and [H - ov_bot, H) are in place.  The tile kernels
+  // run the tiles that read no halo row first, then the hook, then -- behind the event -- the remaining tile rows;
+  // every other path calls the hook and waits before it starts.
+  int (*ov_hook)(void*) = nullptr;
+  void* ov_arg = nullptr;
+  hipEvent_t ov_event = nullptr;
+  int ov_top = 0, ov_bot = 0;
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
   void* zplan = nullptr;          // srmap::ZPlan of the z-tile kernels (kernels_ztile.hip), owned; nullptr = not covered
@@ -175,6 +186,8 @@ int launch_reduce_partials(srmap_problem* p, const double* partials, int n,
 bool ztile_plan(srmap_problem* p);
 void ztile_release(srmap_problem* p);
 void ztile_preload(const srmap_problem* p);
+bool ztile_overlaps_halo(const srmap_problem* p);  // the next tile evaluation can run interior tiles under the halo exchange
+bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms);  // the tile kernel alone produces the regulariser part
 bool ztile_covers_march(const srmap_problem* p);  // the plan is served by the marching kernel (kernels_march.hip)
 size_t ztile_partials_needed(const srmap_problem* p);
 template <typename T>

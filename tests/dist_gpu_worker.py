@@ -44,6 +44,9 @@ def main():
     lr = rng.random((K, C, h, w))
     x0 = rng.random((C, H, W))
     regs = [(srmap.REG_BTV, 0.02, 3, 0.5)] + ([(srmap.REG_TV3D, 0.03, 0, 0.0)] if mode in ("channels", "grid") else [])
+    if mode == "frames2":  # a second regulariser: the direct kernels join in, the regulariser stays on reg_rank (no band split)
+        regs.append((srmap.REG_TV, 0.01, 0, 0.0))
+        mode = "frames"
     opts = srmap.default_irls_options()
     opts.max_num_irls_iterations = 2
     opts.max_num_solver_iterations = 6

@@ -86,6 +86,20 @@ def test_generate_then_super_resolve(tmp_path):
     x, _ = prob.solve(x0, o)
     assert np.max(np.abs(x - result)) < 5e-3
 
+    # and through the CPU oracle (the reference's algorithm, ALGLIB-driven when oracle/_ref is built): the image the
+    # reference binary would have written, up to the float32 file format and the bilinear start's rounding
+    import oracle as orc
+    model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=3, blur_sigma=1.0)
+    ref = orc.Problem(model, frames)
+    ref.add_regularizer(orc.REG_BTV, 0.001, 2, 0.5)
+    oo = orc.default_irls_options()
+    oo.max_num_irls_iterations, oo.max_num_solver_iterations = 5, 30
+    x_ref, rep_ref = ref.solve(x0, oo, use_alglib=orc.have_ref())
+    psnr_cli, psnr_ref = -10 * np.log10(np.mean((result - gt32) ** 2)), orc.psnr(gt32, x_ref)
+    print("CLI result vs oracle solve: max |diff| %.2e, PSNR %.4f / %.4f dB" % (np.max(np.abs(result - x_ref)), psnr_cli, psnr_ref))
+    assert np.max(np.abs(result - x_ref)) < 5e-3
+    assert abs(psnr_cli - psnr_ref) < 0.01
+
 
 def test_pgm_round_trip_and_usage(tmp_path):
     import __graft_entry__ as ge

@@ -25,9 +25,10 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("mode", ["frames", "rows", "channels", "grid"])
+@pytest.mark.parametrize("mode", ["frames", "frames2", "rows", "channels", "grid"])
 def test_two_ranks_on_one_gpu(tmp_path, mode):
-    """2 ranks (grid: 4 = 2 channel blocks x 2 frame groups, the frames x channels sharding of BASELINE configs[4])."""
+    """2 ranks (grid: 4 = 2 channel blocks x 2 frame groups, the frames x channels sharding of BASELINE configs[4]).
+    frames: the regulariser split over the ranks by row band; frames2: two regularisers, evaluated on reg_rank."""
     world, port = (4 if mode == "grid" else 2), _free_port()
     out = str(tmp_path / "res.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -50,7 +51,7 @@ def test_two_ranks_on_one_gpu(tmp_path, mode):
     # same decisions on every rank and as the single-process solve; iterates equal up to reduction order
     assert len(set(res["cg"])) == 1 and len(set(res["irls"])) == 1 and len(set(res["evals"])) == 1
     assert res["solve_err"] <= 1e-9
-    if mode in ("frames", "grid"):
+    if mode in ("frames", "frames2", "grid"):
         assert res["replicas_equal"]
 
 
