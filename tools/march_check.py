@@ -61,11 +61,8 @@ def timing(ctx, W):
     p.set_observations_device(y.data_ptr())
     r = p.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
     p.update_irls_weights_device(r, x.data_ptr())
-    import ctypes as C
-    lib = sr.load()
-    for name, impl in (("tiled", sr.IMPL_TILED), ("march", sr.IMPL_MARCH), ("march-stagger-1", sr.IMPL_MARCH)):
+    for name, impl in (("tiled", sr.IMPL_TILED), ("march", sr.IMPL_MARCH)):
         p.set_impl(impl)
-        if hasattr(lib, "srmap_dev_set_stagger"): lib.srmap_dev_set_stagger(-1 if "stagger" in name else 0)
         for _ in range(1000): p.eval_device(x.data_ptr(), g.data_ptr(), sr.TERM_ALL)
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter(); n = 1000
