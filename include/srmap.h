@@ -95,7 +95,7 @@ enum {
  * the integer-shift geometries of the BASELINE configurations (DESIGN.md
  * section 3.4).  TILED / MARCH force one family and fail with
  * SRMAP_EUNSUPPORTED when it does not cover the problem. */
-typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3 } srmap_impl;
+typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3, SRMAP_IMPL_PERSIST = 4 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */
 /* Binds HIP device `device_id`.  Replaces nothing in the reference (it has no

@@ -80,7 +80,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (A.sel_mode == 1) return;
     const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
     const BorderArgs<T>& Bd = *A.bd;
-    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);
+    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
     else if (threadIdx.x == 0) {
       const int nbb = A.nby * gridDim.x;
       put_partial<WD>(A, (size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx, 0.0, 0.0);
@@ -415,6 +415,7 @@ void ztile_release(srmap_problem* p) {
   if (z->d_bd) (void)hipFree(z->d_bd);
   if (z->d_ctr) (void)hipFree(z->d_ctr);
   if (z->d_ctr64) (void)hipFree(z->d_ctr64);
+  if (z->d_queue) (void)hipFree(z->d_queue);
   if (z->d_mpart) (void)hipFree(z->d_mpart);
   delete z;
   p->zplan = nullptr;
@@ -613,6 +614,8 @@ bool ztile_plan(srmap_problem* p) {
   }
   p->zplan = z;
   if (ok) ok = march_alloc(p, z);
+  if (ok) ok = hipMalloc((void**)&z->d_queue, 16 * sizeof(unsigned)) == hipSuccess &&
+               hipMemset(z->d_queue, 0, 16 * sizeof(unsigned)) == hipSuccess;
   p->zplan = z;
   if (!ok) { ztile_release(p); return false; }
   return true;  // the caller preloads the kernel instance (ztile_preload)
@@ -648,6 +651,8 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   if (z && z->n_ring > 0) ring = (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * g.C;  // border blocks fill whole grid rows
   return std::max(tiles + ring, march_partials_needed(p));
 }
+
+constexpr bool kPersistByDefault = false;  // the persistent tile kernel is opt-in (SRMAP_IMPL_PERSIST): 2.2x slower than the tiles at cfg2
 
 struct MFin { bool on, publish; };  // in-kernel finish of this launch; publish {cost, g.d} to the solver's host words
 
@@ -775,6 +780,7 @@ void ztile_preload(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   if (!z) return;
   march_preload(p);
+  if (p->impl == SRMAP_IMPL_PERSIST || (p->impl == SRMAP_IMPL_AUTO && kPersistByDefault)) persist_preload(p);
   if (p->dtype == SRMAP_F32) preload_sb<float>(z->S, z->B, z->regk, z->regr);
   else preload_sb<double>(z->S, z->B, z->regk, z->regr);
 }
@@ -843,9 +849,20 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   mfin.on = !march && !z.subpix && !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
             (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0));
   mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
+  // persistent tiles (kernels_ptile.hip): one workgroup per CU pulling tiles from per-XCD queues
+  const bool persist = !march && (p->impl == SRMAP_IMPL_PERSIST || (p->impl == SRMAP_IMPL_AUTO && kPersistByDefault)) &&
+                       !z.subpix && p->ov_hook == nullptr && z.d_queue != nullptr && (zterms & SRMAP_TERM_DATA) != 0 &&
+                       persist_has_instance(S, B, regk, regr);  // (the kernel requests observations unconditionally)
+  bool persist_finished = false;
   if (march) {
     rc = launch_eval_march<T>(p, geo, obs_c0, zterms, x, g, wts, regk, regr, partials, &nb, !more_regs, &march_finished, st,
                               dv, pgd, with_d && p->eval_pub != nullptr);
+  }
+  else if (persist) {
+    // in-kernel reduction when nothing follows the launch: no further regulariser kernel, no in-image border correction
+    const bool fin_ok = !more_regs && (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0));
+    rc = launch_eval_persist<T>(p, geo, obs_c0, zterms, x, g, wts, regk, regr, partials, &nb, fin_ok, &persist_finished, st,
+                                dv, pgd, with_d && p->eval_pub != nullptr);
   }
   else if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
   else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
@@ -894,7 +911,13 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     *nblocks = total;
     return SRMAP_OK;
   }
-  if (mfin.on) {  // reduced by the last workgroup of the tile kernel
+  if (persist && persist_finished) {  // reduced by the last workgroup of the persistent kernel
+    p->gd_valid = with_d;  // d_cost[1] = g.d
+    p->eval_published = with_d && p->eval_pub != nullptr;
+    *nblocks = 0;
+    return SRMAP_OK;
+  }
+  if (mfin.on && !persist) {  // reduced by the last workgroup of the tile kernel
     p->gd_valid = with_d;  // d_cost[1] = g.d
     p->eval_published = mfin.publish;
     *nblocks = 0;

@@ -526,9 +526,9 @@ void srmap_problem_destroy(srmap_problem* p) {
 
 int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
-  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_MARCH) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
+  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_PERSIST) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
-  if (impl == SRMAP_IMPL_MARCH) ztile_preload(p);  // its code objects load now, not inside the first evaluation
+  if (impl == SRMAP_IMPL_MARCH || impl == SRMAP_IMPL_PERSIST) ztile_preload(p);  // its code objects load now, not inside the first evaluation
   return SRMAP_OK;
 }
 
