@@ -91,11 +91,9 @@ enum {
 /* Kernel family selection (for tests and A/B measurements).  AUTO picks the
  * workgroup-tile kernels whenever the problem geometry admits them (scale
  * 2..4, blur size 1 or 3, integer or sub-pixel shifts), else the direct
- * kernels.  MARCH is the opt-in single-launch marching-wave implementation of
- * the integer-shift geometries of the BASELINE configurations (DESIGN.md
- * section 3.4).  TILED / MARCH force one family and fail with
- * SRMAP_EUNSUPPORTED when it does not cover the problem. */
-typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3, SRMAP_IMPL_PERSIST = 4 } srmap_impl;
+ * kernels.  TILED forces that family and fails with SRMAP_EUNSUPPORTED when it
+ * does not cover the problem. */
+typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */
 /* Binds HIP device `device_id`.  Replaces nothing in the reference (it has no
@@ -126,7 +124,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* desc,
                          srmap_problem** out);
 void srmap_problem_destroy(srmap_problem* p);
 int srmap_problem_set_impl(srmap_problem* p, int impl /* srmap_impl */);
-/* The family the next evaluation will run (SRMAP_IMPL_DIRECT / TILED / MARCH): how a caller learns that AUTO fell
+/* The family the next evaluation will run (SRMAP_IMPL_DIRECT / TILED): how a caller learns that AUTO fell
  * back to the direct kernels (geometry outside the tile kernels' coverage, or a sub-pixel shift on a 1/32-px
  * rounding tie, whose per-row table only the direct kernels read). */
 int srmap_problem_active_impl(const srmap_problem* p, int* impl);

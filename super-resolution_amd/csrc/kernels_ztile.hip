@@ -57,7 +57,7 @@ namespace srmap {
 namespace {
 
 template <typename T, int S, int B, int REGK, int R, bool WD, bool SP>
-__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : 4)) void k_eval_z(
+__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : (S == 2 ? 6 : 4))) void k_eval_z(
     ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
   using C = ZCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
@@ -413,9 +413,6 @@ void ztile_release(srmap_problem* p) {
   spfwd_release(&z->spf);
   if (z->d_corr) (void)hipFree(z->d_corr);
   if (z->d_bd) (void)hipFree(z->d_bd);
-  if (z->d_ctr) (void)hipFree(z->d_ctr);
-  if (z->d_ctr64) (void)hipFree(z->d_ctr64);
-  if (z->d_queue) (void)hipFree(z->d_queue);
   if (z->d_mpart) (void)hipFree(z->d_mpart);
   delete z;
   p->zplan = nullptr;
@@ -613,10 +610,14 @@ bool ztile_plan(srmap_problem* p) {
     ok = p->dtype == SRMAP_F32 ? put(BorderArgs<float>()) : put(BorderArgs<double>());
   }
   p->zplan = z;
-  if (ok) ok = march_alloc(p, z);
-  if (ok) ok = hipMalloc((void**)&z->d_queue, 16 * sizeof(unsigned)) == hipSuccess &&
-               hipMemset(z->d_queue, 0, 16 * sizeof(unsigned)) == hipSuccess;
-  p->zplan = z;
+  if (ok) {
+    // granules of the in-kernel cost reduction (one per tile + one per border block), up to a cap beyond which the
+    // caller's two-stage reduction is used anyway
+    const size_t cap = std::min<size_t>(ztile_partials_needed(p), (size_t)16384);
+    ok = hipMalloc((void**)&z->d_mpart, 2 * cap * sizeof(double)) == hipSuccess &&
+         hipMemsetD32((hipDeviceptr_t)z->d_mpart, (int)kSentinel32, 4 * cap) == hipSuccess;
+    z->mpart_cap = cap;
+  }
   if (!ok) { ztile_release(p); return false; }
   return true;  // the caller preloads the kernel instance (ztile_preload)
 }
@@ -625,22 +626,17 @@ bool ztile_plan(srmap_problem* p) {
 // regulariser, the one fused into the plan (no 3-D TV / second regulariser / wide BTV pass of the direct kernels).
 bool ztile_overlaps_halo(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
-  return z != nullptr && p->impl != SRMAP_IMPL_DIRECT && p->impl != SRMAP_IMPL_MARCH && !z->subpix;
+  return z != nullptr && p->impl != SRMAP_IMPL_DIRECT && !z->subpix;
 }
 
 bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
-  if (!z || p->impl == SRMAP_IMPL_DIRECT || p->impl == SRMAP_IMPL_MARCH) return false;
+  if (!z || p->impl == SRMAP_IMPL_DIRECT) return false;
   if (!(terms & SRMAP_TERM_REG)) return false;
   int active = 0;
   for (int r = 0; r < p->nreg; ++r)
     if (p->reg[r].lambda > 0.0) { if (!(z->regk != 0 && r == z->reg_index)) return false; active++; }
   return active == 1;
-}
-
-bool ztile_covers_march(const srmap_problem* p) {
-  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
-  return z != nullptr && !z->subpix && march_has_instance(z->S, z->B, z->regk, z->regr);
 }
 
 size_t ztile_partials_needed(const srmap_problem* p) {
@@ -649,10 +645,8 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   size_t ring = 0;
   if (z && z->n_ring > 0) ring = (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * g.C;  // border blocks fill whole grid rows
-  return std::max(tiles + ring, march_partials_needed(p));
+  return tiles + ring;
 }
-
-constexpr bool kPersistByDefault = false;  // the persistent tile kernel is opt-in (SRMAP_IMPL_PERSIST): 2.2x slower than the tiles at cfg2
 
 struct MFin { bool on, publish; };  // in-kernel finish of this launch; publish {cost, g.d} to the solver's host words
 
@@ -779,8 +773,6 @@ static void preload_sb(int S, int B, int regk, int regr) {
 void ztile_preload(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   if (!z) return;
-  march_preload(p);
-  if (p->impl == SRMAP_IMPL_PERSIST || (p->impl == SRMAP_IMPL_AUTO && kPersistByDefault)) persist_preload(p);
   if (p->dtype == SRMAP_F32) preload_sb<float>(z->S, z->B, z->regk, z->regr);
   else preload_sb<double>(z->S, z->B, z->regk, z->regr);
 }
@@ -840,31 +832,13 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
   p->gd_valid = false;
   p->eval_published = false;
-  // marching waves (kernels_march.hip): an opt-in implementation (SRMAP_IMPL_MARCH) of the integer-shift geometries
-  const bool march = p->impl == SRMAP_IMPL_MARCH && !z.subpix;
-  bool march_finished = false;
   // tiles: the cost reduction inside the kernel (no finish launch) when no in-image pixel of the border frame needs a
   // correction, no further regulariser kernel follows and the granules suffice
   MFin mfin;
-  mfin.on = !march && !z.subpix && !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
+  mfin.on = !z.subpix && !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
             (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0));
   mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
-  // persistent tiles (kernels_ptile.hip): one workgroup per CU pulling tiles from per-XCD queues
-  const bool persist = !march && (p->impl == SRMAP_IMPL_PERSIST || (p->impl == SRMAP_IMPL_AUTO && kPersistByDefault)) &&
-                       !z.subpix && p->ov_hook == nullptr && z.d_queue != nullptr && (zterms & SRMAP_TERM_DATA) != 0 &&
-                       persist_has_instance(S, B, regk, regr);  // (the kernel requests observations unconditionally)
-  bool persist_finished = false;
-  if (march) {
-    rc = launch_eval_march<T>(p, geo, obs_c0, zterms, x, g, wts, regk, regr, partials, &nb, !more_regs, &march_finished, st,
-                              dv, pgd, with_d && p->eval_pub != nullptr);
-  }
-  else if (persist) {
-    // in-kernel reduction when nothing follows the launch: no further regulariser kernel, no in-image border correction
-    const bool fin_ok = !more_regs && (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0));
-    rc = launch_eval_persist<T>(p, geo, obs_c0, zterms, x, g, wts, regk, regr, partials, &nb, fin_ok, &persist_finished, st,
-                                dv, pgd, with_d && p->eval_pub != nullptr);
-  }
-  else if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+  if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
   else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
   else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
   else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
@@ -901,23 +875,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
       total += nb2;
     }
   }
-  if (march) {  // corrections were applied in the kernel; the cost too unless more partials followed / too many
-    if (march_finished) {
-      p->gd_valid = with_d;  // d_cost[1] = g.d
-      p->eval_published = with_d && p->eval_pub != nullptr;
-      *nblocks = 0;
-      return SRMAP_OK;
-    }
-    *nblocks = total;
-    return SRMAP_OK;
-  }
-  if (persist && persist_finished) {  // reduced by the last workgroup of the persistent kernel
-    p->gd_valid = with_d;  // d_cost[1] = g.d
-    p->eval_published = with_d && p->eval_pub != nullptr;
-    *nblocks = 0;
-    return SRMAP_OK;
-  }
-  if (mfin.on && !persist) {  // reduced by the last workgroup of the tile kernel
+  if (mfin.on) {  // reduced by the last workgroup of the tile kernel
     p->gd_valid = with_d;  // d_cost[1] = g.d
     p->eval_published = mfin.publish;
     *nblocks = 0;

@@ -257,8 +257,6 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
   }
   if (p->impl == SRMAP_IMPL_TILED && !ztile)
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "tiled kernels do not cover this geometry");
-  if (p->impl == SRMAP_IMPL_MARCH && !(ztile && ztile_covers_march(p)))
-    return set_error(p->ctx, SRMAP_EUNSUPPORTED, "the marching kernel does not cover this geometry");
   int nparts = 0;
   if (ztile) {
     rc = launch_eval_ztile<T>(p, geo, c0, terms, x, g, p->d_partials, &nparts, st);
@@ -526,17 +524,15 @@ void srmap_problem_destroy(srmap_problem* p) {
 
 int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
-  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_PERSIST) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
+  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
-  if (impl == SRMAP_IMPL_MARCH || impl == SRMAP_IMPL_PERSIST) ztile_preload(p);  // its code objects load now, not inside the first evaluation
   return SRMAP_OK;
 }
 
 int srmap_problem_active_impl(const srmap_problem* p, int* impl) {
   if (!p || !impl) return SRMAP_EINVAL;
   const bool ztile = p->impl != SRMAP_IMPL_DIRECT && p->zplan != nullptr;
-  if (p->impl == SRMAP_IMPL_MARCH && ztile && ztile_covers_march(p)) *impl = SRMAP_IMPL_MARCH;
-  else *impl = ztile ? SRMAP_IMPL_TILED : SRMAP_IMPL_DIRECT;
+  *impl = ztile ? SRMAP_IMPL_TILED : SRMAP_IMPL_DIRECT;
   return SRMAP_OK;
 }
 

@@ -188,7 +188,6 @@ void ztile_release(srmap_problem* p);
 void ztile_preload(const srmap_problem* p);
 bool ztile_overlaps_halo(const srmap_problem* p);  // the next tile evaluation can run interior tiles under the halo exchange
 bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms);  // the tile kernel alone produces the regulariser part
-bool ztile_covers_march(const srmap_problem* p);  // the plan is served by the marching kernel (kernels_march.hip)
 size_t ztile_partials_needed(const srmap_problem* p);
 template <typename T>
 int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,

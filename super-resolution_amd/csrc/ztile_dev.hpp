@@ -1,5 +1,5 @@
-// ztile_dev.hpp -- device helpers, kernel-argument blocks and the host-side plan shared by the two hot-path kernels
-// (kernels_ztile.hip: workgroup tiles; kernels_march.hip: marching waves).  Formulation: DESIGN.md section 3.1.
+// ztile_dev.hpp -- device helpers, kernel-argument block and the host-side plan of the hot-path kernel
+// (kernels_ztile.hip: workgroup tiles).  Formulation: DESIGN.md section 3.1.
 #pragma once
 #include <algorithm>
 #include <climits>
@@ -53,7 +53,7 @@ constexpr int zceil(int a, int b) { return (a + b - 1) / b; }
 
 template <typename T, int S, int B, int REGK, int R, int NW_ = 8>
 struct ZCfg {
-  static constexpr int NW = NW_;               // waves = HR rows per tile (8: k_eval_z; the persistent kernel may take more)
+  static constexpr int NW = NW_;               // waves = HR rows per tile
   static constexpr int NT = 64 * NW;
   static constexpr int TH = NW;
   static constexpr int CW = 64;                // LR cells per tile row = lanes
@@ -936,88 +936,9 @@ struct ZPlan {
   RingRects ring = {{0, 0, 0, 0, 0, 0}};
   void* d_corr = nullptr;      // [C][n_ring] border corrections of the gradient
   void* d_bd = nullptr;        // BorderArgs<T> (device)
-  double* d_mpart = nullptr;   // marching kernel: write-through partial granules, [2][mpart_cap] (cost, g.d); sentinel = unpublished
+  double* d_mpart = nullptr;   // write-through partial granules of the in-kernel cost reduction, [2][mpart_cap] (cost, g.d); sentinel = unpublished
   size_t mpart_cap = 0;
-  unsigned long long* d_ctr64 = nullptr;        // marching kernel: monotonic counter of the end-of-wave border task pick-up
-  mutable unsigned long long task_count = 0;  //   its value after the launches issued so far
-  unsigned* d_ctr = nullptr;   // marching kernel: [0] ticket, [1] border duty waves done, [2] wait timed out (zero between launches)
-  unsigned* d_queue = nullptr; // persistent kernel: [0..7] item counters of the XCD lists, [8] exit ticket (zero between launches)
 };
 
-
-// The argument fields every hot-path kernel shares (problem geometry, frame table by value, blur and regulariser
-// constants, border frame); grid-specific fields (nby, n_tile_partials, finish) are the launcher's.
-template <typename T, int S, int B, int REGK, int R, typename ArgsT>
-static inline void fill_common_args(ArgsT& A, srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x,
-                                    T* g, const T* wts, const ZPlan& z, double* partials, const T* dvec,
-                                    double* partials_gd) {
-  constexpr int NP = REGK == 2 ? 2 * R + 1 : 1;
-  A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
-  A.dvec = dvec; A.partials_gd = partials_gd;
-  A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
-  for (int pr = 0; pr < 4; ++pr) {
-    for (int i = 0; i < 8; ++i) A.cntk[pr][i] = z.h_cnt[pr * 8 + i];
-    for (int pc = 0; pc < 4; ++pc) { A.off0[pr][pc] = z.h_off0[pr * 4 + pc]; A.aux0[pr][pc] = z.h_aux0[pr * 4 + pc]; }
-  }
-  A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
-  A.obs_C = p->geo.C;
-  A.E = z.E;
-  A.ring = z.ring;
-  A.cr0 = geo.cr0; A.cr1 = geo.cr1;
-  A.rr0 = geo.rr0; A.rr1 = geo.rr1;
-  A.terms = (int)terms;
-  if (B == 1) { A.blur3[0] = A.blur3[1] = A.blur3[2] = T(1); A.k1s[0] = A.k1s[1] = T(1); }
-  else {
-    const int hb = (B - 1) / 2;
-    A.blur3[0] = (T)p->blur2d[0]; A.blur3[1] = (T)p->blur2d[hb]; A.blur3[2] = (T)p->blur2d[hb * B + hb];
-    A.k1s[0] = (T)p->blur1d[0]; A.k1s[1] = (T)p->blur1d[hb];
-  }
-  A.lambda = T(0);
-  for (int i = 0; i < NP; ++i) A.powtab[i] = T(1);
-  if (REGK != 0 && z.reg_index >= 0) {
-    const RegSpec& rs = p->reg[z.reg_index];
-    A.lambda = (T)rs.lambda;
-    if (REGK == 2) for (int i = 0; i < NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
-  }
-  A.pwsum = T(0);
-  if (REGK == 2)
-    for (int i = 0; i < R; ++i)
-      for (int j = 0; j < R; ++j)
-        if (i + j > 0) A.pwsum += A.powtab[i + j];
-  A.bd = (const BorderArgs<T>*)z.d_bd;
-  A.nby = 0; A.n_tile_partials = 0;
-  A.rbuf = nullptr; A.spw = z.d_spw; A.Dr = z.Dr;
-  A.sel_mode = 0; A.sel0 = 0; A.sel1 = 0;
-  A.mfinish = 0; A.n_partials = 0;
-  A.mpart = z.d_mpart;
-  A.mpart_gd = z.d_mpart ? z.d_mpart + z.mpart_cap : nullptr;
-  A.cost_out = p->d_cost;
-  A.pub = nullptr;
-  A.tag_slot = p->eval_pub_tag_slot;
-  A.tag = p->eval_pub_tag;
-}
-
-// ---- marching-wave kernel (kernels_march.hip) ----
-// One launch: data term + the fused regulariser + border corrections; when finish_ok and the partials are few enough
-// also the fixed-order cost reduction into p->d_cost (*finished).  *nblocks = partials written.
-template <typename T>
-int launch_eval_march(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g, const T* wts,
-                      int regk, int regr, double* partials, int* nblocks, bool finish_ok, bool* finished, hipStream_t st,
-                      const T* dv, double* pgd, bool publish);
-size_t march_partials_needed(const srmap_problem* p);
-bool march_alloc(srmap_problem* p, ZPlan* z);   // counters and granules of the plan
-void march_preload(const srmap_problem* p);
-bool march_has_instance(int S, int B, int regk, int regr);  // compiled instances of the (opt-in) marching kernel
-
-// ---- persistent tile kernel (kernels_ptile.hip) ----
-// One launch of one workgroup per CU; every workgroup pulls tiles (and border blocks) from per-XCD queues and keeps the
-// next tile's inputs in flight while it computes.  Same outputs and partial layout as k_eval_z (*nblocks, *finished as
-// for the marching kernel).
-template <typename T>
-int launch_eval_persist(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g, const T* wts,
-                        int regk, int regr, double* partials, int* nblocks, bool finish_ok, bool* finished, hipStream_t st,
-                        const T* dv, double* pgd, bool publish);
-bool persist_has_instance(int S, int B, int regk, int regr);
-void persist_preload(const srmap_problem* p);
 
 }  // namespace srmap

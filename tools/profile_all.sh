@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_all.sh [tag] (run through gpurun from the repo root): the whole per-round measurement set into
 # gpurun_out/<tag>/ -- profile_round.sh (bench, kernel stats, PMC passes), all configurations, sub-pixel path, solver
-# trace, cfg5 per kernel, the Infinity Cache share of the bench number, tile vs marching kernel.
+# trace, cfg5 per kernel, the Infinity Cache share of the bench number.
 # Then:  python tools/collect_profiles.py gpurun_out/<tag> rNN ; copy the .txt summaries to profiles/rNN_*.txt
 tag=${1:-r03b}
 set -x
@@ -13,5 +13,4 @@ bash tools/sp_prof.sh 2>&1 | tail -12 > gpurun_out/$tag/subpixel.txt
 bash tools/solve_trace.sh 2>&1 | tail -16 > gpurun_out/$tag/solve_trace.txt
 bash tools/cfg_prof.sh 5 16 ${tag}_cfg5 2>&1 | tail -12 > gpurun_out/$tag/cfg5_16ch.txt
 python tools/hbm_fed_timing.py 2>&1 | tail -12 > gpurun_out/$tag/hbm_fed.txt
-python tools/march_check.py --no-oracle --time 2>&1 | tail -12 > gpurun_out/$tag/march_vs_tiles.txt
 ls gpurun_out/$tag
