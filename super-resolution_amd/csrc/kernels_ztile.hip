@@ -1,7 +1,8 @@
 // kernels_ztile.hip -- the hot path: one MAP gradient iteration
 // (ObjectiveFunction::ComputeAllTerms, objective_function.cpp:5-20) as ONE
-// LDS-tiled launch (border blocks ride at the front of its grid) + the one-block
-// finish launch, for the common geometry:
+// LDS-tiled launch (border blocks ride at the front of its grid; the cost
+// partials are reduced by its last workgroup -- a finish launch follows only when
+// in-image border corrections have to be subtracted), for the common geometry:
 // integer motion shifts, HR = LR * S, S in {2,3,4}, blur size B in {1,3}, first
 // regulariser 2-D TV or BTV with range <= 3.  Everything else is evaluated by
 // kernels_direct.hip.
