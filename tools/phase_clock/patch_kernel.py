@@ -4,7 +4,7 @@ import sys
 root = sys.argv[1] if len(sys.argv) > 1 else "/root/repo"
 src=open(root + '/super-resolution_amd/csrc/kernels_ztile.hip').read()
 s=src
-anchor = 'constexpr int floordiv(int a, int b)'
+anchor = 'template <typename T, int S, int B, int REGK, int R, bool WD, bool SP>\n__global__'
 assert anchor in s
 s=s.replace(anchor,'__device__ unsigned long long* g_ztdbg = nullptr;\n#define ZT_STAMP(i) do { zts[i] = __builtin_readcyclecounter(); } while (0)\n\n' + anchor,1)
 def rep(old,new):
@@ -42,8 +42,8 @@ rep('''  __syncthreads();
 rep('''  // ---------------- cost partial of this workgroup ----------------''','''  ZT_STAMP(9);
   if (dbg && lane == 0) { for (int q = 0; q < 10; ++q) dbg[q] = zts[q]; dbg[10] = rt0; dbg[11] = wall_clock64(); dbg[12] = ((unsigned long long)xccid << 32) | hwid; }
   // ---------------- cost partial of this workgroup ----------------''')
-rep('''    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);''','''    const unsigned long long brt0 = wall_clock64();
-    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs);
+rep('''    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);''','''    const unsigned long long brt0 = wall_clock64();
+    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
     if (g_ztdbg && threadIdx.x == 0) { unsigned long long* d = g_ztdbg + ((size_t)(2048 + bidx) * 8) * 16; d[10] = brt0; d[11] = wall_clock64(); d[12] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); d[13] = (bidx * C::NT < Bd.n_ring); }''')
 rep('// ---------------------------------------------------------------------------------------------------------\n// host side: plan','extern "C" int srmap_dbg_set_timing(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ztdbg), &buf, sizeof(buf)); }\n// ---------------------------------------------------------------------------------------------------------\n// host side: plan')
 open('/tmp/spx/kz_time.hip','w').write(s)
