@@ -71,6 +71,21 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   __shared__ T wcs[32];  // IRLS weights of the left-halo-column pixels (two columns x up to 16 rows)
   __shared__ T whs[(C::RU > 0 ? C::RU : 1) * S * C::CW];  // IRLS weights of the halo rows of 2*lambda*w*r
 
+  // Every argument the head of a workgroup reads -- up to its first memory requests -- is requested HERE, in one batch
+  // ahead of the first branch.  Left to the compiler each uniform early-out below (border block? selected tile row?
+  // edge tile?) fetched its own word behind its own s_waitcnt: six dependent scalar-load round trips (~250 cycles
+  // each) stood between the start of a workgroup and its first x request (profiles/r03_phase_clock.txt: "issue x
+  // loads" 2.1 K cycles).  The empty asm makes all of them live at this point; later reads of the same fields reuse
+  // the registers.
+  {
+    const T* a_x = A.x; const T* a_y = A.y; const T* a_w = A.w; T* a_g = A.g;
+    const int a_W = A.W, a_H = A.H, a_wl = A.wl, a_hl = A.hl, a_nby = A.nby, a_E = A.E, a_terms = A.terms, a_obsC = A.obs_C;
+    const int a_cr0 = A.cr0, a_cr1 = A.cr1, a_rr0 = A.rr0, a_rr1 = A.rr1, a_sm = A.sel_mode, a_s0 = A.sel0, a_s1 = A.sel1;
+    const unsigned a_gx = gridDim.x, a_gy = gridDim.y;
+    asm volatile("" ::"s"(a_x), "s"(a_y), "s"(a_w), "s"(a_g), "s"(a_W), "s"(a_H), "s"(a_wl), "s"(a_hl), "s"(a_nby), "s"(a_E),
+                 "s"(a_terms), "s"(a_obsC), "s"(a_cr0), "s"(a_cr1), "s"(a_rr0), "s"(a_rr1), "s"(a_sm), "s"(a_s0), "s"(a_s1),
+                 "s"(a_gx), "s"(a_gy));
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = HR row of the tile (SGPR)
@@ -110,7 +125,6 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // frame shards evaluate the regulariser of their own row band only (whole tiles: the band is tile aligned)
   const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0 && R0 >= A.rr0 && R0 < A.rr1;
   const T* ybase = A.y + (size_t)ch * nl;
-
   // ---------------- global loads whose addresses are known now: x tile, observations, IRLS weights ----------------
   constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // x rows per wave
   constexpr int EXTRA = C::XC - C::CW;              // halo cells, staged by the first lanes
@@ -649,7 +663,8 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   return tiles + ring;
 }
 
-struct MFin { bool on, publish; };  // in-kernel finish of this launch; publish {cost, g.d} to the solver's host words
+// in-kernel finish of this launch; publish {cost, g.d} to the solver's host words; plain partials of an earlier launch to add
+struct MFin { bool on, publish; const double* xpart; int n_xpart; };
 
 template <typename T, int S, int B, int REGK, int R>
 static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
@@ -711,6 +726,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.pub = mfin.publish ? p->eval_pub : nullptr;
   A.tag_slot = p->eval_pub_tag_slot;
   A.tag = p->eval_pub_tag;
+  A.xpart = mfin.xpart; A.n_xpart = mfin.n_xpart;
   if (mfin.on && (size_t)A.n_partials > z.mpart_cap) return set_error(p->ctx, SRMAP_EHIP, "granule capacity");
   A.sel_mode = 0; A.sel0 = 0; A.sel1 = 0;
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
@@ -835,10 +851,14 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   p->eval_published = false;
   // tiles: the cost reduction inside the kernel (no finish launch) when no in-image pixel of the border frame needs a
   // correction, no further regulariser kernel follows and the granules suffice
+  // Sub-pixel plan: the forward kernel's data-cost partials (plain doubles, complete before the tile kernel starts) are
+  // added by the same in-kernel finish; the ring pass that follows touches g only.
   MFin mfin;
-  mfin.on = !z.subpix && !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
-            (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0));
+  mfin.on = !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
+            (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0)) && nfwd <= 16384;
   mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
+  mfin.xpart = (mfin.on && sp_data) ? partials - nfwd : nullptr;
+  mfin.n_xpart = (mfin.on && sp_data) ? nfwd : 0;
   if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
   else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
   else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);

@@ -192,6 +192,9 @@ __device__ __forceinline__ void finish_block(const ArgsT& A, double* red /* LDS,
         acc += (i < A.n_partials) ? __longlong_as_double((long long)a[u]) : 0.0;
       }
     }
+    if (pass == 0 && A.n_xpart > 0) {  // partials of the earlier launch: behind the granules, strided in index order
+      for (int i = tid; i < A.n_xpart; i += NT) acc += A.xpart[i];
+    }
     acc = wave_sum_d(acc);
     __syncthreads();
     if (lane == 0) red[wid] = acc;
@@ -274,6 +277,8 @@ struct ZArgs {
   double* pub;           // solver line search: host-mapped {cost, g.d}, then the arrival tag
   double* tag_slot;
   double tag;
+  const double* xpart;   // plain cost partials of an EARLIER launch on the stream (sub-pixel path: the forward kernel's data
+  int n_xpart;           //   cost), complete when this kernel starts: the in-kernel finish adds them, in index order
 };
 
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
