@@ -523,6 +523,12 @@ bool ztile_plan(srmap_problem* p) {
               hipMemcpy(z->d_spw, spw.data(), sizeof(double) * spw.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&z->d_off, 64) == hipSuccess;
     p->zplan = z;
+    if (ok) {  // granules of the in-kernel cost reduction (as below)
+      const size_t cap = std::min<size_t>(ztile_partials_needed(p), (size_t)16384);
+      ok = hipMalloc((void**)&z->d_mpart, 2 * cap * sizeof(double)) == hipSuccess &&
+           hipMemsetD32((hipDeviceptr_t)z->d_mpart, (int)kSentinel32, 4 * cap) == hipSuccess;
+      z->mpart_cap = cap;
+    }
     if (!ok) { ztile_release(p); return false; }
     (void)spfwd_plan(p, &z->spf);
     return true;
@@ -830,7 +836,8 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (want_reg)
     for (int r = 0; r < p->nreg; ++r)
       if (!(regk && r == z.reg_index) && p->reg[r].lambda > 0.0) more_regs = true;
-  const size_t est_parts = (size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8) * geo.C + (size_t)((z.n_ring + 511) / 512 + (geo.H + 7) / 8) * geo.C;
+  const size_t est_parts = (size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8) * geo.C +
+                           (z.n_ring > 0 ? (size_t)((z.n_ring + 511) / 512 + (geo.H + 7) / 8) * geo.C : (size_t)0);  // as ztile_partials_needed
   const bool sp_data = z.subpix && (terms & SRMAP_TERM_DATA);
   const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= 16384 && !z.subpix;
   int nfwd = 0;
