@@ -416,6 +416,12 @@ __global__ __launch_bounds__(256) void k_finish_eval(T* __restrict__ g, const T*
 // ---------------------------------------------------------------------------------------------------------
 // host side: plan (per problem, owned by the problem) and launch
 
+// Up to this many cost partials (tiles + border blocks of all channels) one workgroup reduces them -- the tile kernel's
+// last one, or k_finish_eval's block 0 -- and the solver gets g.d out of the same launch; beyond it the caller reduces in
+// two stages.  64 K covers configs[2] (RGB 4096^2: 24 576 tiles), which at 16 K paid two more launches per evaluation and
+// a separate 400 MB dot-product pass per trial point of a solve.
+constexpr size_t kMaxFusedPartials = 65536;
+
 void ztile_release(srmap_problem* p) {
   ZPlan* z = static_cast<ZPlan*>(p->zplan);
   if (!z) return;
@@ -524,7 +530,7 @@ bool ztile_plan(srmap_problem* p) {
               hipMalloc((void**)&z->d_off, 64) == hipSuccess;
     p->zplan = z;
     if (ok) {  // granules of the in-kernel cost reduction (as below)
-      const size_t cap = std::min<size_t>(ztile_partials_needed(p), (size_t)16384);
+      const size_t cap = std::min<size_t>(ztile_partials_needed(p), kMaxFusedPartials);
       ok = hipMalloc((void**)&z->d_mpart, 2 * cap * sizeof(double)) == hipSuccess &&
            hipMemsetD32((hipDeviceptr_t)z->d_mpart, (int)kSentinel32, 4 * cap) == hipSuccess;
       z->mpart_cap = cap;
@@ -634,7 +640,7 @@ bool ztile_plan(srmap_problem* p) {
   if (ok) {
     // granules of the in-kernel cost reduction (one per tile + one per border block), up to a cap beyond which the
     // caller's two-stage reduction is used anyway
-    const size_t cap = std::min<size_t>(ztile_partials_needed(p), (size_t)16384);
+    const size_t cap = std::min<size_t>(ztile_partials_needed(p), kMaxFusedPartials);
     ok = hipMalloc((void**)&z->d_mpart, 2 * cap * sizeof(double)) == hipSuccess &&
          hipMemsetD32((hipDeviceptr_t)z->d_mpart, (int)kSentinel32, 4 * cap) == hipSuccess;
     z->mpart_cap = cap;
@@ -839,7 +845,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   const size_t est_parts = (size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8) * geo.C +
                            (z.n_ring > 0 ? (size_t)((z.n_ring + 511) / 512 + (geo.H + 7) / 8) * geo.C : (size_t)0);  // as ztile_partials_needed
   const bool sp_data = z.subpix && (terms & SRMAP_TERM_DATA);
-  const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= 16384 && !z.subpix;
+  const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= kMaxFusedPartials && !z.subpix;
   int nfwd = 0;
   if (sp_data) {
     // sub-pixel shifts: exact residuals (and the data cost) from the direct forward kernel, then the tile kernel
@@ -862,7 +868,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   // added by the same in-kernel finish; the ring pass that follows touches g only.
   MFin mfin;
   mfin.on = !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
-            (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0)) && nfwd <= 16384;
+            (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0)) && (size_t)nfwd <= kMaxFusedPartials;
   mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
   mfin.xpart = (mfin.on && sp_data) ? partials - nfwd : nullptr;
   mfin.n_xpart = (mfin.on && sp_data) ? nfwd : 0;
@@ -911,7 +917,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   }
   // finish: border corrections of g + the fixed-order cost reduction, one launch
   const bool corr_on = (terms & SRMAP_TERM_DATA) && z.n_ring > 0 && g != nullptr;
-  if (total <= 16384) {
+  if ((size_t)total <= kMaxFusedPartials) {
     const int nring = corr_on ? z.n_ring : 0;
     const unsigned nb_f = 1u + (unsigned)((nring + 255) / 256);
     hipLaunchKernelGGL(k_finish_eval<T>, dim3(nb_f), dim3(256), 0, st, corr_on ? g : (T*)nullptr, (const T*)z.d_corr,

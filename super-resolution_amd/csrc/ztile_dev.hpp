@@ -183,8 +183,10 @@ __device__ __forceinline__ void finish_block(const ArgsT& A, double* red /* LDS,
           missing |= (i < A.n_partials) && a[u] == kSentinel;
         }
         if (!__syncthreads_or(missing)) break;
-        if (++spins > (1u << 14)) { timed_out = true; break; }
-        __builtin_amdgcn_s_sleep(4);
+        // bounded like the host's wait (~2 s): a workgroup that never publishes (a fault elsewhere on the device) ends the
+        // evaluation with a NaN cost instead of hanging the stream; a busy or shared GPU does not get near it
+        if (++spins > (1u << 21)) { timed_out = true; break; }
+        if (spins < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
