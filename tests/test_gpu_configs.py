@@ -312,6 +312,34 @@ def test_cfg5_full_size(sr, ctx):
     _full_size_case(sr, ctx, "cfg5", 2048, 2048, 256, [0, 1, 128, 255])
 
 
+def test_many_partials_one_launch_finish_and_gd(sr, ctx):
+    """More than 16 384 cost partials in ONE launch (70 channels x 256 tile rows = 17 920 tiles + border blocks; BASELINE
+    configs[2] has 24 576): the tile kernel's last workgroup still reduces them (several polling chunks) and hands the
+    solver g.d from the same launch.  A short CG run on the tile path must follow the run on the direct kernels (cost and
+    g.d from separate reduction launches there) evaluation for evaluation."""
+    rng = np.random.default_rng(31)
+    s, K, C, h, w = 4, 4, 70, 512, 64
+    H, W = h * s, w * s
+    shifts = [[0, 0], [-1, -2], [-3, -1], [-2, -3]]
+    lr = rng.random((K, C, h, w))
+    x0 = rng.random((C, H, W))
+    res = {}
+    for name, impl in (("tiled", sr.IMPL_TILED), ("direct", sr.IMPL_DIRECT)):
+        p = sr.Problem(ctx, W, H, C, K, s, shifts, 3, 1.0, sr.F64)
+        p.set_impl(impl)
+        p.set_observations(lr)
+        p.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
+        f, g = p.eval(x0)
+        x, its, nfev, term, trace = p.cg_trace(x0, 0.0, 0.0, 0.0, 3)
+        res[name] = (f, g, x, its, nfev, term, trace)
+        del p
+    (f1, g1, x1, i1, n1, t1, tr1), (f2, g2, x2, i2, n2, t2, tr2) = res["tiled"], res["direct"]
+    assert abs(f1 - f2) <= 1e-12 * abs(f2) and relerr(g1, g2) <= 1e-12
+    assert (i1, n1, t1) == (i2, n2, t2) and len(tr1) == len(tr2)
+    assert np.max(np.abs(tr1 - tr2) / np.maximum(1.0, np.abs(tr2))) <= 1e-11
+    assert np.max(np.abs(x1 - x2)) <= 1e-9
+
+
 def test_indexing_beyond_2_31_elements(sr):
     """a15 (GetPixelIndex, 64-bit offsets): K * C * n = 2.28 G observation elements (> 2^31) at cfg5-like extents;
     the gradient of the first / middle / LAST channel of the many-channel problem must be bit-identical to that of a
