@@ -106,7 +106,12 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const int by = blockIdx.y - A.nby, nby_t = gridDim.y - A.nby;
   int tby = by, tbx = blockIdx.x;
   {
-    const int n = blockIdx.x, q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
+    // ... with launch indices 1 and last swapped: the bottom tile row (masked edge path in every column, the slowest
+    // tiles) would otherwise be the LAST workgroup of every tile column -- of the last column too, where it sets the
+    // end of the launch (and carries the in-kernel reduction).  It is dispatched second now, like the top row first.
+    const int n0 = blockIdx.x, last = (int)gridDim.x - 1;
+    const int n = (last > 1) ? (n0 == 1 ? last : (n0 == last ? 1 : n0)) : n0;
+    const int q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
     tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
     // tile columns in the order first, last, second, ...: the masked edge columns (longest-lived tiles) are not the
     // launch's last generation
