@@ -208,6 +208,14 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        # N > 1 has never run on more than one GPU here (1-GPU leases): a rank stuck in an exchange must end the job
+        # with an error instead of holding the node -- the whole multi-rank bench takes well under two minutes
+        import faulthandler
+        import signal
+        faulthandler.enable()
+        signal.signal(signal.SIGALRM, lambda *_: (sys.stderr.write("bench.py: rank %d timed out (900 s)\n" % rank), os._exit(3)))
+        signal.alarm(900)
     local_rank = 0 if args.test_single_device else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
