@@ -230,11 +230,14 @@ __global__ void k_publish(double* __restrict__ dst, const double* __restrict__ s
 // linminnormalized (alglibinternal.cpp:12165-12196): d = (dn * s1) * s2 with s1 = 1 / max|dn| and
 // s2 = 1 / sqrt(sum (dn s1)^2); the sum is taken as (dn.dn) * s1^2 from the pass that produced dn.  norms = device
 // {max|dn|, dn.dn} (already all-reduced); every thread derives the same two factors.  Partials: [0] g.d, [1] d.d.
-// Block 0 publishes s1, s2 in scal_out[0..1] for the host's step scaling.
+// Block 0 publishes s1, s2 in scal_out[0..1] for the host's step scaling.  When the first step of the line search is
+// known before this pass (ALGLIB's lastgoodstep), its trial point x1 = xk + stp1 * d is written here as well: one pass
+// over xk / x less per CG iteration than a separate k_axpy_out (same expression, same rounding).
 template <typename T>
 __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const T* __restrict__ dn, const T* __restrict__ g,
                                                        const double* __restrict__ norms, size_t n, Owned ow,
-                                                       double* __restrict__ part, double* __restrict__ scal_out, Fin fin) {
+                                                       double* __restrict__ part, double* __restrict__ scal_out, Fin fin,
+                                                       const T* __restrict__ xk, T* __restrict__ x1, T stp1) {
   const double mx = norms[0], ss = norms[1];
   double s1 = 1.0, s2 = 1.0;
   if (mx != 0.0) { s1 = 1.0 / mx; s2 = 1.0 / sqrt(ss * s1 * s1); }
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const T v = mx != 0.0 ? (T)(((double)dn[i] * s1) * s2) : dn[i];
     d[i] = v;
+    if (x1 != nullptr) x1[i] = xk[i] + stp1 * v;  // the line search's first trial point (k_axpy_out's expression)
     if (ow.has(i)) { gd += (double)g[i] * (double)v; dd += (double)v * (double)v; }
   }
   if (block_partials3(gd, dd, 0.0, part, false, 2, fin)) {
@@ -707,7 +711,7 @@ static void mt_step(Bracket* b, double* stp, double fp, double dp, bool* brackt,
 // trimfunction after each evaluation as mincgiteration does, optimization.cpp:17594).
 template <typename T>
 static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, double gtol,
-                       int* info, int* nfev, double trim, std::vector<double>* trace) {
+                       int* info, int* nfev, double trim, std::vector<double>* trace, double stp_in_x = 0.0) {
   const double ftol = 0.001, xtol = 100 * 5E-16, stpmin = 1.0e-50, stpmax = 1.0e+50, p5 = 0.5,
                p66 = 0.66, xtrapf = 4.0;
   const int maxfev = 20;
@@ -734,8 +738,10 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
     if ((brackt && (*stp <= stmin || *stp >= stmax)) || *nfev >= maxfev - 1 || infoc == 0 ||
         (brackt && stmax - stmin <= xtol * stmax))
       *stp = b.stx;
-    hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
-                       (const T*)cg.d, (T)*stp, cg.n);
+    // stp_in_x: cg.x already holds xk + stp_in_x * d (written by the normalisation pass); any other step is formed here
+    if (!(*nfev == 0 && stp_in_x != 0.0 && *stp == stp_in_x))
+      hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
+                         (const T*)cg.d, (T)*stp, cg.n);
     rc = cg.evaluate(cg.d);
     if (rc) return rc;
     double h[2];
@@ -831,10 +837,13 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     // d = normalised dk (linminnormalized), g.d, d.d; x = xk is not materialised: the line search writes every
     // trial point x = xk + stp * d itself
     double stp = 1.0, dginit = 0, dd = 0;
+    // the first step is lastgoodstep unless that is 0 (then it comes from the norms this pass reduces)
+    const double stp_pre = (lastgoodstep != 0 && lastgoodstep >= 1.0e-50 && lastgoodstep <= 1.0e+50) ? lastgoodstep : 0.0;
     {
       hipLaunchKernelGGL(k_normalize_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
                          (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
-                         cg.fin_host(false, nullptr, cg.hs + 8, 0));
+                         cg.fin_host(false, nullptr, cg.hs + 8, 0), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
+                         (T)stp_pre);
       double h[2];
       rc = cg.finish(2, false, false, h, 4);  // + {max|dk|, dk.dk, s1, s2} -> hs[8..11]
       if (rc) return rc;
@@ -846,7 +855,7 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     if (lastgoodstep != 0) stp = lastgoodstep;
     int mcinfo = 0, nfev = 0;
     std::swap(cg.g, cg.gp);  // gp = gradient at xk; the trial evaluations write g
-    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace);
+    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace, stp_pre);
     if (rc) return rc;
     if (nfev == 0) std::swap(cg.g, cg.gp);  // nothing was evaluated: g stays the gradient at xk, as in mcsrch
     double betak = 0;
