@@ -287,6 +287,19 @@ __global__ void k_axpy_out(T* __restrict__ dst, const T* __restrict__ a, const T
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = a[i] + alpha * b[i];
 }
+// the same, four elements per thread (16 / 32-byte requests; hipMalloc'ed vectors are aligned): element by element the
+// same expression, so the same bits
+template <typename T>
+__global__ __launch_bounds__(256) void k_axpy_out4(T* __restrict__ dst, const T* __restrict__ a, const T* __restrict__ b, T alpha,
+                                                  size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  T va[4], vb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { va[q] = a[4 * i + q]; vb[q] = b[4 * i + q]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[4 * i + q] = va[q] + alpha * vb[q];
+}
 template <typename T>
 __global__ void k_fill(T* __restrict__ d, T v, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -740,8 +753,14 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
       *stp = b.stx;
     // stp_in_x: cg.x already holds xk + stp_in_x * d (written by the normalisation pass); any other step is formed here
     if (!(*nfev == 0 && stp_in_x != 0.0 && *stp == stp_in_x))
-      hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
-                         (const T*)cg.d, (T)*stp, cg.n);
+    {
+      if ((cg.n & 3) == 0)
+        hipLaunchKernelGGL(k_axpy_out4<T>, dim3((unsigned)((cg.n / 4 + 255) / 256)), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
+                           (const T*)cg.d, (T)*stp, cg.n / 4);
+      else
+        hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
+                           (const T*)cg.d, (T)*stp, cg.n);
+    }
     rc = cg.evaluate(cg.d);
     if (rc) return rc;
     double h[2];
