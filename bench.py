@@ -11,20 +11,24 @@ is quoted on -- 16-frame grayscale, 4x upscale to 2048x2048 HR, Gaussian blur
 (3, sigma 1) + BTV (range 3, decay 0.5, lambda 0.01); cfg3 = configs[2] -- 16-frame
 RGB, 4x upscale to 4096x4096, BTV.  The SAME workload at every N ("strong" scaling).
 
-N > 1 -- one process per GPU, torch.distributed over RCCL.  `python bench.py --gpus N`
-without a launcher re-executes itself under torch.distributed.run.  The path shards
-inside the C ABI (srmap_eval_sharded_device: the exchanges are issued by the library
-on the evaluation's stream):
+N > 1 -- one process per GPU.  `python bench.py --gpus N` without a launcher re-executes
+itself under torch.distributed.run.  The path shards inside the C ABI
+(srmap_eval_sharded_device: the exchanges are issued by the library on the evaluation's
+stream through ITS communicator -- the one RCCL instance of the process; the harness's
+own barriers and host scalars travel over a gloo group):
   * rows (default, the scaling path): rank r owns a band of HR rows; before every
     evaluation the boundary rows of x travel to the two neighbours (ncclSend/ncclRecv,
-    both directions in one group);
+    both directions in one group; --overlap posts them under the interior tile rows);
   * frames (the north-star's exchange, timed in the same run and reported under
     "frames_variant"): rank r owns frames k = r (mod N) and a replica of x; the
     HR gradient and the cost are all-reduced (ncclAllReduce, one group) after the
     local evaluation (reference: alglib_objective.cpp:142-152 is where the gradient
-    of all frames meets).
+    of all frames meets);
   * --shard channels: N independent channels (the reference's split_channels
     semantics), no collective -- an explicit option only, weak scaling.
+A cfg2 run also carries a "cfg3" block: rows strong scaling of configs[2] (16-frame RGB,
+4096x4096) with its N = 1 time measured in the same run (by rank 0 alone when N > 1), so
+that the N = 1 / 2 / 4 / 8 curve contains a configuration large enough to scale.
 
 Timing: W untimed warm-up steps, then K timed steps between barriers, max over
 ranks.  A timed region shorter than --min-timed-ms (50 ms) is extended to whole
@@ -34,6 +38,7 @@ clocks only after ~50 ms of load).
 
 Prints ONE JSON line on rank 0 (see the task contract), including
   "roofline":     algorithmic bytes of one step / mean device time per step vs 8 TB/s
+                  (+ "hbm_fed": the same with three problems in rotation, i.e. inputs from HBM)
   "cpu_baseline": the CPU oracle (a port of the reference, oracle/) timed on this
                   host on a bounded sample of the same workload: 1 core (the
                   reference is single-threaded) and all cores.
@@ -157,6 +162,9 @@ def cpu_baseline(cfg, lr, x0, wts, budget_s=7.0):
                         "sample": "%d threads, each evaluating its own %dx%d HR tile of the image for %.1f s (%d tile "
                                   "evaluations in all), scaled by pixel count to the full workload" % (cores, tch, tch, el, sum(counts)),
                         "ms_per_step": 1e3 / full_per_s if full_per_s > 0 else None}
+    # the same figure inside the 1-core record's text (a consumer that keeps only the contract's fields still sees it)
+    out["sample"] += "; ALL CORES: %.3f iterations/s on %d hardware threads (one %dx%d HR tile per thread for %.1f s)" % (
+        full_per_s, cores, tch, tch, el)
     return out
 
 
@@ -190,6 +198,13 @@ def main():
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
                     help="ablation only: evaluate a subset of the objective terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-fed", action="store_true", help="skip the HBM-fed leg of the roofline (N = 1)")
+    ap.add_argument("--no-cfg3", action="store_true",
+                    help="skip the configs[2] block (rows strong scaling of the 16-frame RGB 4096x4096 problem) that a "
+                         "cfg2 run carries so that the N = 1 / 2 / 4 / 8 curve contains a configuration large enough to scale")
+    ap.add_argument("--overlap", action="store_true",
+                    help="rows, RCCL: post the halo exchange under the interior tile rows (srmap_comm_set_overlap; default: "
+                         "exchange first -- the overlapped form is opt-in until it has run on two GPUs)")
     ap.add_argument("--test-single-device", action="store_true",
                     help="testing aid for 1-GPU boxes: all ranks share GPU 0 and talk over gloo through the library's "
                          "host-callback communicator (exercises the N > 1 code paths; the numbers mean nothing)")
@@ -208,37 +223,32 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
-        # N > 1 has never run on more than one GPU here (1-GPU leases): a rank stuck in an exchange must end the job
-        # with an error instead of holding the node -- the whole multi-rank bench takes well under two minutes
-        import faulthandler
+
+    def watchdog(seconds, what):
+        """A rank stuck in an exchange must end the job with an error instead of holding the node."""
         import signal
+        signal.signal(signal.SIGALRM, lambda *_: (sys.stderr.write("bench.py: rank %d timed out (%d s) in %s\n" % (rank, seconds, what)),
+                                                  os._exit(3)))
+        signal.alarm(seconds)
+
+    if world > 1:
+        import faulthandler
         faulthandler.enable()
-        signal.signal(signal.SIGALRM, lambda *_: (sys.stderr.write("bench.py: rank %d timed out (900 s)\n" % rank), os._exit(3)))
-        signal.alarm(900)
+        watchdog(900, "the job")
     local_rank = 0 if args.test_single_device else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
+        # ONE RCCL instance in the process: the library's own communicator carries every device-side exchange; the
+        # harness (barriers, the broadcast of the RCCL unique id, max over ranks of the wall clock) talks gloo on the
+        # host.  Round 3 also opened an `nccl` process group here, i.e. a second communicator on PyTorch's RCCL.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.test_single_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = dict(CONFIGS[args.config])
-    if args.hr:
-        cfg["hr"] = args.hr
-    s, K, C = cfg["s"], cfg["K"], cfg["C"]
-    W = H = cfg["hr"]
-    w, h = W // s, H // s
-    shifts_all = [[k % s, (k // s) % s] for k in range(K)]
-    blur_k, blur_s = cfg["blur"]  # 0 = no blur module
     dtype = srmap.F64 if args.dtype == "f64" else srmap.F32
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     E = 8 if args.dtype == "f64" else 4
@@ -251,16 +261,23 @@ def main():
     # the library's communicator (N > 1): RCCL, or the host callbacks when every rank shares GPU 0
     comm = None
     comm_info = None
+    comm_lib = None
     if world > 1 and args.shard != "channels":
         if args.test_single_device:
             comm = srmap.Comm(ctx, rank, world, backend="host", dist=dist)
         else:
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
-                uid = torch.frombuffer(bytearray(srmap.Comm.unique_id(ctx)), dtype=torch.uint8).to(dev)
-            dist.broadcast(uid, 0)
-            comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=bytes(uid.cpu().numpy().tobytes()))
+                uid = torch.frombuffer(bytearray(srmap.Comm.unique_id(ctx)), dtype=torch.uint8).clone()
+            dist.broadcast(uid, 0)  # gloo, host memory
+            watchdog(120, "ncclCommInitRank")
+            comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=bytes(uid.numpy().tobytes()))
+            watchdog(900, "the job")
+            if args.overlap:
+                comm.set_overlap(True)
         comm_info = comm.info()
+        comm_lib = comm.describe()
+    is_rccl = comm_info is not None and comm_info[2] == 1
 
     def barrier():
         stream.synchronize()
@@ -269,36 +286,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(shard):
-        """Build this rank's part of the workload under `shard` and time it.  Returns (seconds per step on the
-        wall clock, max over ranks; device ms per step on this rank; timed steps; ramp steps; extras for rank 0)."""
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def make_cfg(name):
+        cfg = dict(CONFIGS[name])
+        if args.hr:
+            cfg["hr"] = args.hr
+        return cfg
+
+    def run(cfg, shard, steps, warmup, only_rank0=False, n_problems=1):
+        """Build this rank's part of the workload `cfg` under `shard` and time it.  only_rank0: rank 0 alone evaluates
+        the whole problem (the N = 1 reference of a strong-scaling block) while the other ranks wait.  n_problems > 1:
+        that many independent copies of the problem evaluated in rotation (the HBM-fed leg: from three copies on a
+        problem's 134 MB have left the 256 MiB Infinity Cache when its turn comes again).
+        Returns wall seconds per step (max over the ranks that ran), device ms per step on this rank, timed steps, ..."""
+        s, K, C = cfg["s"], cfg["K"], cfg["C"]
+        W = H = cfg["hr"]
+        blur_k, blur_s = cfg["blur"]  # 0 = no blur module
+        shifts_all = [[k % s, (k // s) % s] for k in range(K)]
+        solo = only_rank0 or world == 1
+        if only_rank0 and rank != 0:
+            barrier(); barrier(); barrier(); barrier()
+            return None
         frame_ids = list(range(K))
-        if shard == "frames":
+        if shard == "frames" and not solo:
             frame_ids = srmap_dist.frame_shard(K, world, rank)
         shifts = [shifts_all[k] for k in frame_ids]
         Hloc, e0, e1, r0, r1 = H, 0, H, 0, H
         bands = None
-        if shard == "rows":
+        if shard == "rows" and not solo:
             halo = srmap_dist.band_halo(s, max(blur_k, 1), s - 1, cfg["btv"][0])
             bands = [srmap_dist.row_band(H, s, world, r, halo) for r in range(world)]
             (r0, r1), (e0, e1) = bands[rank]
             Hloc = e1 - e0
-        Cloc = 1 if shard == "channels" and world > 1 else C
-        prob = srmap.Problem(ctx, W, Hloc, Cloc, len(frame_ids), s, shifts, blur_k, blur_s, dtype)
-        prob.set_impl(impl)
+        Cloc = 1 if (shard == "channels" and not solo) else C
+        probs = [srmap.Problem(ctx, W, Hloc, Cloc, len(frame_ids), s, shifts, blur_k, blur_s, dtype) for _ in range(n_problems)]
+        prob = probs[0]
         # synthetic data (SURVEY 8d), seeded; channel = rank under channel sharding
         gt = synth_ground_truth(W, H, max(C, world if shard == "channels" else 1))
-        gt = gt[rank:rank + 1] if (shard == "channels" and world > 1) else gt[:C]
+        gt = gt[rank:rank + 1] if (shard == "channels" and not solo) else gt[:C]
         gt = gt[:, e0:e1, :]
         lr = np.stack([prob.apply(gt, i) for i in range(len(frame_ids))])
         lr = lr + (5.0 / 255.0) * np.random.default_rng(777 + rank).standard_normal(lr.shape)
-        prob.set_observations(lr)
-        reg = prob.add_regularizer(srmap.REG_BTV, cfg["lam"], cfg["btv"][0], cfg["btv"][1])
         x0 = np.stack([bilinear_upsample(lr[0, c:c + 1], s)[0] for c in range(Cloc)])
-        wts = 1.0 / np.maximum(1e-5, prob.reg_values(reg, x0))
-        prob.set_irls_weights(reg, wts)
+        wts = None
+        for pr in probs:
+            pr.set_impl(impl)
+            pr.set_observations(lr)
+            reg = pr.add_regularizer(srmap.REG_BTV, cfg["lam"], cfg["btv"][0], cfg["btv"][1])
+            if wts is None:
+                wts = 1.0 / np.maximum(1e-5, pr.reg_values(reg, x0))
+            pr.set_irls_weights(reg, wts)
         sd = None
-        if comm is not None and shard in ("rows", "frames"):
+        if comm is not None and not solo and shard in ("rows", "frames"):
             sd = srmap.ShardDesc()
             if shard == "frames":
                 sd.mode, sd.reg_rank = srmap.SHARD_FRAMES, 0
@@ -312,15 +357,24 @@ def main():
                 if rank > 0:
                     (u0, u1), (ue0, ue1) = bands[rank - 1]
                     sd.send_up_rows = ue1 - u1
-        x_dev = torch.from_numpy(x0).to(dev, tdtype).contiguous()
-        g_dev = torch.empty_like(x_dev)
+        xs = [torch.from_numpy(x0).to(dev, tdtype).contiguous() for _ in range(n_problems)]
+        gs = [torch.empty_like(x) for x in xs]
+        turn = [0]
 
         def step():
+            i = turn[0]
+            turn[0] = (i + 1) % n_problems
             if sd is not None:
-                prob.eval_sharded_device(comm, sd, x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
+                prob.eval_sharded_device(comm, sd, xs[0].data_ptr(), gs[0].data_ptr(), terms, want_cost=False, stream=sh)
             else:
-                prob.eval_device(x_dev.data_ptr(), g_dev.data_ptr(), terms, want_cost=False, stream=sh)
+                probs[i].eval_device(xs[i].data_ptr(), gs[i].data_ptr(), terms, want_cost=False, stream=sh)
 
+        sync_all = (lambda: (stream.synchronize(), torch.cuda.synchronize())) if only_rank0 else barrier
+        if sd is not None:  # first contact of this shard mode with the communicator: a step that hangs ends the job in 30 s
+            watchdog(30, "the first %s-sharded step" % shard)
+            step()
+            stream.synchronize()
+            watchdog(900, "the job")
         ramp_steps = 0
         if args.clock_ramp_ms > 0:  # untimed: bring the GPU to its sustained clock state
             t_r = time.perf_counter()
@@ -329,21 +383,24 @@ def main():
                     step()
                 stream.synchronize()
                 ramp_steps += 20
-        barrier()
-        t_w = time.perf_counter()
-        for _ in range(args.warmup):
+        sync_all()
+        for _ in range(warmup):
             step()
-        barrier()
-        est = (time.perf_counter() - t_w) / max(1, args.warmup)  # seconds per step, from the warm-up
+        sync_all()
+        # how many steps make --min-timed-ms: from a SYNCHRONISED probe of the steady state (the warm-up's wall time
+        # includes two barriers and was, at 20 steps, mostly those)
+        probe = max(20, min(200, steps))
+        stream.synchronize()
+        t_p = time.perf_counter()
+        for _ in range(probe):
+            step()
+        stream.synchronize()
+        est = max_over_ranks((time.perf_counter() - t_p) / probe) if not only_rank0 else (time.perf_counter() - t_p) / probe
         reps = 1
         if args.min_timed_ms > 0 and est > 0:
-            reps = max(1, int(np.ceil(args.min_timed_ms * 1e-3 / (est * args.steps))))
-        if dist is not None:  # every rank times the same number of steps
-            t = torch.tensor([reps], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            reps = int(t.item())
-        n_timed = reps * args.steps
-        barrier()
+            reps = max(1, int(np.ceil(1.05 * args.min_timed_ms * 1e-3 / (est * steps))))
+        n_timed = reps * steps
+        sync_all()
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -353,39 +410,76 @@ def main():
             step()
         with torch.cuda.stream(stream):
             ev1.record(stream)
-        barrier()
+        sync_all()
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
-        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return dict(wall_per_step=float(tmax.item()) / n_timed, dev_ms_per_step=dev_ms / n_timed, timed_steps=n_timed,
+        if not only_rank0:
+            wall = max_over_ranks(wall)
+        if only_rank0:  # the waiting ranks sit in four barriers
+            barrier(); barrier(); barrier(); barrier()
+        return dict(wall_per_step=wall / n_timed, dev_ms_per_step=dev_ms / n_timed, timed_steps=n_timed,
                     ramp_steps=ramp_steps, lr=lr, x0=x0, wts=wts)
 
+    def b_alg_of(cfg, c_unit):
+        N, n = cfg["hr"] * cfg["hr"], (cfg["hr"] // cfg["s"]) ** 2
+        return E * c_unit * ((2 + 1) * N + cfg["K"] * n)  # x, y, w read once, g written once (per unit)
+
+    cfg = make_cfg(args.config)
     if world == 1:
-        main_shard, res = "none", run("none")
+        main_shard, res = "none", run(cfg, "none", args.steps, args.warmup)
         second = None
     elif args.shard == "channels":
-        main_shard, res, second = "channels", run("channels"), None
+        main_shard, res, second = "channels", run(cfg, "channels", args.steps, args.warmup), None
     elif args.shard == "frames":
-        main_shard, res, second = "frames", run("frames"), None
+        main_shard, res, second = "frames", run(cfg, "frames", args.steps, args.warmup), None
     else:
-        main_shard, res = "rows", run("rows")
-        second = run("frames")
+        main_shard, res = "rows", run(cfg, "rows", args.steps, args.warmup)
+        second = run(cfg, "frames", args.steps, args.warmup)
+
+    # ---- HBM-fed leg (N = 1): the same evaluation over three independent problems in rotation ----
+    hbm_fed = None
+    if world == 1 and not args.no_hbm_fed:
+        fed = run(cfg, "none", max(200, args.steps // 4), min(args.warmup, 60), n_problems=3)
+        fed_bytes = b_alg_of(cfg, cfg["C"])
+        hbm_fed = {"problems_in_rotation": 3, "working_set_bytes": 3 * fed_bytes,
+                   "device_ms_per_step": fed["dev_ms_per_step"], "timed_steps": fed["timed_steps"],
+                   "achieved": fed_bytes / (fed["dev_ms_per_step"] * 1e-3) / 1e9,
+                   "frac": fed_bytes / (fed["dev_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "note": "three independent copies of the problem evaluated round robin: a copy's inputs have left the 256 MiB "
+                           "Infinity Cache when its turn comes again, so every step streams its algorithmic bytes from HBM; "
+                           "untimed for `value`"}
+
+    # ---- configs[2] block: the configuration of the curve that is large enough to scale (rows, strong scaling) ----
+    cfg3_block = None
+    if args.config == "cfg2" and not args.no_cfg3 and args.shard != "channels" and args.terms == "all":
+        c3 = make_cfg("cfg3")
+        st3, wu3 = max(20, args.steps // 10), max(5, args.warmup // 10)
+        ref3 = run(c3, "none", st3, wu3, only_rank0=(world > 1))       # the N = 1 time, measured in this very run
+        sh3 = run(c3, "rows", st3, wu3) if world > 1 else ref3
+        if rank == 0:
+            cfg3_block = {"workload": c3["label"] % (c3["hr"], c3["hr"]), "shard": "rows" if world > 1 else "none",
+                          "scaling": "strong", "value": 1.0 / sh3["wall_per_step"], "unit": "MAP gradient iterations/s",
+                          "ms_per_step": sh3["wall_per_step"] * 1e3, "device_ms_per_step": sh3["dev_ms_per_step"],
+                          "timed_steps": sh3["timed_steps"],
+                          "n1_reference_ms_per_step": ref3["wall_per_step"] * 1e3,
+                          "speedup_vs_n1_in_this_run": ref3["wall_per_step"] / sh3["wall_per_step"],
+                          "roofline_frac_n1": b_alg_of(c3, c3["C"]) / (ref3["dev_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
+        s, K, C = cfg["s"], cfg["K"], cfg["C"]
+        W = H = cfg["hr"]
         units = float(world) if main_shard == "channels" else 1.0
-        N, n = W * H, w * h
-        rho = 1
         c_unit = 1 if main_shard == "channels" else C
-        b_alg = E * c_unit * ((2 + rho) * N + K * n)  # x, y, w read once, g written once (per unit)
+        b_alg = b_alg_of(cfg, c_unit)
         step_dev_s = res["dev_ms_per_step"] * 1e-3
         share = 1.0 if main_shard in ("none", "channels") else 1.0 / world  # bytes this GPU moves per step
         achieved = b_alg * share / step_dev_s / 1e9
         traffic, traffic_src = pmc_traffic(args.dtype)
+        sr_name, ar_name = ("ncclSend/ncclRecv", "ncclAllReduce") if (is_rccl or comm_info is None) else \
+            ("host-callback send/recv (test backend)", "host-callback all-reduce (test backend)")
         collective = {"none": "none",
-                      "rows": "ncclSend/ncclRecv of the halo rows of x (both directions in one group) inside srmap_eval_sharded_device",
-                      "frames": "ncclAllReduce(g, C*N) + ncclAllReduce(cost) in one group inside srmap_eval_sharded_device",
+                      "rows": sr_name + " of the halo rows of x (both directions in one group) inside srmap_eval_sharded_device",
+                      "frames": ar_name + "(g, C*N) + " + ar_name + "(cost) in one group inside srmap_eval_sharded_device",
                       "channels": "none (split_channels: independent per-channel solves)"}
         out = {
             "metric": "MAP gradient iterations/sec at fixed HR size",
@@ -393,29 +487,39 @@ def main():
             "unit": "MAP gradient iterations/s" if main_shard != "channels" else "channel-iterations/s (one %d-frame %dx%d channel per GPU)" % (K, W, H),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["wall_per_step"] * 1e3, "higher_is_better": True,
-            "scaling": "weak" if (world == 1 or main_shard == "channels") else "strong",
+            # ONE label for the whole N = 1 / 2 / 4 / 8 curve: the workload is the same at every N (only --shard channels
+            # gives every GPU its own channel)
+            "scaling": "weak" if main_shard == "channels" or (world == 1 and args.shard == "channels") else "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["label"] % (W, H), "frames": K, "scale": s, "channels": C,
                        "shard": main_shard, "collective_per_step": collective[main_shard],
-                       "rccl_ranks": (comm_info[1] if comm_info else (world if world > 1 else 1)),
-                       "comm_backend": (None if comm_info is None else ("rccl" if comm_info[2] == 1 else "host callbacks (test)")),
+                       "comm_ranks": (comm_info[1] if comm_info else (world if world > 1 else 1)),
+                       "comm_backend": (None if comm_info is None else ("rccl" if is_rccl else "host callbacks (test)")),
+                       "comm_library": comm_lib, "harness_group": ("gloo" if world > 1 else None),
+                       "halo_overlap": bool(args.overlap) if main_shard == "rows" else None,
                        "impl": args.impl, "device_ms_per_step": res["dev_ms_per_step"],
                        "timed_steps": res["timed_steps"], "clock_ramp_steps_before_warmup": res["ramp_steps"],
                        "parity_mode": args.dtype == "f64"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "residency": "one problem re-evaluated every step: its %.0f MB working set stays in the 256 MiB Infinity "
+                                      "Cache between steps (the contract's step); `hbm_fed` is the same step with the inputs "
+                                      "coming from HBM" % (b_alg * share / 1e6),
+                         "hbm_fed": hbm_fed,
                          "traffic_source": (traffic_src + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this "
                                             "command; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, the factor 2 being the gfx950 "
                                             "FETCH_SIZE correction of MI355X_MICROARCH.md") if traffic_src else None,
                          "algorithmic_bytes_per_step": b_alg * share,
                          "kernel": "whole evaluation (every kernel of one step: k_eval_z with its in-kernel reduction), HIP "
-                                   "events on the launch stream; the dominant kernel alone is in profiles/r03_bench_*_kernel_stats.csv"},
+                                   "events on the launch stream; the dominant kernel alone is in profiles/r04_bench_*_kernel_stats.csv"},
         }
         if second is not None:
             out["frames_variant"] = {"value": 1.0 / second["wall_per_step"], "unit": "MAP gradient iterations/s",
                                      "ms_per_step": second["wall_per_step"] * 1e3, "scaling": "strong",
                                      "device_ms_per_step": second["dev_ms_per_step"], "timed_steps": second["timed_steps"],
                                      "collective_per_step": collective["frames"]}
+        if cfg3_block is not None:
+            out["cfg3"] = cfg3_block
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, res["lr"], res["x0"], res["wts"])
         else:

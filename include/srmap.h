@@ -325,6 +325,14 @@ void srmap_comm_destroy(srmap_comm* comm);
 /* What the communicator itself reports: rank, size (ncclCommCount for RCCL), backend (1 = RCCL, 0 = host
  * callbacks).  Any out pointer may be NULL.  No reference counterpart (the reference is single-process). */
 int srmap_comm_info(srmap_comm* comm, int* rank, int* world, int* backend);
+/* Row shards: post the halo exchange of x on the communicator's side stream UNDER the tile rows that read no halo row
+ * (on != 0), or exchange first and evaluate afterwards (on == 0).  Default: on for the host-callback backend (whose
+ * callbacks block anyway), off for RCCL -- the overlapped form uses one ncclComm_t from two streams and is opt-in until
+ * it has been validated on the deployment's RCCL.  No reference counterpart. */
+int srmap_comm_set_overlap(srmap_comm* comm, int on);
+/* Which collective library the communicator runs on, as text: "rccl <ncclGetVersion> <path of the loaded librccl>" or
+ * "host callbacks" (a process may carry several librccl copies: PyTorch ships its own).  No reference counterpart. */
+int srmap_comm_describe(srmap_comm* comm, char* buf, size_t cap);
 /* ncclCommSplit: ranks passing the same color form a new communicator ordered by key; the caller states its rank
  * and size in it (RCCL backend; host-callback harnesses build the sub-communicator themselves).  Collective. */
 int srmap_comm_split(srmap_comm* comm, int color, int key, int new_rank, int new_world, srmap_comm** out);

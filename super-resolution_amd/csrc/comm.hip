@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstring>
 #include <new>
 
@@ -38,6 +39,7 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;                       // optional
   ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;     // optional (RCCL >= 2.18)
+  ncclResult_t (*GetVersion)(int*) = nullptr;                                          // optional
 };
 
 RcclApi* rccl_api(srmap_ctx* ctx) {
@@ -63,6 +65,7 @@ RcclApi* rccl_api(srmap_ctx* ctx) {
       api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
       api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
       api.CommSplit = (decltype(api.CommSplit))dlsym(api.lib, "ncclCommSplit");
+      api.GetVersion = (decltype(api.GetVersion))dlsym(api.lib, "ncclGetVersion");
       if (!ok) { dlclose(api.lib); api.lib = nullptr; }
     }
   });
@@ -96,6 +99,7 @@ struct srmap_comm {
   // row shards: the halo exchange runs on this side stream, under the tiles that read no halo row (solver.hip)
   hipStream_t side = nullptr;
   hipEvent_t ev_x = nullptr, ev_halo = nullptr;
+  int overlap = -1;  // row shards: halo exchange under the interior tile rows; -1 = backend default (srmap_comm_set_overlap)
 };
 
 namespace srmap {
@@ -110,6 +114,10 @@ int comm_side(srmap_comm* c, hipStream_t* side, hipEvent_t* ev_x, hipEvent_t* ev
   return SRMAP_OK;
 }
 
+// Overlap of the row-shard halo exchange with the interior tile rows: on by default for the host-callback backend (the
+// hook blocks there, so the two-phase launch is exercised without any concurrency), OFF by default for RCCL until it has
+// been seen running on two GPUs (the same ncclComm_t is then used from two streams) -- srmap_comm_set_overlap opts in.
+bool comm_overlap(const srmap_comm* c) { return c && (c->overlap < 0 ? c->kind == 0 : c->overlap != 0); }
 int comm_rank(const srmap_comm* c) { return c ? c->rank : 0; }
 int comm_world(const srmap_comm* c) { return c ? c->world : 1; }
 
@@ -295,6 +303,25 @@ int srmap_comm_allreduce(srmap_comm* c, void* dev_buf, size_t count, int dtype, 
 
 /* What the communicator itself reports: its rank, its size (ncclCommCount for RCCL) and its backend (1 = RCCL, 0 = host
  * callbacks).  Any out pointer may be NULL. */
+// Which collective library the communicator runs on: "rccl <ncclGetVersion> <file the symbols were resolved from>" or
+// "host callbacks".  A process may carry more than one librccl (PyTorch ships its own): this names the one in use.
+int srmap_comm_describe(srmap_comm* c, char* buf, size_t cap) {
+  if (!c || !buf || cap == 0) return SRMAP_EINVAL;
+  if (c->kind != 1) { snprintf(buf, cap, "host callbacks"); return SRMAP_OK; }
+  int ver = 0;
+  if (c->api->GetVersion) (void)c->api->GetVersion(&ver);
+  Dl_info di;
+  const char* path = (dladdr((void*)c->api->AllReduce, &di) && di.dli_fname) ? di.dli_fname : "?";
+  snprintf(buf, cap, "rccl %d %s", ver, path);
+  return SRMAP_OK;
+}
+
+int srmap_comm_set_overlap(srmap_comm* c, int on) {
+  if (!c) return SRMAP_EINVAL;
+  c->overlap = on ? 1 : 0;
+  return SRMAP_OK;
+}
+
 int srmap_comm_info(srmap_comm* c, int* rank, int* world, int* backend) {
   if (!c) return SRMAP_EINVAL;
   int w = c->world;

@@ -9,6 +9,7 @@ int comm_rank(const srmap_comm* c);
 // The communicator's side stream (non-blocking) and its two events, created on first use.
 int comm_side(srmap_comm* c, hipStream_t* side, hipEvent_t* ev_x, hipEvent_t* ev_halo);
 int comm_world(const srmap_comm* c);
+bool comm_overlap(const srmap_comm* c);  // row shards: run the halo exchange under the interior tile rows
 // In-place all-reduce of a device buffer (op 0 = sum, 1 = max), enqueued on `st` (RCCL) or staged through the
 // caller's host callback (synchronises `st`).  No-op for world 1 / null communicator.
 int comm_allreduce(srmap_comm* c, void* dev, size_t count, int dtype, int op, hipStream_t st);

@@ -52,43 +52,9 @@
 
 
 #include "ztile_dev.hpp"
-#include "zmarch_dev.hpp"
 
-// Build-time switches of the measurement builds (tools/exp_build.sh); the product build defines none of them.
+// Build-time switch of the measurement builds (tools/exp_build.sh); the product build does not define it.
 //   SRMAP_ZT_ONLY_CFG2  instantiate only k_eval_z<double, 4, 3, BTV, 3> (seconds instead of minutes per variant)
-#ifndef SRMAP_EXP_GSTORE
-#define SRMAP_EXP_GSTORE 0   // 0: non-temporal g stores, 1: plain (write-back) stores
-#endif
-#ifndef SRMAP_EXP_GRID1D
-#define SRMAP_EXP_GRID1D 0   // 1: one-dimensional grid, exactly as many border blocks as the border frame needs
-#endif
-#ifndef SRMAP_EXP_MARCH
-#define SRMAP_EXP_MARCH 0    // n > 0: the marching kernel with bands of n steps (8 n rows)
-#endif
-#ifndef SRMAP_EXP_MPF
-#define SRMAP_EXP_MPF 2      // marching kernel, next step's requests: 0 = all after phase 2, 1 = all before it, 2 = x before, observations after
-#endif
-#ifndef SRMAP_EXP_MLAUNDER
-#define SRMAP_EXP_MLAUNDER 1
-#endif
-#ifndef SRMAP_EXP_MUNROLL
-#define SRMAP_EXP_MUNROLL 0   // marching kernel: > 0 = that many steps, unrolled at compile time (must equal SRMAP_EXP_MARCH)
-#endif
-#ifndef SRMAP_EXP_MREARG
-#define SRMAP_EXP_MREARG 1
-#endif
-#ifndef SRMAP_EXP_MW
-#define SRMAP_EXP_MW 0
-#endif
-#ifndef SRMAP_EXP_NOEDGE
-#define SRMAP_EXP_NOEDGE 0   // 1: TIMING ONLY -- the marching kernel without its masked edge paths (wrong at the image border)
-#endif
-#ifndef SRMAP_EXP_MFW
-#define SRMAP_EXP_MFW 0
-#endif
-#ifndef SRMAP_EXP_PRIO2
-#define SRMAP_EXP_PRIO2 0    // n > 0: s_setprio n from the second barrier on
-#endif
 
 namespace srmap {
 
@@ -129,44 +95,26 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin in launch order and every XCD has its
   // own L2; with the tile ROW on blockIdx.x and launch index n -> row band (n mod 8) the workgroups an XCD runs at
   // the same time are vertical neighbours and share their x halo rows in that L2.  Bijective for any row count.
-#if SRMAP_EXP_GRID1D
-  const int vgx = A.g1_gx, vnbb = A.g1_nbb;
-  const int n1 = blockIdx.x;
-  const bool is_border = n1 < vnbb;
-  const int t1 = n1 - vnbb;
-  const int by = is_border ? 0 : (int)__umulhi((unsigned)t1, (unsigned)A.g1_magic);
-  const int vbx = is_border ? n1 : t1 - by * vgx;
-  const int nby_t = A.g1_gyt;
-  const bool last_block = n1 == (int)gridDim.x - 1 && blockIdx.z == gridDim.z - 1;
-#else
-  const int vgx = gridDim.x, vnbb = A.nby * gridDim.x;
-  const bool is_border = (int)blockIdx.y < A.nby;
-  const int by = blockIdx.y - A.nby, nby_t = gridDim.y - A.nby;
-  const int vbx = blockIdx.x;
-  const bool last_block = blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1;
-#endif
-  if (is_border) {  // border blocks come first in dispatch order (uniform branch)
+  if ((int)blockIdx.y < A.nby) {  // border blocks come first in dispatch order (uniform branch)
     if (A.sel_mode == 1) return;
-#if SRMAP_EXP_GRID1D
-    const int bidx = vbx;
-#else
     const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
-#endif
     const BorderArgs<T>& Bd = *A.bd;
-    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, vnbb);
+    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
     else if (threadIdx.x == 0) {
-      put_partial<WD>(A, (size_t)A.n_tile_partials + (size_t)blockIdx.z * vnbb + bidx, 0.0, 0.0);
+      const int nbb = A.nby * gridDim.x;
+      put_partial<WD>(A, (size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx, 0.0, 0.0);
     }
     return;
   }
-  int tby = by, tbx = vbx;
+  const int by = blockIdx.y - A.nby, nby_t = gridDim.y - A.nby;
+  int tby = by, tbx = blockIdx.x;
   {
     // ... with launch indices 1 and last swapped: the bottom tile row (masked edge path in every column, the slowest
     // tiles) would otherwise be the LAST workgroup of every tile column -- of the last column too, where it sets the
     // end of the launch (and carries the in-kernel reduction).  It is dispatched second now, like the top row first.
-    const int n0 = vbx, last = vgx - 1;
+    const int n0 = blockIdx.x, last = (int)gridDim.x - 1;
     const int n = (last > 1) ? (n0 == 1 ? last : (n0 == last ? 1 : n0)) : n0;
-    const int q = vgx >> 3, rem = vgx & 7, bnd = n & 7;
+    const int q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
     tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
     // tile columns in the order first, last, second, ...: the masked edge columns (longest-lived tiles) are not the
     // launch's last generation
@@ -352,7 +300,6 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   __syncthreads();
 
   // ---------------- phase 2 ----------------
-  if (SRMAP_EXP_PRIO2 > 0) __builtin_amdgcn_s_setprio(SRMAP_EXP_PRIO2);
   T dreg[S];  // WD: the search direction at this thread's pixels (g.d is produced with g)
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) dreg[pc] = T(0);
@@ -383,10 +330,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   if (A.g != nullptr && gr < A.H && gc0 < A.W) {
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      if (SRMAP_EXP_GSTORE == 0) __builtin_nontemporal_store(acc[pc], &dst[pc]);  // written once, not re-read here
-      else dst[pc] = acc[pc];
-    }
+    for (int pc = 0; pc < S; ++pc) __builtin_nontemporal_store(acc[pc], &dst[pc]);  // written once, not re-read here
   }
 
   // ---------------- cost partial of this workgroup ----------------
@@ -404,496 +348,16 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
       double c = 0.0, d = 0.0;
 #pragma unroll
       for (int i = 0; i < C::NW; ++i) { c += red[0][i]; if (WD) d += red[1][i]; }
-      const size_t b = ((size_t)blockIdx.z * nby_t + by) * vgx + vbx;
-      put_partial<WD>(A, b, c, d);
-    }
-    // in-kernel finish: the last workgroup of the grid gathers the granules of the evaluation
-    if (A.mfinish && last_block) {
-      __syncthreads();
-      finish_block<WD, C::NT>(A, &red[0][0]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Marching tile kernel.  Same arithmetic, same LDS footprint and the same two co-resident
-// 8-wave workgroups per CU as k_eval_z, but a workgroup owns a BAND of 8 * A.nsteps rows and walks down it eight rows
-// per step with the x tile, zh and 2*lambda*w*r kept in LDS as rings of rows (zmarch_dev.hpp):
-//   * the zh / 2*lambda*w*r halo rows of a tile (4 row passes per 8 rows in k_eval_z) are evaluated once per BAND:
-//     a step's phase 1 evaluates zh one row AHEAD of the rows whose gradient its phase 2 finishes (rows R+1 .. R+8;
-//     rows R-1, R come from the previous step), 2*lambda*w*r for the rows R .. R+7 (rows R-2, R-1 likewise);
-//   * x rows are requested once per band (8 new rows per step instead of 13 per tile); the NEXT step's x rows,
-//     observations and weights are requested before phase 2 and land under it (registers; nothing is carried around
-//     the loop: they are staged at the bottom of the same iteration, and the g stores follow the staging so that only
-//     loads are outstanding where the wait stands);
-//   * kernel-argument fetch, workgroup launch and the input latency of a tile are paid once per band, and a launch has
-//     one or two generations of workgroups instead of four.
-// Step: [stage] barrier A | phase 1 | barrier B | requests of step s+1 | phase 2 | barrier C | stage s+1, g store.
-template <typename T, int S, int B, int REGK, int R, bool WD, int NS>
-__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : (S == 2 ? 6 : 4))) void k_eval_m(
-    ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> Akern) {
-  using C = ZCfg<T, S, B, REGK, R>;
-  // The argument block is read through the kernarg pointer, made opaque again at the head of every phase (M_REARG):
-  // a field is fetched (scalar load, scalar cache) where a phase uses it instead of being held in an SGPR from the first
-  // use to the last -- across the steps of a band that cost ~50 spilled SGPRs (v_writelane / v_readlane: VALU issues).
-  typedef const ZArgs<T, B, C::NP> __attribute__((address_space(4))) CArgs;
-  CArgs* ap = (CArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-#if SRMAP_EXP_MREARG
-#define A (*ap)
-#define M_PWT T pwt[C::NP]; _Pragma("unroll") for (int i_ = 0; i_ < C::NP; ++i_) pwt[i_] = A.powtab[i_]
-#else
-#define A Akern
-#define M_PWT const T (&pwt)[C::NP] = Akern.powtab
-  (void)ap;
-#endif
-#if SRMAP_EXP_MREARG
-#define M_REARG asm volatile("" : "+s"(ap))
-#else
-#define M_REARG
-#endif
-  constexpr int HB = C::HB, NV = C::NV, RU = C::RU, WIN = C::WIN, TH = C::TH;
-  constexpr int XRN = C::XR, ZRN = C::ZR > 0 ? C::ZR : 1, CRN = C::CRR > 0 ? C::CRR : 1;
-  constexpr int ZSH = (B > 1) ? HB : 0;  // zh rows run ZSH rows ahead of the gradient rows
-  constexpr int kBorderLds = (int)((16 * sizeof(int2) + kBorderTabEntries * sizeof(ZEntry) + 16 * sizeof(double) + sizeof(T) - 1) / sizeof(T));
-  __shared__ T xs[C::XS_ELEMS > kBorderLds ? C::XS_ELEMS : kBorderLds];
-  __shared__ T zs[C::ZS_ELEMS > 0 ? C::ZS_ELEMS : 1];
-  __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
-  __shared__ double red[2][C::NW];
-  __shared__ T whs[(C::RU > 0 ? C::RU : 1) * S * C::CW];
-  {
-    const T* a_x = A.x; const T* a_y = A.y; const T* a_w = A.w; T* a_g = A.g;
-    const int a_W = A.W, a_H = A.H, a_wl = A.wl, a_hl = A.hl, a_nby = A.nby, a_E = A.E, a_terms = A.terms, a_obsC = A.obs_C;
-    const int a_cr0 = A.cr0, a_cr1 = A.cr1, a_rr0 = A.rr0, a_rr1 = A.rr1, a_ns = A.nsteps;
-    const unsigned a_gx = gridDim.x, a_gy = gridDim.y;
-    asm volatile("" ::"s"(a_x), "s"(a_y), "s"(a_w), "s"(a_g), "s"(a_W), "s"(a_H), "s"(a_wl), "s"(a_hl), "s"(a_nby), "s"(a_E),
-                 "s"(a_terms), "s"(a_obsC), "s"(a_cr0), "s"(a_cr1), "s"(a_rr0), "s"(a_rr1), "s"(a_ns), "s"(a_gx), "s"(a_gy));
-  }
-  const int tid = threadIdx.x;
-  int lane = tid & 63;
-  int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int vnbb = A.nby * gridDim.x;
-  if ((int)blockIdx.y < A.nby) {  // border blocks come first in dispatch order (uniform branch)
-    const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
-    const BorderArgs<T>& Bd = *Akern.bd;
-    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(Akern, Bd, bidx, blockIdx.z, xs, vnbb);
-    else if (threadIdx.x == 0) put_partial<WD>(A, (size_t)A.n_tile_partials + (size_t)blockIdx.z * vnbb + bidx, 0.0, 0.0);
-    return;
-  }
-  const int by = blockIdx.y - A.nby, nby_t = gridDim.y - A.nby;
-  int tband, tbx;
-  {
-    // dispatch order as in k_eval_z: launch index n -> row band of the image (n mod 8: the bands an XCD runs together
-    // are vertical neighbours), bottom band second; tile columns first, last, second, ...
-    const int vgx = gridDim.x;
-    const int n0 = blockIdx.x, last = vgx - 1;
-    const int n = (last > 1) ? (n0 == 1 ? last : (n0 == last ? 1 : n0)) : n0;
-    const int q = vgx >> 3, rem = vgx & 7, bnd = n & 7;
-    tband = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
-    tbx = (by == 0) ? 0 : (by == 1 ? nby_t - 1 : by - 1);
-  }
-  const int nsteps = NS > 0 ? NS : A.nsteps;  // NS > 0: the steps are unrolled (straight-line code)
-  const int R0 = tband * (TH * nsteps), CJ0 = tbx * C::CW, C0 = CJ0 * S;
-  const int Rend = R0 + TH * nsteps;  // first row of the next band
-  int nst = (A.H - R0 + TH - 1) / TH;
-  nst = nst < nsteps ? nst : nsteps;
-  const int ch = blockIdx.z;
-  const size_t N = (size_t)A.W * A.H;
-  const size_t nl = (size_t)A.wl * A.hl;
-  const T* xplane = A.x + (size_t)ch * N;
-  int gc0 = C0 + S * lane;
-  const bool want_data = (A.terms & SRMAP_TERM_DATA) != 0;
-  const bool want_reg_t = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0;
-  const T* ybase = A.y + (size_t)ch * nl;
-  const T* wplane = (want_reg_t && A.w) ? A.w + (size_t)ch * N : nullptr;
-  constexpr int EXTRA = C::XC - C::CW;
-  // tiles whose residuals can touch LR row / column 0 or leave the LR image take the masked path (uniform per step)
-  const int rm = A.E + HB + 1, cm = (A.E + HB + S) / S + 1;
-  const bool col_edge = (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl) || A.cr0 > 0 || A.cr1 < A.H;
-  const bool reg_halo_on = want_reg_t && A.g != nullptr && RU > 0;
-  const bool col_wave = reg_halo_on && (wv == 4 || wv == 5);
-  double cost_data = 0.0, cost_reg = 0.0, gd = 0.0;
-
-  // ---------------- requests of step 0: the whole x window, observations, IRLS weights ----------------
-  constexpr int ARI = (C::XR + C::NW - 1) / C::NW;
-  T ypre[NV], wreg[S];
-  T wcolv = T(1);
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
-  {
-    T va[ARI][S], vb[ARI][S], ma[ARI], mb[ARI];
-#pragma unroll
-    for (int it = 0; it < ARI; ++it) {
-      const int row = wv + it * C::NW;
-      const int grr = R0 - C::HU + row;
-      const bool row_in = row < C::XR && (unsigned)grr < (unsigned)A.H;
-      const int gca = CJ0 - C::XCL + lane, gcb = gca + C::CW;
-      const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
-      const bool inb = row_in && lane < EXTRA && (unsigned)gcb < (unsigned)A.wl;
-      const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
-      const T* sb = xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
-      ma[it] = ina ? Pre<T>::up(T(1)) : T(0);
-      mb[it] = inb ? Pre<T>::up(T(1)) : T(0);
-    }
-    const bool edge0 = SRMAP_EXP_NOEDGE ? false : (col_edge || (R0 - rm < 0) || (R0 + TH + rm > A.H));
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ypre[v] = T(0);
-    if (want_data) z_prefetch_m<T, S, B, C>(A, R0 + wv + ZSH, CJ0, lane, edge0, ybase, ypre);
-    // the band's first zh rows (-HB .. ZSH-1) are extra row passes of the first waves: their observations
-    T ypre2[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ypre2[v] = T(0);
-    const bool z_extra = want_data && B > 1 && wv < ZSH + HB;
-    if (z_extra) z_prefetch_m<T, S, B, C>(A, R0 + wv - HB, CJ0, lane, edge0, ybase, ypre2);
-    const bool want_reg0 = want_reg_t && R0 >= A.rr0 && R0 < A.rr1;
-    if (SRMAP_EXP_MW == 0 && want_reg0 && wplane != nullptr) {
-      if (R0 + wv < A.H && gc0 < A.W) {
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)(R0 + wv) * A.W + gc0 + pc];
-      }
-      if (col_wave && lane < TH + RU) {
-        const int hgr = R0 + lane - RU, hgc = C0 - (wv == 4 ? 1 : 2);
-        if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
-      }
-    }
-    const int hrow = -(wv - 1);  // wave 2 -> -1, wave 3 -> -2
-    const bool has_reg_halo = reg_halo_on && want_reg0 && wv >= 2 && wv < 2 + RU;
-    T whalo[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) whalo[pc] = T(1);
-    if (has_reg_halo && wplane != nullptr && R0 + hrow >= 0 && gc0 < A.W) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) whalo[pc] = wplane[(size_t)(R0 + hrow) * A.W + gc0 + pc];
-    }
-    // ---- x window -> LDS (ring offset 0: slot = row index); the weights of the halo-row passes wait in LDS ----
-#pragma unroll
-    for (int it = 0; it < ARI; ++it) {
-      const int row = wv + it * C::NW;
-      if (row < C::XR) {
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + lane] = va[it][pc] * ma[it];
-        if (lane < EXTRA) {
-#pragma unroll
-          for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + lane] = vb[it][pc] * mb[it];
-        }
-      }
-    }
-    if (has_reg_halo) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) whs[((wv - 2) * S + pc) * C::CW + lane] = whalo[pc];
-    }
-    __syncthreads();  // barrier A of step 0
-    // ---- the band's extra zh rows (step 0 only) ----
-    if (z_extra) {
-      const int rel = wv - HB;  // -HB .. ZSH-1
-      int xb[B];
-#pragma unroll
-      for (int a = 0; a < B; ++a) xb[a] = (rel + a - HB + C::HU) * C::XROW;
-      const int zb = (rel + HB) * C::ZROW;
-      T mkz[S], dummy[S];
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) mkz[pc] = (R0 + rel < A.H && gc0 + pc < A.W) ? T(1) : T(0);
-      const bool cnt = rel >= 0;
-      if (edge0) z_row_m<T, S, B, C, true>(A, xs, zs, R0 + rel, xb, zb, CJ0, lane, ybase, ypre2, cnt, mkz, dummy, cost_data);
-      else z_row_m<T, S, B, C, false>(A, xs, zs, R0 + rel, xb, zb, CJ0, lane, ybase, ypre2, cnt, mkz, dummy, cost_data);
-    }
-    // ---- the band's 2*lambda*w*r halo rows (step 0 only) ----
-    if (has_reg_halo) {
-      M_PWT;
-      T dacc[S], whl[S];
-      double dc = 0.0;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) whl[pc] = whs[((wv - 2) * S + pc) * C::CW + lane];
-      int xb[WIN + 1];
-#pragma unroll
-      for (int i = 0; i <= WIN; ++i) xb[i] = (hrow + i + C::HU) * C::XROW;
-      const int cb = (hrow + RU) * C::CROW;
-      if (!SRMAP_EXP_NOEDGE && (C0 + C::TW + WIN > A.W || R0 + WIN > A.H))
-        reg_row_m<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whl, xb, cb, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, pwt, A.pwsum, false);
-      else
-        reg_row_m<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whl, xb, cb, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, pwt, A.pwsum, false);
-    }
-  }
-
-  int xb0 = 0, zb0 = 0, cb0 = 0;  // ring offsets: slot of tile-relative row rel = (b0 + rel + halo) mod ring size
-#pragma unroll
-  for (int s = 0; s < (NS > 0 ? NS : nst); ++s) {
-    if (NS > 0 && s >= nst) break;  // uniform: the image ends inside the band
-#if SRMAP_EXP_MFW
-    // firewall between the steps: nothing but the named state crosses it in a form the optimiser can reuse
-    asm volatile("" : "+s"(wv), "+s"(xplane), "+s"(ybase), "+s"(wplane), "+s"(xb0), "+s"(zb0), "+s"(cb0));
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#if SRMAP_EXP_MLAUNDER
-    asm volatile("" : "+v"(lane)); gc0 = C0 + S * lane;  // lane-derived address arithmetic is formed again per phase, not carried
-#endif
-    M_REARG;
-    const int Rs = R0 + TH * s;
-    const int gr = Rs + wv;  // the row whose gradient this wave finishes in this step
-    const bool edge = SRMAP_EXP_NOEDGE ? false : (col_edge || (Rs - rm < 0) || (Rs + TH + rm > A.H));
-    const bool want_reg = want_reg_t && Rs >= A.rr0 && Rs < A.rr1;
-    const bool more = s + 1 < nst;
-    // IRLS weights of this step's rows (SRMAP_EXP_MW 1: requested here and consumed at the end of the regulariser pass;
-    // 0: requested with the step's other inputs, a step ahead)
-    const int r_lo = (s == 0) ? -RU : 0;  // step 0 evaluates the left halo columns of the band's halo rows too
-    if (SRMAP_EXP_MW != 0) {  // step-local: nothing of them survives into the next step
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
-      wcolv = T(1);
-    }
-    if (SRMAP_EXP_MW == 1 && want_reg && wplane != nullptr) {
-      if (gr < A.H && gc0 < A.W) {
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)gr * A.W + gc0 + pc];
-      }
-      if (col_wave && lane < TH - r_lo) {
-        const int hgr = Rs + lane + r_lo, hgc = C0 - (wv == 4 ? 1 : 2);
-        if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
-      }
-    }
-    // ---------------- phase 1: data term, zh row gr + ZSH ----------------
-    T acc[S], zown[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) { acc[j] = T(0); zown[j] = T(0); }
-    if (want_data) {
-      const int rel = wv + ZSH;
-      int xb[B];
-#pragma unroll
-      for (int a = 0; a < B; ++a) xb[a] = ring_slot<XRN>(xb0, rel + a - HB + C::HU) * C::XROW;
-      const int zb = (B > 1) ? ring_slot<ZRN>(zb0, rel + HB) * C::ZROW : 0;
-      T mkz[S];
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) mkz[pc] = (Rs + rel < A.H && gc0 + pc < A.W) ? T(1) : T(0);
-      const bool cnt = Rs + rel < Rend;  // the band's last step runs one row into the next band
-      if (edge) z_row_m<T, S, B, C, true>(A, xs, zs, Rs + rel, xb, zb, CJ0, lane, ybase, ypre, cnt, mkz, zown, cost_data);
-      else z_row_m<T, S, B, C, false>(A, xs, zs, Rs + rel, xb, zb, CJ0, lane, ybase, ypre, cnt, mkz, zown, cost_data);
-    }
-#if SRMAP_EXP_MLAUNDER
-    asm volatile("" : "+v"(lane)); gc0 = C0 + S * lane;  // lane-derived address arithmetic is formed again per phase, not carried
-#endif
-    M_REARG;
-    // ---------------- phase 1: regulariser, row gr ----------------
-    if (SRMAP_EXP_MW == 2) __builtin_amdgcn_sched_barrier(0);  // the weights are requested HERE, not above the data term
-    if (SRMAP_EXP_MW == 2 && want_reg && wplane != nullptr) {
-      if (gr < A.H && gc0 < A.W) {
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)gr * A.W + gc0 + pc];
-      }
-      if (col_wave && lane < TH - r_lo) {
-        const int hgr = Rs + lane + r_lo, hgc = C0 - (wv == 4 ? 1 : 2);
-        if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
-      }
-    }
-    if (SRMAP_EXP_MW == 2) __builtin_amdgcn_sched_barrier(0);
-    if (want_reg) {
-      M_PWT;
-      const bool reg_border = SRMAP_EXP_NOEDGE ? false : ((Rs + TH + WIN > A.H) || (C0 + C::TW + WIN > A.W));
-      const bool cost_row = gr >= A.cr0 && gr < A.cr1;
-      int xb[WIN + 1];
-#pragma unroll
-      for (int i = 0; i <= WIN; ++i) xb[i] = ring_slot<XRN>(xb0, wv + i + C::HU) * C::XROW;
-      const int cb = ring_slot<CRN>(cb0, wv + RU) * C::CROW;
-      if (reg_border)
-        reg_row_m<T, S, REGK, R, C, true, true>(acc, cost_reg, xs, cs, wreg, xb, cb, lane, gr, gc0, A.W, A.H, A.lambda, pwt, A.pwsum, cost_row);
-      else
-        reg_row_m<T, S, REGK, R, C, false, true>(acc, cost_reg, xs, cs, wreg, xb, cb, lane, gr, gc0, A.W, A.H, A.lambda, pwt, A.pwsum, cost_row);
-      // left halo columns -1 .. -RU of the step's rows (step 0: of the halo rows too), one row per lane, one column per wave
-      if (col_wave && lane < TH - r_lo) {
-        const T wcol = wcolv;
-        const int rel = lane + r_lo;
-        int xo[WIN + 1];
-#pragma unroll
-        for (int i = 0; i <= WIN; ++i) xo[i] = ring_slot<XRN>(xb0, rel + i + C::HU) * C::XROW;
-        const int co = ring_slot<CRN>(cb0, rel + RU) * C::CROW;
-        const int hgc = C0 - (wv == 4 ? 1 : 2);
-        if (!SRMAP_EXP_NOEDGE && (reg_border || Rs + r_lo + WIN > A.H)) {
-          if (RU >= 1 && wv == 4) reg_halo_col_m<T, S, REGK, R, C, -1, true>(xs, cs, wcol, xo, co, Rs + rel, hgc, A.W, A.H, A.lambda, pwt);
-          if (RU >= 2 && wv == 5) reg_halo_col_m<T, S, REGK, R, C, -2, true>(xs, cs, wcol, xo, co, Rs + rel, hgc, A.W, A.H, A.lambda, pwt);
-        } else {
-          if (RU >= 1 && wv == 4) reg_halo_col_m<T, S, REGK, R, C, -1, false>(xs, cs, wcol, xo, co, Rs + rel, hgc, A.W, A.H, A.lambda, pwt);
-          if (RU >= 2 && wv == 5) reg_halo_col_m<T, S, REGK, R, C, -2, false>(xs, cs, wcol, xo, co, Rs + rel, hgc, A.W, A.H, A.lambda, pwt);
-        }
-      }
-    }
-    __syncthreads();  // barrier B
-
-#if SRMAP_EXP_MLAUNDER
-    asm volatile("" : "+v"(lane)); gc0 = C0 + S * lane;  // lane-derived address arithmetic is formed again per phase, not carried
-#endif
-    M_REARG;
-    // ---------------- requests of step s + 1 ----------------
-    // x rows before phase 2 (they land under it and are staged right behind it); the observations behind phase 2's
-    // arithmetic (staging, the g stores and the head of the next data pass cover them): carried through phase 2 the
-    // allocator spilled them straight after the load, i.e. waited for them
-    T va[S], vb1 = T(0);
-    const int Rn = Rs + TH;
-    const bool edge_n = SRMAP_EXP_NOEDGE ? false : (col_edge || (Rn - rm < 0) || (Rn + TH + rm > A.H));
-    if (more && SRMAP_EXP_MPF >= 1) {
-      {
-        const int grr = Rn + C::HD + wv;  // new x rows of the next step: its tile rows HD .. HD + 7
-        const bool row_in = (unsigned)grr < (unsigned)A.H;
-        const int gca = CJ0 - C::XCL + lane;
-        const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
-        const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) va[pc] = sa[pc];
-        // the EXTRA halo cells at the right end of the row: one element per lane
-        const int gcb = CJ0 - C::XCL + C::CW + lane / S;
-        const bool inb = row_in && lane < EXTRA * S && (unsigned)gcb < (unsigned)A.wl;
-        vb1 = xplane[inb ? (size_t)grr * A.W + (size_t)gcb * S + (lane % S) : (size_t)0];
-      }
-    }
-    if (more && SRMAP_EXP_MPF == 1) {
-      if (want_data) z_prefetch_m<T, S, B, C>(A, Rn + wv + ZSH, CJ0, lane, edge_n, ybase, ypre);
-      if (SRMAP_EXP_MW == 0) {
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
-        wcolv = T(1);
-        if (want_reg_t && Rn >= A.rr0 && Rn < A.rr1 && wplane != nullptr) {
-          if (Rn + wv < A.H && gc0 < A.W) {
-#pragma unroll
-            for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)(Rn + wv) * A.W + gc0 + pc];
-          }
-          if (col_wave && lane < TH) {
-            const int hgr = Rn + lane, hgc = C0 - (wv == 4 ? 1 : 2);
-            if (hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
-          }
-        }
-      }
-    }
-#if SRMAP_EXP_MLAUNDER
-    asm volatile("" : "+v"(lane)); gc0 = C0 + S * lane;  // lane-derived address arithmetic is formed again per phase, not carried
-#endif
-    M_REARG;
-    // ---------------- phase 2: row gr ----------------
-    T dreg[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) dreg[pc] = T(0);
-    if (WD && gr < A.H && gc0 < A.W && gr >= A.cr0 && gr < A.cr1) {
-      const T* dp = A.dvec + (size_t)ch * N + (size_t)gr * A.W + gc0;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) dreg[pc] = dp[pc];
-    }
-    if (want_data && A.g != nullptr) {
-      const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
-      int zb[B];
-#pragma unroll
-      for (int a = 0; a < B; ++a) zb[a] = (B > 1) ? ring_slot<ZRN>(zb0, wv + a) * C::ZROW : 0;  // rows gr - HB + a
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) {
-        T zz;
-        if (B == 1) {
-          zz = zown[pc];
-        } else {
-          zz = T(0);
-#pragma unroll
-          for (int a = 0; a < B; ++a) zz += k1_tap<B>(A, a) * zs[zb[a] + pc * C::CW + lane];
-        }
-        acc[pc] += sc * zz;
-      }
-    }
-    if (want_reg && A.g != nullptr && RU > 0) {
-      M_PWT;
-      int xb[RU + 1], cb[RU + 1];
-#pragma unroll
-      for (int i = 0; i <= RU; ++i) {
-        xb[i] = ring_slot<XRN>(xb0, wv - i + C::HU) * C::XROW;
-        cb[i] = ring_slot<CRN>(cb0, wv - i + RU) * C::CROW;
-      }
-      reg_pass2_m<T, S, REGK, R, C>(acc, xs, cs, xb, cb, lane, pwt);
-    }
-    if (WD) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) gd += (double)acc[pc] * (double)dreg[pc];
-    }
-    // ---------------- next step's inputs -> LDS, then the g stores ----------------
-#if SRMAP_EXP_MLAUNDER
-    asm volatile("" : "+v"(lane)); gc0 = C0 + S * lane;  // lane-derived address arithmetic is formed again per phase, not carried
-#endif
-    M_REARG;
-    if (more && SRMAP_EXP_MPF == 0) {
-      {
-        const int grr = Rn + C::HD + wv;  // new x rows of the next step: its tile rows HD .. HD + 7
-        const bool row_in = (unsigned)grr < (unsigned)A.H;
-        const int gca = CJ0 - C::XCL + lane;
-        const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
-        const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) va[pc] = sa[pc];
-        // the EXTRA halo cells at the right end of the row: one element per lane
-        const int gcb = CJ0 - C::XCL + C::CW + lane / S;
-        const bool inb = row_in && lane < EXTRA * S && (unsigned)gcb < (unsigned)A.wl;
-        vb1 = xplane[inb ? (size_t)grr * A.W + (size_t)gcb * S + (lane % S) : (size_t)0];
-      }
-    }
-    if (more && SRMAP_EXP_MPF != 1) {
-      if (want_data) z_prefetch_m<T, S, B, C>(A, Rn + wv + ZSH, CJ0, lane, edge_n, ybase, ypre);
-      if (SRMAP_EXP_MW == 0) {
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
-        wcolv = T(1);
-        if (want_reg_t && Rn >= A.rr0 && Rn < A.rr1 && wplane != nullptr) {
-          if (Rn + wv < A.H && gc0 < A.W) {
-#pragma unroll
-            for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)(Rn + wv) * A.W + gc0 + pc];
-          }
-          if (col_wave && lane < TH) {
-            const int hgr = Rn + lane, hgc = C0 - (wv == 4 ? 1 : 2);
-            if (hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
-          }
-        }
-      }
-    }
-    if (more) {
-      __syncthreads();  // barrier C: every wave has finished reading the rows the new ones replace
-      xb0 = ring_slot<XRN>(xb0, TH % XRN);
-      zb0 = ring_slot<ZRN>(zb0, TH % ZRN);
-      cb0 = ring_slot<CRN>(cb0, TH % CRN);
-      const int xrow = ring_slot<XRN>(xb0, C::HD + wv + C::HU) * C::XROW;
-      {
-        // scale 2^Q inside the image, 0 outside (the predicates of the requests, formed again: two registers less)
-        const int grr = Rs + TH + C::HD + wv;
-        const bool row_in = (unsigned)grr < (unsigned)A.H;
-        const T ma = (row_in && (unsigned)(CJ0 - C::XCL + lane) < (unsigned)A.wl) ? Pre<T>::up(T(1)) : T(0);
-        const T mb = (row_in && (unsigned)(CJ0 - C::XCL + C::CW + lane / S) < (unsigned)A.wl) ? Pre<T>::up(T(1)) : T(0);
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) xs[xrow + pc * C::XC + lane] = va[pc] * ma;
-        if (lane < EXTRA * S) xs[xrow + (lane % S) * C::XC + C::CW + lane / S] = vb1 * mb;
-      }
-    }
-    if (A.g != nullptr && gr < A.H && gc0 < A.W) {
-      T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) __builtin_nontemporal_store(acc[pc], &dst[pc]);  // written once, not re-read here
-    }
-    if (more) __syncthreads();  // barrier A of step s + 1
-  }
-
-  // ---------------- cost partial of this workgroup ----------------
-  {
-    if (WD) gd = wave_sum_d(gd);
-    const double cw = wave_sum_d((double)(S * S) * cost_data + cost_reg);
-    if (lane == 0) { red[0][wv] = cw; if (WD) red[1][wv] = gd; }
-    __syncthreads();
-    if (tid == 0) {
-      double c = 0.0, d = 0.0;
-#pragma unroll
-      for (int i = 0; i < C::NW; ++i) { c += red[0][i]; if (WD) d += red[1][i]; }
       const size_t b = ((size_t)blockIdx.z * nby_t + by) * gridDim.x + blockIdx.x;
       put_partial<WD>(A, b, c, d);
     }
+    // in-kernel finish: the last workgroup of the grid gathers the granules of the evaluation
     if (A.mfinish && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) {
       __syncthreads();
       finish_block<WD, C::NT>(A, &red[0][0]);
     }
   }
 }
-#undef A
-#undef M_PWT
-#undef M_REARG
 
 // After the tile kernel: subtract the border corrections from g and reduce every cost partial of the evaluation
 // in index order (deterministic).  Block 0 reduces; all blocks apply corrections.
@@ -1262,12 +726,6 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
         if (i + j > 0) A.pwsum += A.powtab[i + j];
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
-  // marching kernel: a workgroup walks a band of nsteps tile rows (not for sub-pixel plans / row shards under a halo exchange)
-  A.nsteps = 0;
-  if (SRMAP_EXP_MARCH > 0 && !z.subpix && p->ov_hook == nullptr) {
-    A.nsteps = SRMAP_EXP_MARCH;
-    grid.x = (grid.x + A.nsteps - 1) / A.nsteps;
-  }
   const int n_tile_partials = (int)(grid.x * grid.y * grid.z);
   // border blocks: whole rows of the grid in front of the tiles
   A.bd = (const BorderArgs<T>*)z.d_bd;
@@ -1279,16 +737,6 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     nbb = A.nby * (int)grid.x;
     grid.y += A.nby;
   }
-#if SRMAP_EXP_GRID1D
-  {
-    const int gx = (int)grid.x, gyt = (int)grid.y - A.nby;
-    const int need = A.nby > 0 ? (z.n_ring + C::NT - 1) / C::NT : 0;
-    A.g1_gx = gx; A.g1_gyt = gyt; A.g1_nbb = need;
-    A.g1_magic = (int)(unsigned)((0x100000000ull + (unsigned long long)gx - 1) / (unsigned long long)gx);
-    nbb = need;
-    grid = dim3((unsigned)(need + gx * gyt), 1, grid.z);
-  }
-#endif
   A.rbuf = nullptr; A.spw = z.d_spw; A.Dr = z.Dr;
   A.mfinish = mfin.on ? 1 : 0;
   A.n_partials = n_tile_partials + nbb * (int)grid.z;
@@ -1307,11 +755,6 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), 0, st, A);
   } else {
     auto launch = [&]() {
-      if (A.nsteps > 0) {
-        if (dvec != nullptr) hipLaunchKernelGGL((k_eval_m<T, S, B, REGK, R, true, SRMAP_EXP_MUNROLL>), grid, dim3(C::NT), 0, st, A);
-        else hipLaunchKernelGGL((k_eval_m<T, S, B, REGK, R, false, SRMAP_EXP_MUNROLL>), grid, dim3(C::NT), 0, st, A);
-        return;
-      }
       if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), 0, st, A);
       else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
     };

@@ -150,19 +150,55 @@ __device__ __forceinline__ void fin_tag(const Fin& fin) {
   }
 }
 
+// Cache policy of the n-vector passes.  What an EVALUATION touches -- x, the observations, the IRLS weights, the
+// direction d (its g.d), g -- and the line search's base point xk (read for every trial point) should survive in the
+// 256 MiB Infinity Cache from one evaluation to the next: 201 MB at cfg2.  The vectors only the CG update itself
+// streams (dn / dk, the previous gradient gp) are read and written NON-TEMPORAL so that they do not displace that set
+// (profiles/r03_solve_trace.txt: the evaluation ran 51.7 us inside the solve against 39.9 us alone).
+// V consecutive elements as one request (V * sizeof(T) <= 16 bytes, p aligned to it); STREAM = non-temporal
+template <typename T, int V, bool STREAM>
+__device__ __forceinline__ void ldv(const T* __restrict__ p, T (&out)[V]) {
+  typedef T __attribute__((ext_vector_type(V))) VT;
+  if (V == 1) { out[0] = STREAM ? __builtin_nontemporal_load(p) : *p; return; }
+  const VT v = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const VT*>(p)) : *reinterpret_cast<const VT*>(p);
+#pragma unroll
+  for (int q = 0; q < V; ++q) out[q] = v[q];
+}
+template <typename T, int V, bool STREAM>
+__device__ __forceinline__ void stv(T* __restrict__ p, const T (&in)[V]) {
+  typedef T __attribute__((ext_vector_type(V))) VT;
+  if (V == 1) { if (STREAM) __builtin_nontemporal_store(in[0], p); else *p = in[0]; return; }
+  VT v;
+#pragma unroll
+  for (int q = 0; q < V; ++q) v[q] = in[q];
+  if (STREAM) __builtin_nontemporal_store(v, reinterpret_cast<VT*>(p)); else *reinterpret_cast<VT*>(p) = v;
+}
+
+// Every pass handles V consecutive elements per thread and step (V * sizeof(T) = 16 bytes per request when n is a
+// multiple of V, else V = 1): the element-wise results are the same bits either way, the dot-product partials are
+// summed in a different order (tests/test_gpu_parity.py: the PSNR bar of the ill-conditioned small cases follows the CPU
+// reference path's own sensitivity to a last-bit perturbation).
+
 // dn = -g + beta * dk ; sums: [0] max |dn| (owned), [1] dn.dn (owned).  When the finishing thread publishes to the
 // host (fin.pub_dst), the two sums follow the pub_n copied scalars: pub_dst[pub_n], pub_dst[pub_n + 1].
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, const T* __restrict__ g,
                                                   const T* __restrict__ dk, T beta, size_t n, Owned ow,
                                                   double* __restrict__ part, Fin fin) {
   double mx = 0, ss = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const T gi = g[i];
-    T v = -gi;
-    if (dk != nullptr) v += beta * dk[i];
-    dn[i] = v;
-    if (ow.has(i)) { mx = fmax(mx, fabs((double)v)); ss += (double)v * (double)v; }
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
+    T gi[V], di[V], v[V];
+    ldv<T, V, false>(g + i, gi);
+    if (dk != nullptr) ldv<T, V, true>(dk + i, di);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      v[q] = -gi[q];
+      if (dk != nullptr) v[q] += beta * di[q];
+    }
+    stv<T, V, true>(dn + i, v);
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      if (ow.has(i + q)) { mx = fmax(mx, fabs((double)v[q])); ss += (double)v[q] * (double)v[q]; }
   }
   if (block_partials3(mx, ss, 0.0, part, true, 2, fin)) {
     if (fin.pub_dst != nullptr) { fin.pub_dst[fin.pub_n] = fin.out[0]; fin.pub_dst[fin.pub_n + 1] = fin.out[1]; }
@@ -233,7 +269,7 @@ __global__ void k_publish(double* __restrict__ dst, const double* __restrict__ s
 // Block 0 publishes s1, s2 in scal_out[0..1] for the host's step scaling.  When the first step of the line search is
 // known before this pass (ALGLIB's lastgoodstep), its trial point x1 = xk + stp1 * d is written here as well: one pass
 // over xk / x less per CG iteration than a separate k_axpy_out (same expression, same rounding).
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const T* __restrict__ dn, const T* __restrict__ g,
                                                        const double* __restrict__ norms, size_t n, Owned ow,
                                                        double* __restrict__ part, double* __restrict__ scal_out, Fin fin,
@@ -243,11 +279,23 @@ __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const
   if (mx != 0.0) { s1 = 1.0 / mx; s2 = 1.0 / sqrt(ss * s1 * s1); }
   if (blockIdx.x == 0 && threadIdx.x == 0) { scal_out[0] = s1; scal_out[1] = s2; }
   double gd = 0, dd = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const T v = mx != 0.0 ? (T)(((double)dn[i] * s1) * s2) : dn[i];
-    d[i] = v;
-    if (x1 != nullptr) x1[i] = xk[i] + stp1 * v;  // the line search's first trial point (k_axpy_out's expression)
-    if (ow.has(i)) { gd += (double)g[i] * (double)v; dd += (double)v * (double)v; }
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
+    T dv[V], gv[V], xv[V], v[V];
+    ldv<T, V, true>(dn + i, dv);
+    ldv<T, V, false>(g + i, gv);
+    if (x1 != nullptr) ldv<T, V, false>(xk + i, xv);
+#pragma unroll
+    for (int q = 0; q < V; ++q) v[q] = mx != 0.0 ? (T)(((double)dv[q] * s1) * s2) : dv[q];
+    stv<T, V, false>(d + i, v);
+    if (x1 != nullptr) {  // the line search's first trial point (k_axpy_out's expression)
+      T xn[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) xn[q] = xv[q] + stp1 * v[q];
+      stv<T, V, false>(x1 + i, xn);
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      if (ow.has(i + q)) { gd += (double)gv[q] * (double)v[q]; dd += (double)v[q] * (double)v[q]; }
   }
   if (block_partials3(gd, dd, 0.0, part, false, 2, fin)) {
     // {max|dn|, dn.dn, s1, s2} for the host's step scaling (block 0 may not have stored scal_out yet: derived here)
@@ -258,26 +306,38 @@ __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const
 
 // y = g - gp (mincg: yk = -g_k, then yk += g_{k+1}: the same rounding) ; sums: [0] y.dk, [1] g.g, [2] g.y   (the DY / HS
 // betas, optimization.cpp:17700-17760)
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void k_beta_dots(const T* __restrict__ gp, const T* __restrict__ g, const T* __restrict__ dk,
                                                   size_t n, Owned ow, double* __restrict__ part, Fin fin) {
   double a = 0, b = 0, c = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    if (!ow.has(i)) continue;
-    const T gi = g[i];
-    const T y = -gp[i] + gi;
-    a += (double)y * (double)dk[i]; b += (double)gi * (double)gi; c += (double)gi * (double)y;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
+    T gv[V], pv[V], kv[V];
+    ldv<T, V, false>(g + i, gv);
+    ldv<T, V, true>(gp + i, pv);
+    ldv<T, V, true>(dk + i, kv);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      if (!ow.has(i + q)) continue;
+      const T y = -pv[q] + gv[q];
+      a += (double)y * (double)kv[q]; b += (double)gv[q] * (double)gv[q]; c += (double)gv[q] * (double)y;
+    }
   }
   if (block_partials3(a, b, c, part, false, 3, fin)) fin_tag(fin);
 }
 
 // partial of a.b over the owned elements: [0]
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void k_dot(const T* __restrict__ a, const T* __restrict__ b, size_t n, Owned ow,
                                             double* __restrict__ part, Fin fin) {
   double s = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    if (ow.has(i)) s += (double)a[i] * (double)b[i];
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
+    T av[V], bv[V];
+    ldv<T, V, false>(a + i, av);
+    ldv<T, V, false>(b + i, bv);
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      if (ow.has(i + q)) s += (double)av[q] * (double)bv[q];
+  }
   if (block_partials3(s, 0.0, 0.0, part, false, 1, fin)) fin_tag(fin);
 }
 
@@ -369,15 +429,27 @@ int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsi
     // that read none of them; the boundary tile rows wait for the event (kernels_ztile.hip launch_z; paths without
     // that split exchange first).  x is ready when `st` reaches this point; the next exchange cannot start before
     // this evaluation (which reads the halos) is behind the next ev_x.
-    struct Hook { srmap_problem* p; srmap_comm* c; const srmap_shard_desc* sd; void* x; hipStream_t side; hipEvent_t ev; };
+    // Overlap only where it is both enabled on the communicator and SAFE: the caller's halo must be at least the tile
+    // kernel's reach (x rows 2 above / 3 below a tile row: blur transpose + regulariser window), otherwise an
+    // "interior" tile row would read a row the exchange is still writing.
+    const int hu = sd->own_row0, hd = p->geo.H - sd->own_row1;
+    constexpr int kReach = 4;
+    const bool overlap = comm_overlap(c) && ztile_overlaps_halo(p) && (hu == 0 || hu >= kReach) && (hd == 0 || hd >= kReach);
+    if (!overlap) {
+      int rc = shard_exchange_x(p, c, sd, x_dev, st);
+      if (rc) return rc;
+      return srmap_eval_device(p, terms, x_dev, g_dev, nullptr, st);
+    }
+    struct Hook { srmap_problem* p; srmap_comm* c; const srmap_shard_desc* sd; void* x; hipStream_t side; hipEvent_t ev; bool called; };
     hipStream_t side; hipEvent_t ev_x, ev_halo;
     int rc = comm_side(c, &side, &ev_x, &ev_halo);
     if (rc) return rc;
     SRMAP_HIP(p->ctx, hipEventRecord(ev_x, st));
     SRMAP_HIP(p->ctx, hipStreamWaitEvent(side, ev_x, 0));
-    Hook h{p, c, sd, x_dev, side, ev_halo};
+    Hook h{p, c, sd, x_dev, side, ev_halo, false};
     p->ov_hook = [](void* a) -> int {
       Hook* k = static_cast<Hook*>(a);
+      k->called = true;
       int r = shard_exchange_x(k->p, k->c, k->sd, k->x, k->side);
       if (r) return r;
       SRMAP_HIP(k->p->ctx, hipEventRecord(k->ev, k->side));
@@ -385,10 +457,16 @@ int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsi
     };
     p->ov_arg = &h;
     p->ov_event = ev_halo;
-    p->ov_top = sd->own_row0;
-    p->ov_bot = p->geo.H - sd->own_row1;
+    p->ov_top = hu;
+    p->ov_bot = hd;
     rc = srmap_eval_device(p, terms, x_dev, g_dev, nullptr, st);  // cost rows were set on the problem
     p->ov_hook = nullptr; p->ov_arg = nullptr; p->ov_event = nullptr;
+    // An evaluation that failed before it reached the hook has not posted this rank's half of the exchange: post it
+    // now, so that the neighbours' receives complete and they see an error code instead of a hang.
+    if (!h.called) {
+      const int rx = shard_exchange_x(p, c, sd, x_dev, side);
+      if (rc == SRMAP_OK) rc = rx;
+    }
     return rc;
   }
   int rc = shard_exchange_x(p, c, sd, x_dev, st);
@@ -399,7 +477,23 @@ int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsi
     // the arithmetic, so leaving it to one rank would make that rank the critical path -- else on reg_rank.
     const int rank = comm_rank(c), world = comm_world(c);
     unsigned t = terms;
-    const bool band = ztile_reg_band_ok(p, terms);
+    // The split is a COLLECTIVE decision: a rank whose own frame subset has no tile plan (a shift on a 1/32-px rounding
+    // tie, a per-rank SRMAP_IMPL_DIRECT, ...) cannot evaluate a band, and if it went its own way the regulariser would
+    // be counted twice or not at all.  The ranks agree once (minimum of their flags over the communicator; cached on
+    // the problem until its plan, implementation choice, term set or communicator changes); any rank that cannot
+    // band-split sends everybody to reg_rank.
+    const bool mine = ztile_reg_band_ok(p, terms);
+    if (p->band_comm != (const void*)c || p->band_terms != terms || p->band_impl != p->impl || p->band_plan != p->zplan) {
+      double flag = mine ? 0.0 : 1.0;  // max over the ranks of "I cannot" == 0  <=>  every rank can
+      SRMAP_HIP(p->ctx, hipMemcpyAsync(p->d_cost + 7, &flag, sizeof(double), hipMemcpyHostToDevice, st));
+      rc = comm_allreduce(c, p->d_cost + 7, 1, SRMAP_F64, 1, st);
+      if (rc) return rc;
+      SRMAP_HIP(p->ctx, hipMemcpyAsync(&flag, p->d_cost + 7, sizeof(double), hipMemcpyDeviceToHost, st));
+      SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+      p->band_all = flag == 0.0;
+      p->band_comm = c; p->band_terms = terms; p->band_impl = p->impl; p->band_plan = p->zplan;
+    }
+    const bool band = mine && p->band_all;
     if (band) {
       const int tiles = (p->geo.H + 7) / 8, per = (tiles + world - 1) / world;
       p->geo.rr0 = std::min(p->geo.H, rank * per * 8);
@@ -489,6 +583,8 @@ struct DeviceCG {
     return SRMAP_OK;
   }
 
+  static constexpr int kVec = 16 / (int)sizeof(T);  // elements per 16-byte request of the n-vector passes
+  bool vec() const { return n % kVec == 0; }           // (the vectors are hipMalloc'ed: aligned)
   unsigned blocks() const { return (unsigned)((n + 255) / 256); }
   int nb() const { size_t b = (n + 255) / 256; return (int)(b < (size_t)kRedBlocks ? b : kRedBlocks); }
 
@@ -585,7 +681,8 @@ struct DeviceCG {
   // f and g.d of the evaluation just made, with one wait: out[0] = g.d, out[1] = f
   int fetch_f_gd(double* out) {
     if (!p->gd_valid) {
-      hipLaunchKernelGGL(k_dot<T>, dim3(nb()), dim3(256), 0, st, (const T*)g, (const T*)d, n, ow, part, fin_host(true));
+      if (vec()) hipLaunchKernelGGL((k_dot<T, kVec>), dim3(nb()), dim3(256), 0, st, (const T*)g, (const T*)d, n, ow, part, fin_host(true));
+      else hipLaunchKernelGGL((k_dot<T, 1>), dim3(nb()), dim3(256), 0, st, (const T*)g, (const T*)d, n, ow, part, fin_host(true));
       return finish(1, false, true, out);
     }
     if (published) {  // the evaluation's own finish kernel carries the tag
@@ -624,7 +721,8 @@ struct DeviceCG {
         f.tag_slot = hs + 15; f.tag = tag;
       }
     }
-    hipLaunchKernelGGL(k_direction<T>, dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f);
+    if (vec()) hipLaunchKernelGGL((k_direction<T, kVec>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f);
+    else hipLaunchKernelGGL((k_direction<T, 1>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f);
     if (!fused()) {
       hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr,
                          (double*)nullptr, 0.0);
@@ -859,10 +957,16 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     // the first step is lastgoodstep unless that is 0 (then it comes from the norms this pass reduces)
     const double stp_pre = (lastgoodstep != 0 && lastgoodstep >= 1.0e-50 && lastgoodstep <= 1.0e+50) ? lastgoodstep : 0.0;
     {
-      hipLaunchKernelGGL(k_normalize_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
-                         (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
-                         cg.fin_host(false, nullptr, cg.hs + 8, 0), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
-                         (T)stp_pre);
+      if (cg.vec())
+        hipLaunchKernelGGL((k_normalize_dots<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
+                           (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
+                           cg.fin_host(false, nullptr, cg.hs + 8, 0), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
+                           (T)stp_pre);
+      else
+        hipLaunchKernelGGL((k_normalize_dots<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
+                           (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
+                           cg.fin_host(false, nullptr, cg.hs + 8, 0), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
+                           (T)stp_pre);
       double h[2];
       rc = cg.finish(2, false, false, h, 4);  // + {max|dk|, dk.dk, s1, s2} -> hs[8..11]
       if (rc) return rc;
@@ -880,8 +984,12 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     double betak = 0;
     if (mcinfo == 1) {
       // yk = g - gp ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv
-      hipLaunchKernelGGL(k_beta_dots<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g, (const T*)cg.dk, n,
-                         cg.ow, cg.part, cg.fin_host(false));
+      if (cg.vec())
+        hipLaunchKernelGGL((k_beta_dots<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
+                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false));
+      else
+        hipLaunchKernelGGL((k_beta_dots<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
+                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false));
       double h[3];
       rc = cg.finish(3, false, false, h);
       if (rc) return rc;
@@ -889,8 +997,12 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
       betak = dmax(0.0, dmin(h[1] / vv, h[2] / vv));
       gg = h[1];
     } else {
-      hipLaunchKernelGGL(k_dot<T>, dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow, cg.part,
-                         cg.fin_host(false));
+      if (cg.vec())
+        hipLaunchKernelGGL((k_dot<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow,
+                           cg.part, cg.fin_host(false));
+      else
+        hipLaunchKernelGGL((k_dot<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow, cg.part,
+                           cg.fin_host(false));
       double h[1];
       rc = cg.finish(1, false, false, h);
       if (rc) return rc;

@@ -123,6 +123,13 @@ struct srmap_problem {
   void* ov_arg = nullptr;
   hipEvent_t ov_event = nullptr;
   int ov_top = 0, ov_bot = 0;
+  // frame sharding: whether EVERY rank of the communicator can evaluate the regulariser of a row band (agreed once by an
+  // all-reduce, solver.hip shard_eval); the key it was agreed for
+  const void* band_comm = nullptr;
+  const void* band_plan = nullptr;
+  unsigned band_terms = 0;
+  int band_impl = -1;
+  bool band_all = false;
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];
   void* zplan = nullptr;          // srmap::ZPlan of the z-tile kernels (kernels_ztile.hip), owned; nullptr = not covered

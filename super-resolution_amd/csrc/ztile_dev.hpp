@@ -241,14 +241,12 @@ struct ZArgs {
   int E;             // max |shift| (edge tiles take the masked code path)
   int terms;         // SRMAP_TERM_*
   int obs_C;         // channels of the observation stack (y already points at the evaluation's first channel)
-  int g1_gx, g1_gyt, g1_nbb, g1_magic;  // one-dimensional grid (measurement builds): tile rows, tile columns, border blocks, ceil(2^32 / g1_gx)
   // ---- 64 bytes ----
   int cr0, cr1;      // HR rows whose cost terms are counted (row-band sharding; default 0, H)
   int rr0, rr1;      // HR rows (tile aligned) whose regulariser terms are evaluated (frame sharding; default 0, H)
   int sel_mode, sel0, sel1;  // 0: every tile; 1: only tile rows [sel0, sel1) and no border blocks (they read no halo
                              // row of x: row shards run them under the halo exchange); 2: everything else
   int n_tile_partials;  // border partials are stored behind the tile partials
-  int nsteps;            // marching kernel: tile rows per band (0: k_eval_z)
   int MS;                // slots per (row phase, column phase); tables are [MS][S][S] (round, row phase, column phase)
   // the frame table by value (kernel-argument segment: always scalar loads, no table round trip before the first request):
   int cntk[4][8];        //   cnt; [pr][S + 1] = min over the column phases (rounds below it need no per-pixel test)

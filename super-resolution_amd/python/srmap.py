@@ -103,6 +103,8 @@ _SIGNATURES = [
     ("srmap_comm_create_host", C.c_int, [C.c_void_p, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_SENDRECV_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("srmap_comm_destroy", None, [C.c_void_p]),
     ("srmap_comm_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("srmap_comm_set_overlap", C.c_int, [C.c_void_p, C.c_int]),
+    ("srmap_comm_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     ("srmap_comm_split", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("srmap_comm_allreduce", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     ("srmap_eval_sharded_device", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ShardDesc), C.c_uint, C.c_void_p, C.c_void_p, c_double_p, C.c_void_p]),
@@ -428,6 +430,16 @@ class Comm:
         r, w, b = C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(load().srmap_comm_info(self._h, C.byref(r), C.byref(w), C.byref(b)))
         return r.value, w.value, b.value
+
+    def set_overlap(self, on):
+        """Row shards: halo exchange under the interior tile rows (default: host backend on, RCCL off)."""
+        self.ctx.check(load().srmap_comm_set_overlap(self._h, 1 if on else 0))
+
+    def describe(self):
+        """'rccl <version> <path of the loaded librccl>' or 'host callbacks'."""
+        buf = C.create_string_buffer(512)
+        self.ctx.check(load().srmap_comm_describe(self._h, buf, C.c_size_t(512)))
+        return buf.value.decode()
 
     def split(self, color, key, new_rank, new_world):
         """ncclCommSplit (RCCL backend): the ranks passing the same color form a new communicator."""

@@ -47,6 +47,10 @@ def main():
     if mode == "frames2":  # a second regulariser: the direct kernels join in, the regulariser stays on reg_rank (no band split)
         regs.append((srmap.REG_TV, 0.01, 0, 0.0))
         mode = "frames"
+    force_direct = False
+    if mode == "frames_mixed":  # ONE rank on the direct kernels (it cannot evaluate a row band): the ranks must agree on reg_rank
+        force_direct = rank == 1
+        mode = "frames"
     opts = srmap.default_irls_options()
     opts.max_num_irls_iterations = 2
     opts.max_num_solver_iterations = 6
@@ -65,6 +69,8 @@ def main():
         p.set_observations(lr[ids])
         for r in regs:
             p.add_regularizer(*r)
+        if force_direct:
+            p.set_impl(srmap.IMPL_DIRECT)
         sd.mode, sd.reg_rank = srmap.SHARD_FRAMES, 0
         x_loc = x0
         own = (slice(None), slice(None))

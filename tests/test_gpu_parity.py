@@ -356,9 +356,21 @@ def test_solver_psnr_parity_with_cpu_reference(sr, ctx, dtype, reg):
     print("PSNR cpu %.4f dB gpu %.4f dB; irls %d/%d cg %d/%d nfev %d/%d" % (
         psnr_ref, psnr_gpu, rep_ref.irls_rounds, rep.irls_rounds, rep_ref.cg_iterations, rep.cg_iterations,
         rep_ref.nfev, rep.evaluations))
-    # f64 is the parity mode (0.01 dB); f32 storage changes the CG path enough
-    # to move the stopping point, so its bound is looser
-    assert abs(psnr_ref - psnr_gpu) < (0.01 if dtype == 0 else 0.05)
+    # f64 is the parity mode: 0.01 dB (the north-star's tolerance) wherever the problem itself is that well determined.
+    # On this 48 x 48 image the IRLS weights 1 / max(1e-5, r) span five decades and the solve amplifies a last-bit
+    # difference of ONE dot product into the third decimal of the PSNR: the oracle itself, restarted from
+    # x0 * (1 + 1e-14 * noise), moves by `own` dB.  The bar is therefore max(0.01, 10 * own) -- the rule of
+    # tests/test_gpu_solve_parity.py::test_cfg1_solve_matches_oracle, DESIGN.md section 4 -- so that a reordered
+    # reduction in the solver's vector passes is judged against what the reference's own arithmetic can resolve.
+    # f32 storage changes the CG path enough to move the stopping point, so its bound is looser.
+    own = 0.0
+    if dtype == 0:
+        for seed in (1, 2):
+            x_p, _ = ref.solve(x0 * (1 + 1e-14 * np.random.default_rng(seed).standard_normal(x0.shape)),
+                               use_alglib=orc.have_ref())
+            own = max(own, abs(orc.psnr(gt, x_p) - psnr_ref))
+        print("oracle's own PSNR sensitivity to a 1e-14 perturbation of x0: %.5f dB" % own)
+    assert abs(psnr_ref - psnr_gpu) < (max(0.01, 10 * own) if dtype == 0 else 0.05)
     # the iterates follow the reference's up to reduction order; on the non-smooth TV/BTV objective a last-bit
     # difference can move the |cost difference| < threshold stopping decision by a few IRLS rounds (each late round
     # changes the cost by ~the threshold), so the round count is only loosely bounded; the result is not affected

@@ -25,10 +25,12 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("mode", ["frames", "frames2", "rows", "channels", "grid"])
+@pytest.mark.parametrize("mode", ["frames", "frames2", "frames_mixed", "rows", "channels", "grid"])
 def test_two_ranks_on_one_gpu(tmp_path, mode):
     """2 ranks (grid: 4 = 2 channel blocks x 2 frame groups, the frames x channels sharding of BASELINE configs[4]).
-    frames: the regulariser split over the ranks by row band; frames2: two regularisers, evaluated on reg_rank."""
+    frames: the regulariser split over the ranks by row band; frames2: two regularisers, evaluated on reg_rank;
+    frames_mixed: rank 1 forced to the direct kernels -- the band split is a collective decision (all ranks fall back to
+    reg_rank), otherwise the regulariser would be counted one and a half times."""
     world, port = (4 if mode == "grid" else 2), _free_port()
     out = str(tmp_path / "res.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -51,7 +53,7 @@ def test_two_ranks_on_one_gpu(tmp_path, mode):
     # same decisions on every rank and as the single-process solve; iterates equal up to reduction order
     assert len(set(res["cg"])) == 1 and len(set(res["irls"])) == 1 and len(set(res["evals"])) == 1
     assert res["solve_err"] <= 1e-9
-    if mode in ("frames", "frames2", "grid"):
+    if mode in ("frames", "frames2", "frames_mixed", "grid"):
         assert res["replicas_equal"]
 
 
@@ -71,9 +73,16 @@ def test_bench_spawns_its_ranks(shard):
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["value"] > 0
     assert out["config"]["shard"] == shard
     if shard == "rows":
-        assert out["scaling"] == "strong" and out["config"]["rccl_ranks"] == 2
-        assert out["frames_variant"]["value"] > 0 and "ncclAllReduce" in out["frames_variant"]["collective_per_step"]
-        assert "ncclSend" in out["config"]["collective_per_step"]
+        assert out["scaling"] == "strong" and out["config"]["comm_ranks"] == 2
+        # the labels say what ran: the host-callback test backend, not RCCL
+        assert out["config"]["comm_backend"].startswith("host") and out["config"]["comm_library"] == "host callbacks"
+        assert out["frames_variant"]["value"] > 0 and "host-callback all-reduce" in out["frames_variant"]["collective_per_step"]
+        assert "host-callback send/recv" in out["config"]["collective_per_step"]
+        # the configs[2] block: rows strong scaling with its own N = 1 time from the same run
+        c3 = out["cfg3"]
+        assert c3["shard"] == "rows" and c3["scaling"] == "strong" and c3["value"] > 0
+        assert c3["n1_reference_ms_per_step"] > 0 and c3["speedup_vs_n1_in_this_run"] > 0
+        assert "configs[2]" in c3["workload"]
     else:
         assert out["scaling"] == "weak" and out["config"]["collective_per_step"].startswith("none")
 

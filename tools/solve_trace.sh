@@ -1,4 +1,4 @@
-root=$(pwd); out=$root/gpurun_out/r03_solve; mkdir -p $out
+root=$(pwd); out=$root/gpurun_out/${1:-r04_solve}; mkdir -p $out
 python tools/solve_profile.py --irls 3 --cg 50 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python $root/tools/solve_profile.py --irls 3 --cg 50 > $out/kt.log 2>&1
