@@ -61,6 +61,9 @@ int main(int argc, char** argv) {
   const double pca_retained_variance = flags.Double("pca_retained_variance", 0.0);
   const std::string evaluators = flags.Str("evaluators");
   const std::string result_path = flags.Str("result_path");
+  // not a reference flag: the solver's start x0 as raw little-endian float64 [C][H][W], so that a CPU run of the
+  // reference algorithm can start from the IDENTICAL estimate (tests/test_gpu_apps.py compares the two results)
+  const std::string save_initial_estimate = flags.Str("save_initial_estimate");
   const bool verbose = flags.Bool("verbose", false);
   flags.RejectUnknown();
   flags.Require("data_path");
@@ -110,6 +113,16 @@ int main(int argc, char** argv) {
 
   ImageData initial_estimate = low_res_images[0];
   initial_estimate.ResizeImage(upsampling_scale, INTERPOLATE_LINEAR);
+
+  if (!save_initial_estimate.empty()) {
+    const std::vector<double> planar = initial_estimate.ToPlanar();
+    std::FILE* f = std::fopen(save_initial_estimate.c_str(), "wb");
+    if (!f || std::fwrite(planar.data(), sizeof(double), planar.size(), f) != planar.size()) {
+      std::fprintf(stderr, "ERROR: cannot write '%s'.\n", save_initial_estimate.c_str());
+      return 1;
+    }
+    std::fclose(f);
+  }
 
   IRLSMapSolver solver(solver_options, image_model, low_res_images, verbose);
   if (regularization_parameter > 0.0) {

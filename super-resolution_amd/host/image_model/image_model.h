@@ -52,8 +52,11 @@ class DegradationOperator {
   virtual ~DegradationOperator() = default;
   virtual void ApplyToImage(ImageData* image_data, const int index) const = 0;
   virtual void ApplyTransposeToImage(ImageData* image_data, const int index) const = 0;
-  // What this operator contributes to a fused chain.
-  virtual void Describe(srmap_host::ChainParams* chain) const = 0;
+  // What this operator contributes to a fused chain.  The reference's interface has no such member
+  // (degradation_operator.h:17-57) and its callers subclass DegradationOperator (test/test_image_model.cpp:31-46): the
+  // default is "nothing" -- ImageModel::Canonical() does not recognise such an operator, so a model that contains one is
+  // applied operator by operator on the host side of the ABI, exactly as the reference's loop does.
+  virtual void Describe(srmap_host::ChainParams* chain) const { (void)chain; }
 };
 
 class MotionModule : public DegradationOperator {

@@ -420,7 +420,45 @@ static void TestRegistration() {
   EXPECT(registration::TranslationalRegistration({}).GetNumMotionShifts() == 0);
 }
 
+// A caller-defined operator, as the reference's own tests define them (test/test_image_model.cpp:31-46 subclass
+// DegradationOperator): it overrides the reference's two members only.  A model that contains it is not a canonical
+// chain, so ImageModel applies its operators one by one, in insertion order / reverse order for the transpose
+// (image_model.cpp:76-101).
+class GainOperator : public DegradationOperator {
+ public:
+  explicit GainOperator(double gain) : gain_(gain) {}
+  void ApplyToImage(ImageData* image, const int) const override { Scale(image); }
+  void ApplyTransposeToImage(ImageData* image, const int) const override { Scale(image); }
+
+ private:
+  void Scale(ImageData* image) const {
+    for (int c = 0; c < image->GetNumChannels(); ++c) {
+      double* px = image->GetMutableChannelData(c);
+      for (int i = 0; i < image->GetNumPixels(); ++i) px[i] *= gain_;
+    }
+  }
+  const double gain_;
+};
+
+static void TestCallerDefinedOperator() {
+  ImageModel model(2);
+  model.AddDegradationOperator(std::make_shared<GainOperator>(3.0));
+  model.AddDegradationOperator(std::make_shared<DownsamplingModule>(2));
+  srmap_host::ChainParams chain;
+  EXPECT(!model.Canonical(&chain));  // unknown operator: per-operator path
+  ImageData img(kSmall, cv::Size(6, 4));
+  model.ApplyToImage(&img, 0);
+  EXPECT(img.GetImageSize() == cv::Size(3, 2));
+  EXPECT(Near(img.GetChannelData(0), {3, 9, 15, 27, 15, 6}, 1e-12));  // 3 x the decimation literal of test_image_model.cpp:188-193
+  const double lr[6] = {1, 3, 5, 9, 5, 2};
+  ImageData up(lr, cv::Size(3, 2));
+  model.ApplyTransposeToImage(&up, 0);  // D^T first, then the gain
+  EXPECT(up.GetImageSize() == cv::Size(6, 4));
+  EXPECT(Near(up.GetChannelData(0), {3, 0, 9, 0, 15, 0, 0, 0, 0, 0, 0, 0, 27, 0, 15, 0, 6, 0, 0, 0, 0, 0, 0, 0}, 1e-12));
+}
+
 int main() {
+  TestCallerDefinedOperator();
   TestDownsamplingModule();
   TestBlurModule();
   TestRegularizers();

@@ -66,7 +66,8 @@ def test_generate_then_super_resolve(tmp_path):
                           "--upsampling_scale=%d" % s, "--blur_radius=3", "--blur_sigma=1.0",
                           "--motion_sequence_path=" + str(motion), "--regularizer=btv", "--btv_scale_range=2",
                           "--regularization_parameter=0.001", "--optimization_iterations=5",
-                          "--solver_iterations=30", "--evaluators=psnr", "--result_path=" + result_path],
+                          "--solver_iterations=30", "--evaluators=psnr", "--result_path=" + result_path,
+                          "--save_initial_estimate=" + str(tmp_path / "x0.f64")],
                          capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0
@@ -86,19 +87,23 @@ def test_generate_then_super_resolve(tmp_path):
     x, _ = prob.solve(x0, o)
     assert np.max(np.abs(x - result)) < 5e-3
 
-    # and through the CPU oracle (the reference's algorithm, ALGLIB-driven when oracle/_ref is built): the image the
-    # reference binary would have written, up to the float32 file format and the bilinear start's rounding
+    # and through the CPU oracle (the reference's algorithm, ALGLIB-driven when oracle/_ref is built), started from the
+    # IDENTICAL x0 the tool used (--save_initial_estimate: raw float64): the image the reference binary would have
+    # written, up to the float32 file format of the result -- a wrong lambda or weight would show at 1e-3
     import oracle as orc
+    x0_cli = np.fromfile(str(tmp_path / "x0.f64"), dtype=np.float64).reshape(C, H, W)
+    print("tool's bilinear start vs the harness's: max |diff| %.2e" % np.max(np.abs(x0_cli - x0)))
     model = orc.ImageModel(scale=s, shifts=shifts, blur_ksize=3, blur_sigma=1.0)
     ref = orc.Problem(model, frames)
     ref.add_regularizer(orc.REG_BTV, 0.001, 2, 0.5)
     oo = orc.default_irls_options()
     oo.max_num_irls_iterations, oo.max_num_solver_iterations = 5, 30
-    x_ref, rep_ref = ref.solve(x0, oo, use_alglib=orc.have_ref())
+    x_ref, rep_ref = ref.solve(x0_cli, oo, use_alglib=orc.have_ref())
     psnr_cli, psnr_ref = -10 * np.log10(np.mean((result - gt32) ** 2)), orc.psnr(gt32, x_ref)
-    print("CLI result vs oracle solve: max |diff| %.2e, PSNR %.4f / %.4f dB" % (np.max(np.abs(result - x_ref)), psnr_cli, psnr_ref))
-    assert np.max(np.abs(result - x_ref)) < 5e-3
-    assert abs(psnr_cli - psnr_ref) < 0.01
+    print("CLI result vs oracle solve from the same x0: max |diff| %.2e, PSNR %.4f / %.4f dB" % (
+        np.max(np.abs(result - x_ref)), psnr_cli, psnr_ref))
+    assert np.max(np.abs(result - x_ref)) < 2e-6
+    assert abs(psnr_cli - psnr_ref) < 0.001
 
 
 def test_pgm_round_trip_and_usage(tmp_path):
