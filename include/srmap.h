@@ -38,8 +38,11 @@
  *   - the problem's device state (observations, IRLS weights) is ordered by the
  *     library itself: a write through srmap_update_irls_weights_device on one
  *     stream is waited for (an event) by evaluations on another, and a writer
- *     first drains the stream of the last evaluation when it is a different one.
- *     srmap_set_observations_device is complete when it returns.
+ *     first drains the stream of the LAST evaluation when it is a different one.
+ *     Only that one: a problem may have evaluations in flight on ONE stream at a
+ *     time (it owns one set of cost partials and scratch buffers anyway) -- finish
+ *     the evaluations on stream A (or order B after A) before evaluating the same
+ *     problem on stream B.  srmap_set_observations_device is complete when it returns.
  *   - srmap_eval_device / srmap_eval_sharded_device with cost == NULL return
  *     right after enqueueing; x_dev / g_dev must stay alive and untouched by
  *     other streams until the stream reaches that point.

@@ -109,12 +109,15 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const int by = blockIdx.y - A.nby, nby_t = gridDim.y - A.nby;
   int tby = by, tbx = blockIdx.x;
   {
-    // ... with launch indices 1 and last swapped: the bottom tile row (masked edge path in every column, the slowest
-    // tiles) would otherwise be the LAST workgroup of every tile column -- of the last column too, where it sets the
-    // end of the launch (and carries the in-kernel reduction).  It is dispatched second now, like the top row first.
-    const int n0 = blockIdx.x, last = (int)gridDim.x - 1;
-    const int n = (last > 1) ? (n0 == 1 ? last : (n0 == last ? 1 : n0)) : n0;
-    const int q = gridDim.x >> 3, rem = gridDim.x & 7, bnd = n & 7;
+    // ... with launch index 1 and the launch index of the BOTTOM tile row swapped: the bottom row (masked edge path in
+    // every column, the slowest tiles) would otherwise be among the last workgroups of every tile column -- of the last
+    // column too, where it sets the end of the launch.  It is dispatched second now, like the top row first.  The
+    // bottom row is the last row of band 7: launch index 8 q - 1 (= the last index when the row count is a multiple
+    // of 8; with a remainder the last index maps to another band's last row).
+    const int q = gridDim.x >> 3, rem = gridDim.x & 7;
+    const int n0 = blockIdx.x, nbot = (rem == 0) ? (int)gridDim.x - 1 : 8 * q - 1;
+    const int n = (nbot > 1) ? (n0 == 1 ? nbot : (n0 == nbot ? 1 : n0)) : n0;
+    const int bnd = n & 7;
     tby = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
     // tile columns in the order first, last, second, ...: the masked edge columns (longest-lived tiles) are not the
     // launch's last generation
@@ -445,6 +448,11 @@ void ztile_release(srmap_problem* p) {
   if (z->d_mpart) (void)hipFree(z->d_mpart);
   delete z;
   p->zplan = nullptr;
+}
+
+void ztile_rearm(srmap_problem* p) {
+  ZPlan* z = static_cast<ZPlan*>(p->zplan);
+  if (z && z->d_mpart) (void)hipMemsetD32((hipDeviceptr_t)z->d_mpart, (int)kSentinel32, 4 * z->mpart_cap);
 }
 
 // Decide whether k_eval_z covers the problem; build the frame table.

@@ -114,12 +114,15 @@ __device__ __forceinline__ bool block_partials3(double s0, double s1, double s2,
   double v0 = 0, v1 = 0, v2 = 0;
   for (int i = threadIdx.x; i < nbk; i += 256) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0;  // +0.0 for absent rows
-    for (;;) {
+    // bounded like the tile kernel's finisher (~2 s): a block that never publishes ends the pass with NaN sums (the
+    // host's stopping rules then end the solve) instead of hanging the stream
+    for (unsigned spins = 0;; ++spins) {
       if (rows > 0) a0 = ld_dev(fin.gran + i);
       if (rows > 1) a1 = ld_dev(fin.gran + (size_t)nbk + i);
       if (rows > 2) a2 = ld_dev(fin.gran + (size_t)2 * nbk + i);
       if (a0 != kArm && a1 != kArm && a2 != kArm) break;
-      __builtin_amdgcn_s_sleep(1);
+      if (spins > (1u << 22)) break;  // kArm is a NaN pattern: the sums become NaN
+      if (spins < 64) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
     }
     if (rows > 0) st_dev(fin.gran + i, kArm);  // re-armed for the next pass
     if (rows > 1) st_dev(fin.gran + (size_t)nbk + i, kArm);

@@ -758,6 +758,18 @@ int srmap_eval_device(srmap_problem* p, unsigned terms, const void* x_dev, void*
   if (cost) {
     SRMAP_HIP(p->ctx, hipMemcpyAsync(cost, p->d_cost, sizeof(double), hipMemcpyDeviceToHost, st));
     SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+    if (*cost != *cost) {  // NaN: the input's, or the in-kernel reduction gave up waiting for a workgroup (sticky word)
+      double flag = 0.0;
+      SRMAP_HIP(p->ctx, hipMemcpy(&flag, p->d_cost + 6, sizeof(double), hipMemcpyDeviceToHost));
+      if (flag != 0.0) {
+        // the granules were left as they were (a late workgroup may still publish into them): re-initialise them
+        // behind everything in flight, clear the word, and report -- the evaluation's gradient is not trustworthy
+        SRMAP_HIP(p->ctx, hipDeviceSynchronize());
+        ztile_rearm(p);
+        SRMAP_HIP(p->ctx, hipMemset(p->d_cost + 6, 0, sizeof(double)));
+        return set_error(p->ctx, SRMAP_EHIP, "in-kernel cost reduction timed out waiting for a workgroup (device fault or a wedged queue)");
+      }
+    }
   }
   return SRMAP_OK;
 }

@@ -193,6 +193,7 @@ int launch_reduce_partials(srmap_problem* p, const double* partials, int n,
 bool ztile_plan(srmap_problem* p);
 void ztile_release(srmap_problem* p);
 void ztile_preload(const srmap_problem* p);
+void ztile_rearm(srmap_problem* p);  // re-initialise the granules of the in-kernel cost reduction (after its time-out)
 bool ztile_overlaps_halo(const srmap_problem* p);  // the next tile evaluation can run interior tiles under the halo exchange
 bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms);  // the tile kernel alone produces the regulariser part
 size_t ztile_partials_needed(const srmap_problem* p);

@@ -205,14 +205,19 @@ __device__ __forceinline__ void finish_block(const ArgsT& A, double* red /* LDS,
     for (int i = 0; i < NT / 64; ++i) t += red[i];
     tot[pass] = t;
   }
-  // re-arm: the next evaluation finds every granule unpublished
+  // re-arm: the next evaluation finds every granule unpublished.  NOT after a time-out: a workgroup that arrives late
+  // would publish into a re-armed slot and the next evaluation would consume that stale partial; the granules stay as
+  // they are, cost_out[0] is NaN, the sticky word cost_out[6] tells the host to re-initialise them (srmap_api.hip).
+  if (timed_out) {
+    if (tid == 0) { A.cost_out[0] = __builtin_nan(""); A.cost_out[6] = 1.0; if (WD && A.pub != nullptr) { A.pub[0] = A.cost_out[0]; A.pub[1] = 0.0; __threadfence_system(); *(volatile double*)A.tag_slot = A.tag; } }
+    return;
+  }
   for (int i = tid; i < A.n_partials; i += NT) {
     st_agent(reinterpret_cast<unsigned long long*>(A.mpart) + i, kSentinel);
     if (WD) st_agent(reinterpret_cast<unsigned long long*>(A.mpart_gd) + i, kSentinel);
   }
   if (tid == 0) {
-    double v = tot[0];
-    if (timed_out) v = __builtin_nan("");  // a granule never arrived: the evaluation is not trustworthy
+    const double v = tot[0];
     A.cost_out[0] = v;
     if (WD) {
       A.cost_out[1] = tot[1];
