@@ -55,26 +55,15 @@
 
 // Build-time switch of the measurement builds (tools/exp_build.sh); the product build does not define it.
 //   SRMAP_ZT_ONLY_CFG2  instantiate only k_eval_z<double, 4, 3, BTV, 3> (seconds instead of minutes per variant)
-#ifndef SRMAP_EXP_COLW0
-#define SRMAP_EXP_COLW0 4
-#define SRMAP_EXP_COLW1 5
-#endif
-#ifndef SRMAP_EXP_ORD
-#define SRMAP_EXP_ORD 0
-#endif
-#ifndef SRMAP_ZT_HALF
-#define SRMAP_ZT_HALF 1   // 1: tiles of 16 rows x 32 cells (two rows per wave) where 8 % S == 0; 0: 8 x 64 everywhere
-#endif
 
 namespace srmap {
 
 namespace {
 
-template <typename T, int S, int B, int REGK, int R, bool WD, bool SP, bool HF = false>
+template <typename T, int S, int B, int REGK, int R, bool WD, bool SP>
 __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : (S == 2 ? 6 : 4))) void k_eval_z(
     ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
-  using C = ZCfg<T, S, B, REGK, R, 8, HF>;  // HF: two rows of 32 cells per wave (16 x 32 S tiles), ztile_dev.hpp
-  static_assert(!HF || (!SP && C::NW % S == 0), "HALF layout: integer shifts, wave rows share the row phase");
+  using C = ZCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
   // border blocks borrow the x tile's LDS for the frame table
   constexpr int kBorderLds = (int)((16 * sizeof(int2) + kBorderTabEntries * sizeof(ZEntry) + 16 * sizeof(double) + sizeof(T) - 1) / sizeof(T));
@@ -82,7 +71,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   __shared__ T zs[C::ZS_ELEMS > 0 ? C::ZS_ELEMS : 1];
   __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
   __shared__ double red[2][C::NW];
-  __shared__ T wcs[64];  // IRLS weights of the left-halo-column pixels (two columns x up to 32 rows)
+  __shared__ T wcs[32];  // IRLS weights of the left-halo-column pixels (two columns x up to 16 rows)
   __shared__ T whs[(C::RU > 0 ? C::RU : 1) * S * C::CW];  // IRLS weights of the halo rows of 2*lambda*w*r
 
   // Every argument the head of a workgroup reads -- up to its first memory requests -- is requested HERE, in one batch
@@ -102,8 +91,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = HR row of the tile (SGPR); HF: rows wv and wv + NW
-  const LaneMap<C> L(lane);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = HR row of the tile (SGPR)
   // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin in launch order and every XCD has its
   // own L2; with the tile ROW on blockIdx.x and launch index n -> row band (n mod 8) the workgroups an XCD runs at
   // the same time are vertical neighbours and share their x halo rows in that L2.  Bijective for any row count.
@@ -134,8 +122,6 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     // tile columns in the order first, last, second, ...: the masked edge columns (longest-lived tiles) are not the
     // launch's last generation
     tbx = (by == 0) ? 0 : (by == 1 ? nby_t - 1 : by - 1);
-    if (HF && SRMAP_EXP_ORD == 1) tbx = by;                       // plain column order
-    if (HF && SRMAP_EXP_ORD == 2) { tbx = by; tby = blockIdx.x; }  // plain order, no band mapping
   }
   if (A.sel_mode != 0 && ((A.sel_mode == 1) != (tby >= A.sel0 && tby < A.sel1))) return;  // uniform; before any barrier
   const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;
@@ -143,25 +129,25 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const size_t N = (size_t)A.W * A.H;
   const size_t nl = (size_t)A.wl * A.hl;
   const T* xplane = A.x + (size_t)ch * N;
-  const int gr = R0 + wv + L.drow();  // global HR row of this thread
-  const int gc0 = C0 + S * L.cl;      // first global HR column of this thread
+  const int gr = R0 + wv;          // global HR row of this thread
+  const int gc0 = C0 + S * lane;   // first global HR column of this thread
+  const int cellg = CJ0 + lane;
   const bool want_data = (A.terms & SRMAP_TERM_DATA) != 0;
   // frame shards evaluate the regulariser of their own row band only (whole tiles: the band is tile aligned)
   const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0 && R0 >= A.rr0 && R0 < A.rr1;
   const T* ybase = A.y + (size_t)ch * nl;
   // ---------------- global loads whose addresses are known now: x tile, observations, IRLS weights ----------------
-  constexpr int RPI = HF ? 2 * C::NW : C::NW;       // x rows the workgroup requests per iteration
-  constexpr int ARI = (C::XR + RPI - 1) / RPI;      // iterations
+  constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // x rows per wave
   constexpr int EXTRA = C::XC - C::CW;              // halo cells, staged by the first lanes
   T va[ARI][S], vb[ARI][S], ma[ARI], mb[ARI];
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
-    const int row = wv + L.drow() + it * RPI;
+    const int row = wv + it * C::NW;
     const int grr = R0 - C::HU + row;
-    const bool row_in = row < C::XR && (unsigned)grr < (unsigned)A.H;  // uniform (HF: per half)
-    const int gca = CJ0 - C::XCL + L.cl, gcb = gca + C::CW;
+    const bool row_in = row < C::XR && (unsigned)grr < (unsigned)A.H;  // uniform
+    const int gca = CJ0 - C::XCL + lane, gcb = gca + C::CW;
     const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
-    const bool inb = row_in && L.cl < EXTRA && (unsigned)gcb < (unsigned)A.wl;
+    const bool inb = row_in && lane < EXTRA && (unsigned)gcb < (unsigned)A.wl;
     const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
     const T* sb = xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
 #pragma unroll
@@ -182,15 +168,12 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const bool edge = (R0 - rm < 0) || (R0 + C::TH + rm > A.H) || (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl) ||
                     A.cr0 > 0 || A.cr1 < A.H;  // partial tiles (bottom / right) are edge tiles by the first two tests
   const int hrowz = wv == 0 ? -HB : C::TH - 1 + HB;  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
-  // HF: the two halo rows have different row phases, so each takes the upper half of its wave (the lower half idles)
   const bool has_z_halo = want_data && B > 1 && A.g != nullptr && wv < 2;
-  const bool z_halo_lane = !HF || L.hf == 0;
-  const LaneMap<C> Lh(HF ? (lane & 31) : lane);  // lane map of a halo row pass (upper half: no row offset)
   T ypre2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) ypre2[v] = T(0);
-  if (!SP && want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, CJ0, L, edge, ybase, ypre);
-  if (!SP && has_z_halo && z_halo_lane) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, Lh, edge, ybase, ypre2);
+  if (!SP && want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, CJ0, lane, edge, ybase, ypre);
+  if (!SP && has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
   const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
   T wreg[S];
 #pragma unroll
@@ -199,11 +182,10 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)gr * A.W + gc0 + pc];
   }
-  // halo row of 2*lambda*w*r this wave evaluates (waves 2 .. 2+RU-1: tile rows -1 .. -RU) and its weights.
-  // HF: ONE wave takes them all, one row per half (wave 2: upper half row -1, lower half row -2)
+  // halo row of 2*lambda*w*r this wave evaluates (waves 2 .. 2+RU-1: tile rows -1 .. -RU) and its weights
   const bool reg_halo_on = want_reg && A.g != nullptr && RU > 0;
-  const int hrow = HF ? -1 - L.hf : -(wv - 1);  // wave 2 -> -1, wave 3 -> -2
-  const bool has_reg_halo = reg_halo_on && (HF ? (wv == 2 && L.hf < RU) : (wv >= 2 && wv < 2 + RU));
+  const int hrow = -(wv - 1);  // wave 2 -> -1, wave 3 -> -2
+  const bool has_reg_halo = reg_halo_on && wv >= 2 && wv < 2 + RU;
   T whalo[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) whalo[pc] = T(1);
@@ -216,31 +198,29 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // with the tile's other inputs and parked in LDS with the x tile -- a load inside the task stalled these two waves,
   // and with them the workgroup's second barrier, for a memory round trip
   T wcolv = T(1);
-  // the waves that take the two left halo columns (lanes = rows; HF: 18 of them)
-  constexpr int CW0 = HF ? SRMAP_EXP_COLW0 : 4, CW1 = HF ? SRMAP_EXP_COLW1 : 5;
-  const bool col_task = reg_halo_on && (wv == CW0 || wv == CW1) && lane < C::TH + RU;
+  const bool col_task = reg_halo_on && (wv == 4 || wv == 5) && lane < C::TH + RU;
   if (col_task && wplane != nullptr) {
-    const int hgr = R0 + lane - RU, hgc = C0 - (wv == CW0 ? 1 : 2);
+    const int hgr = R0 + lane - RU, hgc = C0 - (wv == 4 ? 1 : 2);
     if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
   }
 
   // ---------------- x tile -> LDS, polyphase ----------------
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
-    const int row = wv + L.drow() + it * RPI;
-    if (row < C::XR) {  // uniform (HF: per half)
+    const int row = wv + it * C::NW;
+    if (row < C::XR) {  // uniform
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + L.cl] = va[it][pc] * ma[it];
-      if (L.cl < EXTRA) {
+      for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + lane] = va[it][pc] * ma[it];
+      if (lane < EXTRA) {
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + L.cl] = vb[it][pc] * mb[it];
+        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + lane] = vb[it][pc] * mb[it];
       }
     }
   }
-  if (col_task) wcs[(wv == CW0 ? 0 : 32) + lane] = wcolv;
+  if (col_task) wcs[(wv - 4) * 16 + lane] = wcolv;
   if (has_reg_halo) {  // the halo row's weights wait in LDS too (eight registers less across the data term)
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) whs[(((HF ? L.hf : wv - 2)) * S + pc) * C::CW + L.cl] = whalo[pc];
+    for (int pc = 0; pc < S; ++pc) whs[((wv - 2) * S + pc) * C::CW + lane] = whalo[pc];
   }
   __syncthreads();
 
@@ -277,11 +257,11 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     T dummy[S];
     double dcost = 0.0;
     if (edge) {
-      z_row<T, S, B, C, true>(A, xs, zs, wv, R0, CJ0, L, ybase, true, ypre, true, mk, zown, cost_data);
-      if (has_z_halo && z_halo_lane) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, CJ0, Lh, ybase, true, ypre2, false, mk, dummy, dcost);
+      z_row<T, S, B, C, true>(A, xs, zs, wv, R0, CJ0, lane, ybase, true, ypre, true, mk, zown, cost_data);
+      if (has_z_halo) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, CJ0, lane, ybase, true, ypre2, false, mk, dummy, dcost);
     } else {
-      z_row<T, S, B, C, false>(A, xs, zs, wv, R0, CJ0, L, ybase, true, ypre, true, mk, zown, cost_data);
-      if (has_z_halo && z_halo_lane) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, CJ0, Lh, ybase, true, ypre2, false, mk, dummy, dcost);
+      z_row<T, S, B, C, false>(A, xs, zs, wv, R0, CJ0, lane, ybase, true, ypre, true, mk, zown, cost_data);
+      if (has_z_halo) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, CJ0, lane, ybase, true, ypre2, false, mk, dummy, dcost);
     }
   }
   // ---------------- phase 1: regulariser ----------------
@@ -289,39 +269,34 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     const bool reg_border = (R0 + C::TH + C::WIN > A.H) || (C0 + C::TW + C::WIN > A.W);
     const bool cost_row = gr >= A.cr0 && gr < A.cr1;
     if (reg_border)
-      reg_row<T, S, REGK, R, C, true, true>(acc, cost_reg, xs, cs, wreg, wv, L, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
+      reg_row<T, S, REGK, R, C, true, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
     else
-      reg_row<T, S, REGK, R, C, false, true>(acc, cost_reg, xs, cs, wreg, wv, L, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
+      reg_row<T, S, REGK, R, C, false, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
     if (has_reg_halo) {
       T dacc[S];
       double dc = 0.0;
       T whl[S];
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) whl[pc] = whs[(((HF ? L.hf : wv - 2)) * S + pc) * C::CW + L.cl];
+      for (int pc = 0; pc < S; ++pc) whl[pc] = whs[((wv - 2) * S + pc) * C::CW + lane];
       // right-edge masks follow the tile's; the rows above a tile reach below the image only when the tile keeps
       // fewer than WIN rows of it (a partial bottom tile: found by tests/test_gpu_fuzz.py, H - R0 = 2 with BTV(3))
-      // HF: the row differs per half (hrow = -1 - hf): row -1 as the uniform row, the lower half one row further up
-      // through its lane offsets (negative row offset of the x tile / 2*lambda*w*r arrays)
-      LaneMap<C> Lr(HF ? (lane & 31) : lane);
-      if (HF) { Lr.lx -= L.hf * C::XROW; Lr.lc -= L.hf * C::CROW; }
-      const int hrow_u = HF ? -1 : hrow;
       if (C0 + C::TW + C::WIN > A.W || R0 + C::WIN > A.H)
-        reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whl, hrow_u, Lr, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
+        reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whl, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
       else
-        reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whl, hrow_u, Lr, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
+        reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whl, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
     }
     // left halo columns -1 .. -RU, one row per lane, one column per wave (a few-lane task with a
     // long dependent chain -- both columns on one wave made the whole workgroup wait for it at the barrier)
     if (col_task) {  // waves 4 / 5: their SIMDs carry the z halo rows only
-      const T wcol = wcs[(wv == CW0 ? 0 : 32) + lane];
+      const T wcol = wcs[(wv - 4) * 16 + lane];
       const int rowrel = lane - RU;
       const int lo = rowrel * C::XROW, lc = rowrel * C::CROW;  // per-lane row offsets
       if (reg_border) {
-        if (RU >= 1 && wv == CW0) reg_halo_col<T, S, REGK, R, C, -1, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-        if (RU >= 2 && wv == CW1) reg_halo_col<T, S, REGK, R, C, -2, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+        if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+        if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
       } else {
-        if (RU >= 1 && wv == CW0) reg_halo_col<T, S, REGK, R, C, -1, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-        if (RU >= 2 && wv == CW1) reg_halo_col<T, S, REGK, R, C, -2, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+        if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
+        if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
       }
     }
   }
@@ -346,14 +321,14 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
       } else {
         zz = T(0);
 #pragma unroll
-        for (int a = 0; a < B; ++a) zz += k1_tap<B>(A, a) * zs[(wv + a) * C::ZROW + pc * C::CW + L.lz];  // rows wv-HB+a
+        for (int a = 0; a < B; ++a) zz += k1_tap<B>(A, a) * zs[(wv + a) * C::ZROW + pc * C::CW + lane];  // rows wv-HB+a
       }
       if (SP)  // the ring pass owns the pixels within Dr of the image edge
         zz = ((unsigned)(gr - A.Dr) < (unsigned)(A.H - 2 * A.Dr) && (unsigned)(gc0 + pc - A.Dr) < (unsigned)(A.W - 2 * A.Dr)) ? zz : T(0);
       acc[pc] += sc * zz;
     }
   }
-  if (want_reg && A.g != nullptr) reg_pass2z<T, S, REGK, R, C>(acc, xs, cs, wv, L, A.powtab);
+  if (want_reg && A.g != nullptr) reg_pass2z<T, S, REGK, R, C>(acc, xs, cs, wv, lane, A.powtab);
 
   if (A.g != nullptr && gr < A.H && gc0 < A.W) {
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
@@ -514,7 +489,6 @@ bool ztile_plan(srmap_problem* p) {
   ZPlan* z = new ZPlan();
   z->S = S; z->B = B;
   z->E = amax;
-  z->half = SRMAP_ZT_HALF != 0 && (8 % S == 0);  // 16-row x 32-cell tiles (two rows per wave); never for sub-pixel plans
   if (subpix) {
     // ---- sub-pixel plan: z(p) = sum over (frame, bilinear tap of the TRANSPOSE warp) pairs that land on the LR grid ----
     z->subpix = true;
@@ -710,7 +684,7 @@ bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms) {
 
 size_t ztile_partials_needed(const srmap_problem* p) {
   const Geometry& g = p->geo;
-  const size_t tiles = std::max((size_t)((g.w + 63) / 64) * ((g.H + 7) / 8), (size_t)((g.w + 31) / 32) * ((g.H + 15) / 16)) * g.C;
+  const size_t tiles = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * g.C;
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   size_t ring = 0;
   if (z && z->n_ring > 0) ring = (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * g.C;  // border blocks fill whole grid rows
@@ -720,16 +694,11 @@ size_t ztile_partials_needed(const srmap_problem* p) {
 // in-kernel finish of this launch; publish {cost, g.d} to the solver's host words; plain partials of an earlier launch to add
 struct MFin { bool on, publish; const double* xpart; int n_xpart; };
 
-template <typename T, int S, int B, int REGK, int R, bool HF = false>
+template <typename T, int S, int B, int REGK, int R>
 static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                     const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st, const T* dvec,
                     double* partials_gd, MFin mfin) {
-  // the 16-row x 32-cell layout (two rows per wave) where the plan selects it: integer shifts, 8 % S == 0
-  if constexpr (!HF && (8 % S == 0)) {
-    if (z.half && !z.subpix)
-      return launch_z<T, S, B, REGK, R, true>(p, geo, obs_c0, terms, x, g, wts, z, partials, nblocks, st, dvec, partials_gd, mfin);
-  }
-  using C = ZCfg<T, S, B, REGK, R, 8, HF>;
+  using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
   A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
   A.dvec = dvec; A.partials_gd = partials_gd;
@@ -791,11 +760,11 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
     A.rbuf = (const T*)p->d_resid;
     A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
-    if constexpr (!HF) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), 0, st, A);
+    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), 0, st, A);
   } else {
     auto launch = [&]() {
-      if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false, HF>), grid, dim3(C::NT), 0, st, A);
-      else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false, HF>), grid, dim3(C::NT), 0, st, A);
+      if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), 0, st, A);
+      else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
     };
     if (p->ov_hook != nullptr) {
       // Row shard: a tile row [8 t, 8 t + 8) reads x rows within the halo width of itself, so the tile rows t with
@@ -826,10 +795,6 @@ static void preload_z() {
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false, false>));
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, true, false>));
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false, true>));
-  if constexpr (8 % S == 0) {
-    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false, false, true>));
-    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, true, false, true>));
-  }
 }
 template <typename T, int S, int B>
 static void preload_reg(int regk, int regr) {
@@ -898,7 +863,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (want_reg)
     for (int r = 0; r < p->nreg; ++r)
       if (!(regk && r == z.reg_index) && p->reg[r].lambda > 0.0) more_regs = true;
-  const size_t est_parts = std::max((size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8), (size_t)((geo.w + 31) / 32) * ((geo.H + 15) / 16)) * geo.C +
+  const size_t est_parts = (size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8) * geo.C +
                            (z.n_ring > 0 ? (size_t)((z.n_ring + 511) / 512 + (geo.H + 7) / 8) * geo.C : (size_t)0);  // as ztile_partials_needed
   const bool sp_data = z.subpix && (terms & SRMAP_TERM_DATA);
   const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= kMaxFusedPartials && !z.subpix;

@@ -51,17 +51,12 @@ __device__ __forceinline__ double absv<double>(double d) { return __builtin_fabs
 constexpr int zmax(int a, int b) { return a > b ? a : b; }
 constexpr int zceil(int a, int b) { return (a + b - 1) / b; }
 
-template <typename T, int S, int B, int REGK, int R, int NW_ = 8, bool HALF_ = false>
+template <typename T, int S, int B, int REGK, int R, int NW_ = 8>
 struct ZCfg {
-  // HALF: a wave owns TWO tile rows (wv and wv + NW) of 32 cells each -- lanes 0-31 the upper, 32-63 the lower row: tiles
-  // of 2 NW rows x 32 S columns.  Same pixels per workgroup, same waves, but the halo rows of zh / 2*lambda*w*r (row
-  // passes beyond the tile's own: 4 per 8 rows) serve 16 rows, and the x window is 21 rows per 16 instead of 13 per 8.
-  // Needs NW % S == 0 (both rows of a wave share the row phase: the frame tables stay scalar).
-  static constexpr bool HALF = HALF_;
-  static constexpr int NW = NW_;               // waves
+  static constexpr int NW = NW_;               // waves = HR rows per tile
   static constexpr int NT = 64 * NW;
-  static constexpr int TH = HALF_ ? 2 * NW : NW;   // HR rows per tile
-  static constexpr int CW = HALF_ ? 32 : 64;       // LR cells per tile row
+  static constexpr int TH = NW;
+  static constexpr int CW = 64;                // LR cells per tile row = lanes
   static constexpr int TW = CW * S;
   static constexpr int HB = (B - 1) / 2;
   static constexpr int WIN = REGK == 2 ? R : (REGK == 1 ? 1 : 0);      // pass 1 reaches WIN pixels right / down
@@ -84,23 +79,6 @@ struct ZCfg {
   static constexpr int CRR = REGK ? TH + RU : 0;
   static constexpr int CS_ELEMS = CRR * CROW;
   static constexpr int NP = REGK == 2 ? 2 * R + 1 : 1;
-};
-
-// How a lane maps onto the tile: cl = LR cell of the tile row, hf = which of the wave's rows (HALF layouts; else 0).
-// lx / lz / lc: the lane's element offset into a row of the x tile / zh / 2*lambda*w*r arrays INCLUDING its row's offset
-// from the wave's first row (hf * NW rows), so that every LDS index stays `uniform row base + immediate + lane offset`.
-template <typename C>
-struct LaneMap {
-  int cl, hf, lx, lz, lc;
-  __device__ __forceinline__ explicit LaneMap(int lane) {
-    if (C::HALF) {
-      cl = lane & 31; hf = lane >> 5;
-      lx = cl + hf * (C::NW * C::XROW); lz = cl + hf * (C::NW * C::ZROW); lc = cl + hf * (C::NW * C::CROW);
-    } else {
-      cl = lane; hf = 0; lx = lane; lz = lane; lc = lane;
-    }
-  }
-  __device__ __forceinline__ int drow() const { return C::HALF ? hf * C::NW : 0; }  // HR row offset of the lane's row
 };
 
 struct ZEntry { int k, io, jo, oyx; };  // frame, LR row / column offset of the residual a pixel of this phase owns,
@@ -402,7 +380,7 @@ __device__ __forceinline__ void row_phase(int gr, int& rc, int& pr) {
 // (frame table: SURVEY.md section 8a' restated per HR pixel).  Interior tiles: one scalar offset per pixel phase,
 // address = row base + offset + cell.  EDGE: explicit (frame, LR row, LR column), clamped into the image.
 template <typename T, int S, typename C, bool EDGE, typename ArgsT>
-__device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int t, int cell0, const LaneMap<C>& L,
+__device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int t, int cell0, int lane,
                                              const T* __restrict__ ybase, const int (&cn)[S], T (&yv)[C::NV]) {
   constexpr int HB = C::HB, NV = C::NV;
   const size_t slot = (size_t)(t * S + pr) * S;  // uniform; round-major: round 0 (the prefetch) needs no table size
@@ -418,8 +396,7 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
       const T* yp = yrow + (offs[pc] + dc);  // uniform pointer; the lane adds its (non-negative) cell index
-      // HALF: the lane's row lies NW / S LR rows below the wave's first (rc is that first row's)
-      yv[v] = yp[(unsigned)(C::HALF ? L.cl + L.hf * ((C::NW / S) * A.wl) : L.cl)];
+      yv[v] = yp[(unsigned)lane];
     }
     return;
   }
@@ -432,7 +409,7 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
   for (int v = 0; v < NV; ++v) {
     const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
     const ZEntry e = ent[pc];
-    yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + L.hf * (C::NW / S) + e.io, cell0 + L.cl + dc + e.jo, A.hl, A.wl);
+    yv[v] = obs_at<T>(ybase + (size_t)e.k * A.obs_C * ((size_t)A.wl * A.hl), rc + e.io, cell0 + lane + dc + e.jo, A.hl, A.wl);
   }
   (void)cn;
 }
@@ -444,7 +421,7 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
 // taps of LR row 0 / column 0.  The staged x is pre-scaled by 2^Q: residual = (B x') * 2^-Q - y.
 template <typename T, int S, int B, typename C, bool EDGE, typename ArgsT>
 __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ zs, int rowrel,
-                                      int R0, int cell0, const LaneMap<C>& L, const T* __restrict__ ybase, bool use_pre,
+                                      int R0, int cell0, int lane, const T* __restrict__ ybase, bool use_pre,
                                       const T (&ypre)[C::NV], bool count, const T (&mk)[S], T (&zout)[S],
                                       double& cost) {
   constexpr int HB = C::HB, NV = C::NV;
@@ -458,7 +435,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
   for (int a = 0; a < B; ++a) {
     T xr[NV + B - 1];
 #pragma unroll
-    for (int j = 0; j < NV + B - 1; ++j) xr[j] = xs[xi<C>(xrow + a - HB, j - 2 * HB) + L.lx];
+    for (int j = 0; j < NV + B - 1; ++j) xr[j] = xs[xi<C>(xrow + a - HB, j - 2 * HB) + lane];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
@@ -488,7 +465,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
 #pragma unroll
       for (int v = 0; v < NV; ++v) yv[v] = ypre[v];
     } else {
-      load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, L, ybase, cn, yv);
+      load_obs_row<T, S, C, EDGE>(A, pr, rc, t, cell0, lane, ybase, cn, yv);
     }
     if (!EDGE && t < mfull) {  // uniform; the common case (K a multiple of S*S distinct phases): no per-pixel selects
 #pragma unroll
@@ -513,15 +490,12 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
           if (own && count) cost += (double)rr * (double)rr;
         } else {
           const ZEntry e = (t == 0) ? aux0_at(A, pr, pc) : ctab(A.aux, slot + pc);
-          const int i = rc + L.hf * (C::NW / S) + e.io, j = cell0 + L.cl + dc + e.jo;  // i: per lane in HALF layouts
+          const int i = rc + e.io, j = cell0 + lane + dc + e.jo;
           T bxv = bx[v];
           if (B > 1) {
             // filter2D's zero padding acts on the warped image: LR row 0 loses blur tap row 0, LR column 0 tap column 0
             const bool j0 = j == 0;
-            if (C::HALF) {  // selects: the LR row differs between the two halves of the wave
-              const T ct = (i == 0) ? btop[v] : T(0), cl2 = j0 ? bleft[v] : T(0), cc = (i == 0 && j0) ? bcorner[v] : T(0);
-              bxv = bxv - ct - (cl2 - cc);
-            } else if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
+            if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
             else bxv = bxv - (j0 ? bleft[v] : T(0));
           }
           rr = bxv * unscale - yv[v];
@@ -545,7 +519,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
       T zh = T(0);
 #pragma unroll
       for (int e = 0; e < B; ++e) zh += k1_tap<B>(A, e) * z[pc + e];
-      zs[(rowrel + HB) * C::ZROW + pc * C::CW + L.lz] = zh;
+      zs[(rowrel + HB) * C::ZROW + pc * C::CW + lane] = zh;
     }
   }
 }
@@ -628,15 +602,15 @@ __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int
 
 // t = 0 observations of the NV pixels of the thread's cell in tile row `rowrel`, issued at kernel start.
 template <typename T, int S, int B, typename C, typename ArgsT>
-__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cell0, const LaneMap<C>& L, bool edge,
+__device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R0, int cell0, int lane, bool edge,
                                                const T* __restrict__ ybase, T (&ypre)[C::NV]) {
   int rc, pr;
   row_phase<S>(R0 + rowrel, rc, pr);
   int cn[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-  if (edge) load_obs_row<T, S, C, true>(A, pr, rc, 0, cell0, L, ybase, cn, ypre);
-  else load_obs_row<T, S, C, false>(A, pr, rc, 0, cell0, L, ybase, cn, ypre);
+  if (edge) load_obs_row<T, S, C, true>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
+  else load_obs_row<T, S, C, false>(A, pr, rc, 0, cell0, lane, ybase, cn, ypre);
 }
 
 // ---- regulariser pass 1 for the S pixels of one cell (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
@@ -644,7 +618,7 @@ __device__ __forceinline__ void z_row_prefetch(const ArgsT& A, int rowrel, int R
 // Stores 0 for pixels outside the image and, BTV only, for the absolute pixel (0,0) (btv_regularizer.cpp:143-146).
 template <typename T, int S, int REGK, int R, typename C, bool BORDER, bool FULL>
 __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __restrict__ xs, T* __restrict__ cs,
-                                        const T (&wv)[S], int rowrel, const LaneMap<C>& L, int gr, int gc0, int W, int H,
+                                        const T (&wv)[S], int rowrel, int lane, int gr, int gc0, int W, int H,
                                         T lambda, const T (&pw)[C::NP], T pwsum, bool cost_row) {
   constexpr int WIN = C::WIN;
   constexpr int NC = S + WIN;
@@ -657,7 +631,7 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
   for (int i = 0; i <= WIN; ++i) {
     T row[NC];
 #pragma unroll
-    for (int j = 0; j < NC; ++j) row[j] = xs[xi<C>(xrow + i, j) + L.lx];
+    for (int j = 0; j < NC; ++j) row[j] = xs[xi<C>(xrow + i, j) + lane];
     if (i == 0) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) x0v[pc] = row[pc];
@@ -702,7 +676,7 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
       cost += cd;
     }
     if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
-    cs[ci<C>(rowrel + C::RU, pc) + L.lc] = cr2;
+    cs[ci<C>(rowrel + C::RU, pc) + lane] = cr2;
   }
 }
 
@@ -745,7 +719,7 @@ __device__ __forceinline__ void reg_halo_col(const T* __restrict__ xs, T* __rest
 // btv_regularizer.cpp:137-162) ----
 template <typename T, int S, int REGK, int R, typename C>
 __device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs, const T* __restrict__ cs, int rowrel,
-                                           const LaneMap<C>& L, const T (&pw)[C::NP]) {
+                                           int lane, const T (&pw)[C::NP]) {
   constexpr int RU = C::RU;
   if (RU == 0) return;
   constexpr int NC = S + RU;
@@ -758,8 +732,8 @@ __device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs
     T xw[NC], cw[NC];              // columns -RU .. S-1
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      xw[j] = xs[xi<C>(xrow - i, j - RU) + L.lx];
-      cw[j] = cs[ci<C>(crow - i, j - RU) + L.lc];
+      xw[j] = xs[xi<C>(xrow - i, j - RU) + lane];
+      cw[j] = cs[ci<C>(crow - i, j - RU) + lane];
     }
     if (i == 0) {
 #pragma unroll
@@ -955,7 +929,6 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
 struct ZPlan {
   int S = 0, B = 1;
   int regk = 0, regr = 0, reg_index = -1;
-  bool half = false;    // 16-row x 32-cell tiles, two rows per wave (ZCfg::HALF)
   bool subpix = false;  // sub-pixel shifts: residuals from k_forward_direct, z by 4-tap tables, exact ring by k_gather_direct
   int Dr = 0;           //   ring width
   double* d_spw = nullptr;
