@@ -95,6 +95,11 @@ def test_rccl_backend_world_one():
     uid = srmap.Comm.unique_id(ctx)
     assert len(uid) == 128
     comm = srmap.Comm(ctx, 0, 1, backend="rccl", unique_id=uid)
+    # the communicator names the collective library it resolved (a process may carry several librccl copies)
+    what = comm.describe().split()
+    assert what[0] == "rccl" and int(what[1]) > 0 and "rccl" in what[2]
+    assert comm.info() == (0, 1, 1)
+    comm.set_overlap(True)   # opt-in of the halo-exchange overlap (row shards); a no-op for this one-rank solve
     t = torch.arange(1000, dtype=torch.float64, device="cuda")
     comm.allreduce(t.data_ptr(), t.numel(), srmap.F64, 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
