@@ -52,12 +52,6 @@
 
 
 #include "ztile_dev.hpp"
-#ifndef SRMAP_EXP_BUNROLL
-#define SRMAP_EXP_BUNROLL 0
-#endif
-#ifndef SRMAP_EXP_BAND
-#define SRMAP_EXP_BAND 0   // n > 0: k_eval_b, bands of n tile rows per workgroup
-#endif
 
 // Build-time switch of the measurement builds (tools/exp_build.sh); the product build does not define it.
 //   SRMAP_ZT_ONLY_CFG2  instantiate only k_eval_z<double, 4, 3, BTV, 3> (seconds instead of minutes per variant)
@@ -361,299 +355,6 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
       put_partial<WD>(A, b, c, d);
     }
     // in-kernel finish: the last workgroup of the grid gathers the granules of the evaluation
-    if (A.mfinish && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) {
-      __syncthreads();
-      finish_block<WD, C::NT>(A, &red[0][0]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Band kernel k_eval_b: the tile kernel's phases, unchanged (same helpers, same LDS layout, same immediates), run
-// A.nsteps times by one workgroup that walks down a band of 8 * nsteps rows.  Between two steps the rows the next
-// step shares with this one are COPIED to the front of the LDS arrays (x rows 6..10 -> -2..2, zh rows 7, 8 -> -1, 0,
-// 2*lambda*w*r rows 6, 7 -> -2, -1: 4.6 elements per thread), so that the next step finds them where a fresh tile
-// would have staged / evaluated them: the halo row passes of zh and 2*lambda*w*r run once per band, x rows are
-// requested once per band, and a workgroup's launch and argument fetch are paid once per band.  No ring
-// arithmetic (the marching kernel of round 4, history be934b7, paid 2 M scalar instructions and 0.9 M vector
-// instructions per launch for its rings and spilled SGPRs).
-template <typename T, int S, int B, int REGK, int R, bool WD, int NS>
-__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : (S == 2 ? 6 : 4))) void k_eval_b(
-    ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
-  using C = ZCfg<T, S, B, REGK, R>;
-  constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
-  constexpr int kBorderLds = (int)((16 * sizeof(int2) + kBorderTabEntries * sizeof(ZEntry) + 16 * sizeof(double) + sizeof(T) - 1) / sizeof(T));
-  __shared__ T xs[C::XS_ELEMS > kBorderLds ? C::XS_ELEMS : kBorderLds];
-  __shared__ T zs[C::ZS_ELEMS > 0 ? C::ZS_ELEMS : 1];
-  __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
-  __shared__ double red[2][C::NW];
-  __shared__ T wcs[32];
-  __shared__ T whs[(C::RU > 0 ? C::RU : 1) * S * C::CW];
-  {
-    const T* a_x = A.x; const T* a_y = A.y; const T* a_w = A.w; T* a_g = A.g;
-    const int a_W = A.W, a_H = A.H, a_wl = A.wl, a_hl = A.hl, a_nby = A.nby, a_E = A.E, a_terms = A.terms, a_obsC = A.obs_C;
-    const int a_cr0 = A.cr0, a_cr1 = A.cr1, a_rr0 = A.rr0, a_rr1 = A.rr1, a_ns = A.nsteps;
-    const unsigned a_gx = gridDim.x, a_gy = gridDim.y;
-    asm volatile("" ::"s"(a_x), "s"(a_y), "s"(a_w), "s"(a_g), "s"(a_W), "s"(a_H), "s"(a_wl), "s"(a_hl), "s"(a_nby), "s"(a_E),
-                 "s"(a_terms), "s"(a_obsC), "s"(a_cr0), "s"(a_cr1), "s"(a_rr0), "s"(a_rr1), "s"(a_ns), "s"(a_gx), "s"(a_gy));
-  }
-  const int tid = threadIdx.x;
-  int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if ((int)blockIdx.y < A.nby) {  // border blocks come first in dispatch order (uniform branch)
-    const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
-    const BorderArgs<T>& Bd = *A.bd;
-    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
-    else if (threadIdx.x == 0) {
-      const int nbb = A.nby * gridDim.x;
-      put_partial<WD>(A, (size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx, 0.0, 0.0);
-    }
-    return;
-  }
-  const int by = blockIdx.y - A.nby, nby_t = gridDim.y - A.nby;
-  int tband, tbx;
-  {
-    const int q = gridDim.x >> 3, rem = gridDim.x & 7;
-    const int n0 = blockIdx.x, nbot = (rem == 0) ? (int)gridDim.x - 1 : 8 * q - 1;
-    const int n = (nbot > 1) ? (n0 == 1 ? nbot : (n0 == nbot ? 1 : n0)) : n0;
-    const int bnd = n & 7;
-    tband = bnd * q + (bnd < rem ? bnd : rem) + (n >> 3);
-    tbx = (by == 0) ? 0 : (by == 1 ? nby_t - 1 : by - 1);
-  }
-  const int nsteps = NS > 0 ? NS : A.nsteps;  // NS > 0: the steps are unrolled at compile time
-  const int Rb = tband * (C::TH * nsteps), CJ0 = tbx * C::CW, C0 = CJ0 * S;
-  const int Rend = Rb + C::TH * nsteps;  // first row of the next band
-  int nst = (A.H - Rb + C::TH - 1) / C::TH;
-  nst = nst < nsteps ? nst : nsteps;
-  const int ch = blockIdx.z;
-  const size_t N = (size_t)A.W * A.H;
-  const size_t nl = (size_t)A.wl * A.hl;
-  const T* xplane = A.x + (size_t)ch * N;
-  const bool want_data = (A.terms & SRMAP_TERM_DATA) != 0;
-  const T* ybase = A.y + (size_t)ch * nl;
-  double cost_data = 0.0, cost_reg = 0.0, gdsum = 0.0;
-  constexpr int EXTRA = C::XC - C::CW;
-  constexpr int KEEP = C::HU + C::HD;  // x rows a step shares with the next one (its rows TH - HU .. TH + HD - 1)
-
-#pragma unroll
-  for (int s = 0; s < (NS > 0 ? NS : nst); ++s) {
-    if (NS > 0 && s >= nst) break;  // uniform: the image ends inside the band
-    asm volatile("" : "+v"(lane));  // lane-derived address arithmetic is formed per step, not carried around the loop
-    const bool first = s == 0;
-    const bool more = s + 1 < nst;
-    const int R0 = Rb + C::TH * s;
-    const int gr = R0 + wv;
-    const int gc0 = C0 + S * lane;
-    const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0 && R0 >= A.rr0 && R0 < A.rr1;
-    // ---------------- requests: the x rows this step adds, observations, IRLS weights ----------------
-    // step 0: the whole window (rows -HU .. TH + HD - 1, two rounds); later steps: its last TH rows (rows KEEP - HU ..)
-    T va[2][S], vb[2][S], ma[2], mb[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = first ? wv + it * C::NW : KEEP + wv;
-      const int grr = R0 - C::HU + row;
-      const bool on = (first || it == 0) && row < C::XR;  // uniform
-      const bool row_in = on && (unsigned)grr < (unsigned)A.H;
-      const int gca = CJ0 - C::XCL + lane, gcb = gca + C::CW;
-      const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
-      const bool inb = row_in && lane < EXTRA && (unsigned)gcb < (unsigned)A.wl;
-      const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
-      const T* sb = xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
-      if (first || it == 0) {  // (later steps request one round; the out-of-window rows of round 1 read a valid element)
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
-      }
-      ma[it] = ina ? Pre<T>::up(T(1)) : T(0);
-      mb[it] = inb ? Pre<T>::up(T(1)) : T(0);
-    }
-    T ypre[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ypre[v] = T(0);
-    const int rm = A.E + HB + 1, cm = (A.E + HB + S) / S + 1;
-    const bool edge = (R0 - rm < 0) || (R0 + C::TH + rm > A.H) || (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl) ||
-                      A.cr0 > 0 || A.cr1 < A.H;
-    // zh rows of this step: step 0 as a tile (own rows + halo rows -HB on wave 0, TH - 1 + HB on wave 1); later steps
-    // find rows -HB .. HB - 1 in LDS (the previous step's rows TH - HB .. TH + HB - 1): wave 0 takes the bottom halo row
-    // instead of its own row 0
-    const bool z_two = want_data && B > 1 && A.g != nullptr && first && wv < 2;
-    const int hrowz = wv == 0 ? -HB : C::TH - 1 + HB;
-    const int zrow_own = (!first && B > 1 && wv < HB) ? C::TH - 1 + HB - wv : wv;  // HB == 1: wave 0 -> row TH
-    // cost of a zh row's residuals: counted once, in the band that owns the row
-    const bool z_count = R0 + zrow_own < Rend;
-    T ypre2[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ypre2[v] = T(0);
-    if (want_data) z_row_prefetch<T, S, B, C>(A, zrow_own, R0, CJ0, lane, edge, ybase, ypre);
-    if (z_two) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
-    const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
-    T wreg[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
-    if (wplane != nullptr && gr < A.H && gc0 < A.W) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)gr * A.W + gc0 + pc];
-    }
-    const bool reg_halo_on = want_reg && A.g != nullptr && RU > 0;
-    const int hrow = -(wv - 1);  // wave 2 -> -1, wave 3 -> -2
-    const bool has_reg_halo = reg_halo_on && first && wv >= 2 && wv < 2 + RU;
-    T whalo[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) whalo[pc] = T(1);
-    if (has_reg_halo && wplane != nullptr && R0 + hrow >= 0 && gc0 < A.W) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) whalo[pc] = wplane[(size_t)(R0 + hrow) * A.W + gc0 + pc];
-    }
-    // left halo columns: rows -RU .. TH - 1 at step 0, rows 0 .. TH - 1 later (lanes = rows, offset by RU)
-    T wcolv = T(1);
-    const int c_lo = first ? 0 : RU;
-    const bool col_task = reg_halo_on && (wv == 4 || wv == 5) && lane >= c_lo && lane < C::TH + RU;
-    if (col_task && wplane != nullptr) {
-      const int hgr = R0 + lane - RU, hgc = C0 - (wv == 4 ? 1 : 2);
-      if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
-    }
-
-    // ---------------- x rows -> LDS, polyphase ----------------
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = first ? wv + it * C::NW : KEEP + wv;
-      if ((first || it == 0) && row < C::XR) {  // uniform
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + lane] = va[it][pc] * ma[it];
-        if (lane < EXTRA) {
-#pragma unroll
-          for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + lane] = vb[it][pc] * mb[it];
-        }
-      }
-    }
-    if (col_task) wcs[(wv - 4) * 16 + lane] = wcolv;
-    if (has_reg_halo) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) whs[((wv - 2) * S + pc) * C::CW + lane] = whalo[pc];
-    }
-    __syncthreads();  // barrier A
-
-    T mk[S], mk2[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      mk[pc] = (R0 + zrow_own < A.H && gc0 + pc < A.W) ? T(1) : T(0);
-      mk2[pc] = (R0 + hrowz < A.H && gc0 + pc < A.W) ? T(1) : T(0);
-    }
-    // the bottom halo row of step 0 is row 0 of step 1, which does not evaluate it again: its residuals are counted here
-    const bool z2_count = wv == 1 && R0 + C::TH < Rend;
-    T acc[S], zown[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) { acc[j] = T(0); zown[j] = T(0); }
-
-    // ---------------- phase 1: data term ----------------
-    if (want_data) {
-      T dummy[S];
-      if (edge) {
-        z_row<T, S, B, C, true>(A, xs, zs, zrow_own, R0, CJ0, lane, ybase, true, ypre, z_count, mk, zown, cost_data);
-        if (z_two) z_row<T, S, B, C, true>(A, xs, zs, hrowz, R0, CJ0, lane, ybase, true, ypre2, z2_count, mk2, dummy, cost_data);
-      } else {
-        z_row<T, S, B, C, false>(A, xs, zs, zrow_own, R0, CJ0, lane, ybase, true, ypre, z_count, mk, zown, cost_data);
-        if (z_two) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, CJ0, lane, ybase, true, ypre2, z2_count, mk2, dummy, cost_data);
-      }
-    }
-    // ---------------- phase 1: regulariser ----------------
-    if (want_reg) {
-      const bool reg_border = (R0 + C::TH + C::WIN > A.H) || (C0 + C::TW + C::WIN > A.W);
-      const bool cost_row = gr >= A.cr0 && gr < A.cr1;
-      if (reg_border)
-        reg_row<T, S, REGK, R, C, true, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
-      else
-        reg_row<T, S, REGK, R, C, false, true>(acc, cost_reg, xs, cs, wreg, wv, lane, gr, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, cost_row);
-      if (has_reg_halo) {
-        T dacc[S];
-        double dc = 0.0;
-        T whl[S];
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) whl[pc] = whs[((wv - 2) * S + pc) * C::CW + lane];
-        if (C0 + C::TW + C::WIN > A.W || R0 + C::WIN > A.H)
-          reg_row<T, S, REGK, R, C, true, false>(dacc, dc, xs, cs, whl, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
-        else
-          reg_row<T, S, REGK, R, C, false, false>(dacc, dc, xs, cs, whl, hrow, lane, R0 + hrow, gc0, A.W, A.H, A.lambda, A.powtab, A.pwsum, false);
-      }
-      if (col_task) {
-        const T wcol = wcs[(wv - 4) * 16 + lane];
-        const int rowrel = lane - RU;
-        const int lo = rowrel * C::XROW, lc = rowrel * C::CROW;  // per-lane row offsets
-        if (reg_border) {
-          if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-          if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2, true>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-        } else {
-          if (RU >= 1 && wv == 4) reg_halo_col<T, S, REGK, R, C, -1, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-          if (RU >= 2 && wv == 5) reg_halo_col<T, S, REGK, R, C, -2, false>(xs + lo, cs + lc, wcol, rowrel, R0, C0, A.W, A.H, A.lambda, A.powtab);
-        }
-      }
-    }
-    __syncthreads();  // barrier B
-
-    // ---------------- phase 2 ----------------
-    T dreg[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) dreg[pc] = T(0);
-    if (WD && gr < A.H && gc0 < A.W && gr >= A.cr0 && gr < A.cr1) {
-      const T* dp = A.dvec + (size_t)ch * N + (size_t)gr * A.W + gc0;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) dreg[pc] = dp[pc];
-    }
-    if (want_data && A.g != nullptr) {
-      const T sc = (T)(2 * S * S);
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) {
-        T zz;
-        if (B == 1) {
-          zz = zown[pc];
-        } else {
-          zz = T(0);
-#pragma unroll
-          for (int a = 0; a < B; ++a) zz += k1_tap<B>(A, a) * zs[(wv + a) * C::ZROW + pc * C::CW + lane];
-        }
-        acc[pc] += sc * zz;
-      }
-    }
-    if (want_reg && A.g != nullptr) reg_pass2z<T, S, REGK, R, C>(acc, xs, cs, wv, lane, A.powtab);
-    if (WD) {
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) gdsum += (double)acc[pc] * (double)dreg[pc];
-    }
-    if (A.g != nullptr && gr < A.H && gc0 < A.W) {
-      T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) __builtin_nontemporal_store(acc[pc], &dst[pc]);
-    }
-    // ---------------- the rows the next step shares with this one move to the front of the arrays ----------------
-    if (more) {
-      __syncthreads();  // barrier C: every wave has finished reading
-      // x rows TH .. TH + KEEP - 1 (tile rows TH - HU .. TH + HD - 1) -> rows 0 .. KEEP - 1
-      for (int i = tid; i < KEEP * C::XROW; i += C::NT) xs[i] = xs[C::TH * C::XROW + i];
-      if (B > 1) {  // zh rows TH .. TH + 2 HB - 1 -> 0 .. 2 HB - 1
-        for (int i = tid; i < 2 * HB * C::ZROW; i += C::NT) zs[i] = zs[C::TH * C::ZROW + i];
-      }
-      if (REGK != 0 && RU > 0) {  // 2*lambda*w*r rows TH .. TH + RU - 1 -> 0 .. RU - 1
-        for (int i = tid; i < RU * C::CROW; i += C::NT) cs[i] = cs[C::TH * C::CROW + i];
-      }
-      __syncthreads();  // barrier D: the next step stages its new x rows over the rows just copied FROM
-    }
-  }
-
-  // ---------------- cost partial of this workgroup ----------------
-  {
-    if (WD) gdsum = wave_sum_d(gdsum);
-    const double cw = wave_sum_d((double)(S * S) * cost_data + cost_reg);
-    const int l0 = tid & 63;
-    if (l0 == 0) { red[0][wv] = cw; if (WD) red[1][wv] = gdsum; }
-    __syncthreads();
-    if (tid == 0) {
-      double c = 0.0, d = 0.0;
-#pragma unroll
-      for (int i = 0; i < C::NW; ++i) { c += red[0][i]; if (WD) d += red[1][i]; }
-      const size_t b = ((size_t)blockIdx.z * nby_t + by) * gridDim.x + blockIdx.x;
-      put_partial<WD>(A, b, c, d);
-    }
     if (A.mfinish && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) {
       __syncthreads();
       finish_block<WD, C::NT>(A, &red[0][0]);
@@ -1033,11 +734,6 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
         if (i + j > 0) A.pwsum += A.powtab[i + j];
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
-  A.nsteps = 0;
-  if (SRMAP_EXP_BAND > 0 && !z.subpix && p->ov_hook == nullptr) {
-    A.nsteps = SRMAP_EXP_BAND;
-    grid.x = (grid.x + A.nsteps - 1) / A.nsteps;
-  }
   const int n_tile_partials = (int)(grid.x * grid.y * grid.z);
   // border blocks: whole rows of the grid in front of the tiles
   A.bd = (const BorderArgs<T>*)z.d_bd;
@@ -1067,11 +763,6 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), 0, st, A);
   } else {
     auto launch = [&]() {
-      if (A.nsteps > 0) {
-        if (dvec != nullptr) hipLaunchKernelGGL((k_eval_b<T, S, B, REGK, R, true, SRMAP_EXP_BUNROLL>), grid, dim3(C::NT), 0, st, A);
-        else hipLaunchKernelGGL((k_eval_b<T, S, B, REGK, R, false, SRMAP_EXP_BUNROLL>), grid, dim3(C::NT), 0, st, A);
-        return;
-      }
       if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), 0, st, A);
       else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
     };

@@ -252,7 +252,6 @@ struct ZArgs {
   int sel_mode, sel0, sel1;  // 0: every tile; 1: only tile rows [sel0, sel1) and no border blocks (they read no halo
                              // row of x: row shards run them under the halo exchange); 2: everything else
   int n_tile_partials;  // border partials are stored behind the tile partials
-  int nsteps;            // band kernel: tile rows per workgroup (0: k_eval_z)
   int MS;                // slots per (row phase, column phase); tables are [MS][S][S] (round, row phase, column phase)
   // the frame table by value (kernel-argument segment: always scalar loads, no table round trip before the first request):
   int cntk[4][8];        //   cnt; [pr][S + 1] = min over the column phases (rounds below it need no per-pixel test)
