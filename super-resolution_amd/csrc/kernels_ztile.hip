@@ -52,6 +52,9 @@
 
 
 #include "ztile_dev.hpp"
+#ifndef SRMAP_EXP_XT
+#define SRMAP_EXP_XT 1
+#endif
 
 // Build-time switch of the measurement builds (tools/exp_build.sh); the product build does not define it.
 //   SRMAP_ZT_ONLY_CFG2  instantiate only k_eval_z<double, 4, 3, BTV, 3> (seconds instead of minutes per variant)
@@ -139,21 +142,28 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // ---------------- global loads whose addresses are known now: x tile, observations, IRLS weights ----------------
   constexpr int ARI = (C::XR + C::NW - 1) / C::NW;  // x rows per wave
   constexpr int EXTRA = C::XC - C::CW;              // halo cells, staged by the first lanes
+  // XT: the EXTRA halo cells of ALL rows are requested by the last wave in its (otherwise idle) last round -- one lane per
+  // (row, cell) -- instead of by the first EXTRA lanes of every wave in every round (half of a wave's x requests
+  // served two lanes each)
+  constexpr bool XT = SRMAP_EXP_XT != 0 && ARI >= 2 && (C::NW - 1) + (ARI - 1) * C::NW >= C::XR && C::XR * EXTRA <= 64;
   T va[ARI][S], vb[ARI][S], ma[ARI], mb[ARI];
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
-    const int row = wv + it * C::NW;
+    const bool xt_slot = XT && it == ARI - 1 && wv == C::NW - 1;  // uniform
+    const int row = xt_slot ? lane / EXTRA : wv + it * C::NW;
     const int grr = R0 - C::HU + row;
-    const bool row_in = row < C::XR && (unsigned)grr < (unsigned)A.H;  // uniform
-    const int gca = CJ0 - C::XCL + lane, gcb = gca + C::CW;
+    const bool row_in = row < C::XR && (unsigned)grr < (unsigned)A.H;  // uniform (XT slot: per lane)
+    const int gca = xt_slot ? CJ0 - C::XCL + C::CW + lane % EXTRA : CJ0 - C::XCL + lane, gcb = gca + C::CW;
     const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
-    const bool inb = row_in && lane < EXTRA && (unsigned)gcb < (unsigned)A.wl;
+    const bool inb = !XT && row_in && lane < EXTRA && (unsigned)gcb < (unsigned)A.wl;
     const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
     const T* sb = xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
+    if (!XT) {
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
+      for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
+    }
     // scale 2^Q inside the image, 0 outside: applied as ONE multiply when the tile goes to LDS -- a select on the
     // loaded value makes the compiler wait for this row group before it requests the next one
     ma[it] = ina ? Pre<T>::up(T(1)) : T(0);
@@ -207,11 +217,20 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // ---------------- x tile -> LDS, polyphase ----------------
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
+    const bool xt_slot = XT && it == ARI - 1 && wv == C::NW - 1;  // uniform
+    if (xt_slot) {
+      const int xrow = lane / EXTRA;
+      if (xrow < C::XR) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) xs[xrow * C::XROW + pc * C::XC + C::CW + lane % EXTRA] = va[it][pc] * ma[it];
+      }
+      continue;
+    }
     const int row = wv + it * C::NW;
     if (row < C::XR) {  // uniform
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + lane] = va[it][pc] * ma[it];
-      if (lane < EXTRA) {
+      if (!XT && lane < EXTRA) {
 #pragma unroll
         for (int pc = 0; pc < S; ++pc) xs[row * C::XROW + pc * C::XC + C::CW + lane] = vb[it][pc] * mb[it];
       }
