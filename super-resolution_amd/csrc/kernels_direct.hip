@@ -371,11 +371,93 @@ __global__ __launch_bounds__(256) void k_btv_values4(const T* __restrict__ x, T*
   }
 }
 
+// The same with a thread walking DOWN a strip of RS rows: the window's R + 1 rows stay in registers and every output
+// row requests ONE new row (two 4-element vectors) instead of R + 1 -- (RS + R) / RS rows read per row written instead
+// of R + 1, a quarter of the memory instructions at R = 3.  Per pixel the same taps in the same order with the same
+// zeros for the skipped ones as k_btv_values4: bit-identical (tests/test_gpu_parity.py, reg values against the CPU path).
+#ifndef SRMAP_BTV_STRIP
+#define SRMAP_BTV_STRIP 4
+#endif
+__device__ __forceinline__ float fabs_mod(float v) { return __builtin_fabsf(v); }
+__device__ __forceinline__ double fabs_mod(double v) { return __builtin_fabs(v); }
+// BORDER = false: the strip's windows stay inside the image (no per-tap masks: two f64 issues per tap instead of four).
+template <typename T, int R, int RS, bool BORDER>
+__device__ __forceinline__ void btv_strip_rows(const T* __restrict__ plane, T* __restrict__ oplane, int W, int H, int r0,
+                                               int c0, bool nin, const PowTable& pw, int as_weights) {
+  T win[R + 1][8];  // window rows r .. r + R of the row being written (rotating: row q lives in win[q % (R + 1)])
+#pragma unroll
+  for (int q = 0; q < RS + R; ++q) {
+    // row r0 + q enters the window (rows below the image: a valid address, never used -- see `rin` below)
+    {
+      const int rr = r0 + q;
+      const T* row = plane + (size_t)((!BORDER || rr < H) ? rr : r0) * W + c0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) win[q % (R + 1)][e] = row[e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) win[q % (R + 1)][4 + e] = row[(!BORDER || nin) ? 4 + e : e];
+    }
+    if (q < R) continue;
+    const int o = q - R, r = r0 + o;  // the output row whose window is complete now
+    if (BORDER && r >= H) continue;
+    T tv[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int i = 0; i <= R; ++i) {
+      const bool rin = r + i < H;
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+#pragma unroll
+        for (int j = 0; j <= R; ++j) {
+          T d = win[o % (R + 1)][pc] - win[(o + i) % (R + 1)][pc + j];
+          if (BORDER) d = (rin && (pc + j < 4 || nin)) ? d : T(0);
+          // |d| as the FMA's source modifier (absval's compare + select cost three more issues per tap).  The two differ
+          // for d = -0 only, and a -0 product leaves the sum -- which starts at +0 -- unchanged just like a +0 one.
+          tv[pc] += (T)pw.v[i + j] * fabs_mod(d);
+        }
+      }
+    }
+    T* out = oplane + (size_t)r * W + c0;
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+      T v = tv[pc];
+      if (as_weights) {  // w = 1 / max(1e-5, r) (k_irls_weights' arithmetic)
+        const T m = v > (T)0.00001 ? v : (T)0.00001;
+        v = T(1) / m;
+      }
+      out[pc] = v;
+    }
+  }
+}
+
+template <typename T, int R, int RS>
+__global__ __launch_bounds__(256) void k_btv_values_strip(const T* __restrict__ x, T* __restrict__ values, int W, int H,
+                                                         PowTable pw, int as_weights) {
+  const int W4 = W >> 2;
+  const int nstrips = (H + RS - 1) / RS;
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (cell >= W4 * nstrips) return;
+  const int sidx = cell / W4, c0 = (cell - sidx * W4) * 4;
+  const int r0 = sidx * RS;
+  const T* plane = x + (size_t)c * W * H;
+  T* oplane = values + (size_t)c * W * H;
+  const bool nin = c0 + 4 < W;  // the next cell of the row exists
+  // one path per wave: only the waves that hold a row's last cell or the image's last strips take the masked one
+  if (__all(nin && r0 + RS + R <= H)) btv_strip_rows<T, R, RS, false>(plane, oplane, W, H, r0, c0, nin, pw, as_weights);
+  else btv_strip_rows<T, R, RS, true>(plane, oplane, W, H, r0, c0, nin, pw, as_weights);
+}
+
 template <typename T>
 static bool launch_btv_values4(const Geometry& g, const RegSpec& rs, const T* x, T* out, int as_weights, const PowTable& pw,
                                hipStream_t st) {
   if (rs.kind != SRMAP_REG_BTV || rs.range < 1 || rs.range > 3 || (g.W & 3) != 0) return false;
   if ((long long)g.W * g.H / 4 >= (long long)INT_MAX) return false;
+  if (SRMAP_BTV_STRIP > 0 && rs.range == 3 && g.H >= 4 * SRMAP_BTV_STRIP) {  // the solve's pass at cfg2
+    constexpr int RS = SRMAP_BTV_STRIP > 0 ? SRMAP_BTV_STRIP : 1;
+    const long long cells = (long long)(g.W >> 2) * ((g.H + RS - 1) / RS);
+    dim3 sgrid((unsigned)((cells + 255) / 256), g.C);
+    hipLaunchKernelGGL((k_btv_values_strip<T, 3, RS>), sgrid, dim3(256), 0, st, x, out, g.W, g.H, pw, as_weights);
+    return true;
+  }
   dim3 grid((unsigned)(((long long)(g.W >> 2) * g.H + 255) / 256), g.C);
   if (rs.range == 1) hipLaunchKernelGGL((k_btv_values4<T, 1>), grid, dim3(256), 0, st, x, out, g.W, g.H, pw, as_weights);
   else if (rs.range == 2) hipLaunchKernelGGL((k_btv_values4<T, 2>), grid, dim3(256), 0, st, x, out, g.W, g.H, pw, as_weights);

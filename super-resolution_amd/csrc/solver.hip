@@ -94,7 +94,7 @@ struct Fin {
 // ascending order, then the wave and the four-wave combination of k_finish: the same additions in the same order as
 // the two-launch scheme.  Returns true in the one thread that wrote out[] (it still owes fin_tag()).
 __device__ __forceinline__ bool block_partials3(double s0, double s1, double s2, double* __restrict__ part, bool max0,
-                                                int rows, const Fin& fin) {
+                                                int rows, const Fin& fin, double* tot = nullptr) {
   __shared__ double red[3][4];
   s0 = max0 ? wmax(s0) : wsum(s0);
   s1 = wsum(s1);
@@ -138,10 +138,14 @@ __device__ __forceinline__ bool block_partials3(double s0, double s1, double s2,
   if (lane == 0) { red[0][wid] = v0; red[1][wid] = v1; red[2][wid] = v2; }
   __syncthreads();
   if (threadIdx.x != 0) return false;
-  if (rows > 0) fin.out[0] = max0 ? fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))
-                                  : (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-  if (rows > 1) fin.out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-  if (rows > 2) fin.out[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  const double t0 = max0 ? fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))
+                         : (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  const double t1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const double t2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  if (rows > 0) fin.out[0] = t0;
+  if (rows > 1) fin.out[1] = t1;
+  if (rows > 2) fin.out[2] = t2;
+  if (tot != nullptr) { tot[0] = t0; tot[1] = t1; tot[2] = t2; }  // the same sums for the finishing thread's own use
   if (fin.cost_src != nullptr) fin.out[rows] = fin.cost_src[0];
   for (int i = 0; i < fin.pub_n; ++i) fin.pub_dst[i] = fin.pub_src[i];
   return true;
@@ -187,7 +191,9 @@ __device__ __forceinline__ void stv(T* __restrict__ p, const T (&in)[V]) {
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, const T* __restrict__ g,
                                                   const T* __restrict__ dk, T beta, size_t n, Owned ow,
-                                                  double* __restrict__ part, Fin fin) {
+                                                  double* __restrict__ part, Fin fin, const double* __restrict__ beta_dev) {
+  // beta_dev: the beta the preceding k_beta_dots left on the device (the host queues this pass without waiting for it)
+  if (beta_dev != nullptr) beta = (T)beta_dev[0];
   double mx = 0, ss = 0;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
     T gi[V], di[V], v[V];
@@ -311,7 +317,8 @@ __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const
 // betas, optimization.cpp:17700-17760)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_beta_dots(const T* __restrict__ gp, const T* __restrict__ g, const T* __restrict__ dk,
-                                                  size_t n, Owned ow, double* __restrict__ part, Fin fin) {
+                                                  size_t n, Owned ow, double* __restrict__ part, Fin fin,
+                                                  double* __restrict__ beta_dst, int restart) {
   double a = 0, b = 0, c = 0;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
     T gv[V], pv[V], kv[V];
@@ -325,7 +332,19 @@ __global__ __launch_bounds__(256) void k_beta_dots(const T* __restrict__ gp, con
       a += (double)y * (double)kv[q]; b += (double)gv[q] * (double)gv[q]; c += (double)gv[q] * (double)y;
     }
   }
-  if (block_partials3(a, b, c, part, false, 3, fin)) fin_tag(fin);
+  double tot[3];
+  if (block_partials3(a, b, c, part, false, 3, fin, tot)) {
+    if (beta_dst != nullptr) {
+      // betak = max(0, min(betady, betahs)) exactly as run_cg forms it on the host (same IEEE divisions and compares):
+      // the direction pass queued behind this one reads it, the host never has to answer in between
+      const double vv = tot[0], bdy = tot[1] / vv, bhs = tot[2] / vv;
+      const double bm = bdy < bhs ? bdy : bhs;
+      double bk = 0.0 > bm ? 0.0 : bm;
+      if (restart) bk = 0.0;
+      beta_dst[0] = bk;
+    }
+    fin_tag(fin);
+  }
 }
 
 // partial of a.b over the owned elements: [0]
@@ -560,26 +579,29 @@ struct DeviceCG {
   T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr, *gp = nullptr;
   double* part = nullptr;   // [3][kRedBlocks] block partials (two-launch reductions: sharded solves)
   unsigned long long* gran = nullptr;  // [3][kRedBlocks] granules of the one-launch reductions (armed)
-  double* dscal = nullptr;  // device scalars: [0..3] reduction results, [4..5] direction norms
-  double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal): results [0..11], arrival tag [15]
+  double* dscal = nullptr;  // device scalars: [0..3] reduction results, [4..5] direction norms, [6..7] s1 s2, [8] beta
+  double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal): results [0..13], arrival tag [15]
   double tag = 0;           // last tag handed to a publishing kernel
   int evaluations = 0;
   double wait_seconds = 0;  // host time spent in wait_tag
   int waits = 0;
 
-  // Wait until the kernel that was given `tag` has published its results (see k_finish): poll the host-mapped word,
-  // fall back to a stream synchronisation after ~2 s (also surfaces asynchronous errors).
-  int wait_tag() {
+  // Wait until the kernel that was given tag `want` (default: the last one handed out) has published its results (see
+  // k_finish): poll the host-mapped word, fall back to a stream synchronisation after ~2 s (also surfaces asynchronous
+  // errors).  Tags only grow and the publishing kernels of one stream finish in order, so "arrived" is slot >= want:
+  // a later kernel queued behind the awaited one (chained passes, run_cg) may already have stored its own tag.
+  int wait_tag(double want = -1.0) {
+    if (want < 0) want = tag;
     volatile double* slot = hs + 15;
     const auto t0 = std::chrono::steady_clock::now();
     struct Acc { DeviceCG* c; std::chrono::steady_clock::time_point t; ~Acc() {
       c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); c->waits++; } } acc{this, t0};
     unsigned spins = 0;
-    while (*slot != tag) {
+    while (!(*slot >= want)) {
       if ((++spins & 0x3ff) == 0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
         SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
-        if (*slot != tag) return set_error(p->ctx, SRMAP_EHIP, "solver: device results did not arrive");
+        if (!(*slot >= want)) return set_error(p->ctx, SRMAP_EHIP, "solver: device results did not arrive");
         break;
       }
     }
@@ -595,8 +617,8 @@ struct DeviceCG {
     T** v[] = {&x, &g, &xk, &dk, &dn, &d, &gp};
     for (T** q : v) SRMAP_HIP(p->ctx, hipMalloc((void**)q, n * sizeof(T)));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&part, sizeof(double) * 3 * kRedBlocks));
-    SRMAP_HIP(p->ctx, hipMalloc((void**)&dscal, sizeof(double) * 8));
-    SRMAP_HIP(p->ctx, hipMemsetAsync(dscal, 0, sizeof(double) * 8, st));
+    SRMAP_HIP(p->ctx, hipMalloc((void**)&dscal, sizeof(double) * 16));
+    SRMAP_HIP(p->ctx, hipMemsetAsync(dscal, 0, sizeof(double) * 16, st));
     SRMAP_HIP(p->ctx, hipMalloc((void**)&gran, sizeof(double) * 3 * kRedBlocks));
     SRMAP_HIP(p->ctx, hipMemsetD32Async((hipDeviceptr_t)gran, (int)kArm32, 2 * 3 * kRedBlocks, st));
     // sharded evaluations write only the owned part of g: the vector kernels run over all n elements, so everything
@@ -624,11 +646,12 @@ struct DeviceCG {
   // One-launch reductions (struct Fin) whenever the sums need no all-reduce.
   bool fused() const { return !reduce_scalars; }
   // the pass about to be launched reduces to the host: out = hs[0 .. rows) (+ the cost at hs[rows]), then the tag
-  Fin fin_host(bool with_cost, const double* pub_src = nullptr, double* pub_dst = nullptr, int pub_n = 0) {
+  Fin fin_host(bool with_cost, const double* pub_src = nullptr, double* pub_dst = nullptr, int pub_n = 0,
+               double* out = nullptr) {
     Fin f{};
     if (fused()) {
       tag += 1.0;
-      f.gran = gran; f.out = hs; f.cost_src = with_cost ? (const double*)p->d_cost : nullptr;
+      f.gran = gran; f.out = out ? out : hs; f.cost_src = with_cost ? (const double*)p->d_cost : nullptr;
       f.pub_src = pub_src; f.pub_dst = pub_dst; f.pub_n = pub_n;
       f.tag_slot = hs + 15; f.tag = tag;
     }
@@ -664,7 +687,7 @@ struct DeviceCG {
   // objective at x: g <- gradient; the cost stays on the device (finish(with_cost) fetches it).  With a direction
   // the tile kernel may produce g.d in the same pass (p->gd_valid; not under frame sharding, where the local
   // gradient is only a partial sum).
-  int evaluate(const T* dir = nullptr) {
+  int evaluate(const T* dir = nullptr, T* at = nullptr) {  // at: the point (default x)
     evaluations++;
     const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
     p->eval_dvec = (mode == SRMAP_SHARD_FRAMES || mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) ? nullptr : dir;
@@ -674,12 +697,19 @@ struct DeviceCG {
     p->eval_pub = (!reduce_scalars && p->eval_dvec != nullptr) ? hs : nullptr;
     p->eval_pub_tag_slot = hs + 15;
     p->eval_pub_tag = tag + 1.0;
-    const int rc = shard_eval(p, comm, shard, SRMAP_TERM_ALL, x, g, st);
+    const int rc = shard_eval(p, comm, shard, SRMAP_TERM_ALL, at ? at : x, g, st);
     p->eval_dvec = nullptr;
     p->eval_pub = nullptr;
     published = p->eval_published;
     if (published) tag += 1.0;
     return rc;
+  }
+  // The evaluation queued ahead of the host's decision (run_cg: the first trial point behind the normalisation pass)
+  // turned out not to be wanted: it is not one of the solve's evaluations and nobody fetches its sums.  Its tag, if it
+  // publishes one, is simply passed over (wait_tag compares with >=).
+  void discard_speculative() {
+    evaluations--;
+    published = false;
   }
   // f and g.d of the evaluation just made, with one wait: out[0] = g.d, out[1] = f
   int fetch_f_gd(double* out) {
@@ -714,7 +744,8 @@ struct DeviceCG {
   }
   // dn = -g + beta dk (dk may be null); direction norms -> dscal[4..5] (device, all-reduced).  publish_cost: the
   // first pass of a CG run also hands {f -> hs[0], norms -> hs[8..9]} to the host (fetched by finish(0, ..., 2)).
-  int direction(const T* dk_or_null, double beta, bool publish_cost = false) {
+  // beta_dev: beta comes from the device scalar the k_beta_dots queued just before left there (one-launch scheme only)
+  int direction(const T* dk_or_null, double beta, bool publish_cost = false, const double* beta_dev = nullptr) {
     Fin f{};
     if (fused()) {
       f.gran = gran; f.out = dscal + 4;
@@ -724,8 +755,8 @@ struct DeviceCG {
         f.tag_slot = hs + 15; f.tag = tag;
       }
     }
-    if (vec()) hipLaunchKernelGGL((k_direction<T, kVec>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f);
-    else hipLaunchKernelGGL((k_direction<T, 1>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f);
+    if (vec()) hipLaunchKernelGGL((k_direction<T, kVec>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f, beta_dev);
+    else hipLaunchKernelGGL((k_direction<T, 1>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f, beta_dev);
     if (!fused()) {
       hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr,
                          (double*)nullptr, 0.0);
@@ -825,7 +856,8 @@ static void mt_step(Bracket* b, double* stp, double fp, double dp, bool* brackt,
 // trimfunction after each evaluation as mincgiteration does, optimization.cpp:17594).
 template <typename T>
 static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, double gtol,
-                       int* info, int* nfev, double trim, std::vector<double>* trace, double stp_in_x = 0.0) {
+                       int* info, int* nfev, double trim, std::vector<double>* trace, double stp_in_x = 0.0,
+                       bool pre_launched = false) {
   const double ftol = 0.001, xtol = 100 * 5E-16, stpmin = 1.0e-50, stpmax = 1.0e+50, p5 = 0.5,
                p66 = 0.66, xtrapf = 4.0;
   const int maxfev = 20;
@@ -836,8 +868,11 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
   *nfev = 0;
   // On entry the base point is cg.xk; cg.x is scratch for the trial points.  The paths that try nothing
   // still leave x = base, as mcsrch does.
-  if (*stp <= 0) return cg.copy(cg.x, cg.xk);
-  if (dginit >= 0) return cg.copy(cg.x, cg.xk);  // not a descent direction
+  // pre_launched: the evaluation at xk + stp_in_x * d is already queued (behind the pass that wrote that point)
+  if (*stp <= 0 || dginit >= 0) {  // (dginit >= 0: not a descent direction)
+    if (pre_launched) cg.discard_speculative();
+    return cg.copy(cg.x, cg.xk);
+  }
   bool brackt = false, stage1 = true;
   const double finit = *f, dgtest = ftol * dginit;
   double width = stpmax - stpmin, width1 = width / p5;
@@ -853,7 +888,9 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
         (brackt && stmax - stmin <= xtol * stmax))
       *stp = b.stx;
     // stp_in_x: cg.x already holds xk + stp_in_x * d (written by the normalisation pass); any other step is formed here
-    if (!(*nfev == 0 && stp_in_x != 0.0 && *stp == stp_in_x))
+    const bool first_in_x = *nfev == 0 && stp_in_x != 0.0 && *stp == stp_in_x;
+    if (*nfev == 0 && pre_launched && !first_in_x) { cg.discard_speculative(); pre_launched = false; }
+    if (!first_in_x)
     {
       if ((cg.n & 3) == 0)
         hipLaunchKernelGGL(k_axpy_out4<T>, dim3((unsigned)((cg.n / 4 + 255) / 256)), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
@@ -862,8 +899,10 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
         hipLaunchKernelGGL(k_axpy_out<T>, dim3(cg.blocks()), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
                            (const T*)cg.d, (T)*stp, cg.n);
     }
-    rc = cg.evaluate(cg.d);
-    if (rc) return rc;
+    if (!(first_in_x && pre_launched)) {
+      rc = cg.evaluate(cg.d);
+      if (rc) return rc;
+    }
     double h[2];
     rc = cg.fetch_f_gd(h);  // h[0] = g.d, h[1] = f
     if (rc) return rc;
@@ -926,9 +965,10 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
   const size_t n = cg.n;
   CgResult res;
   double f = 0, gg = 0;
-  int rc = cg.copy(cg.xk, cg.x);
-  if (rc) return rc;
-  rc = cg.evaluate();
+  // the start point becomes the base point xk by exchanging the two buffers (no copy); x is trial scratch from here on:
+  // every path below writes it before reading it (the trial points) or copies xk back into it (the early exits)
+  std::swap(cg.xk, cg.x);
+  int rc = cg.evaluate(nullptr, cg.xk);
   if (rc) return rc;
   // dk = -g (written as dn, swapped below), norms of dk; g.g = dk.dk comes with them
   rc = cg.direction(nullptr, 0.0, true);
@@ -957,22 +997,42 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     // d = normalised dk (linminnormalized), g.d, d.d; x = xk is not materialised: the line search writes every
     // trial point x = xk + stp * d itself
     double stp = 1.0, dginit = 0, dd = 0;
+    bool pre_launched = false, g_swapped = false;
     // the first step is lastgoodstep unless that is 0 (then it comes from the norms this pass reduces)
     const double stp_pre = (lastgoodstep != 0 && lastgoodstep >= 1.0e-50 && lastgoodstep <= 1.0e+50) ? lastgoodstep : 0.0;
     {
       if (cg.vec())
         hipLaunchKernelGGL((k_normalize_dots<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
                            (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
-                           cg.fin_host(false, nullptr, cg.hs + 8, 0), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
+                           cg.fin_host(false, nullptr, cg.hs + 8, 0, cg.hs + 12), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
                            (T)stp_pre);
       else
         hipLaunchKernelGGL((k_normalize_dots<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
                            (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
-                           cg.fin_host(false, nullptr, cg.hs + 8, 0), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
+                           cg.fin_host(false, nullptr, cg.hs + 8, 0, cg.hs + 12), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
                            (T)stp_pre);
       double h[2];
-      rc = cg.finish(2, false, false, h, 4);  // + {max|dk|, dk.dk, s1, s2} -> hs[8..11]
-      if (rc) return rc;
+      if (cg.fused()) {
+        // One-launch scheme: {g.d, d.d} arrive in hs[12..13] (+ {max|dk|, dk.dk, s1, s2} in hs[8..11]) under the pass's
+        // own tag.  The line search's first trial point is already in cg.x, so its evaluation is queued NOW, behind the
+        // pass, and runs while the host waits for these sums and decides (mcsrch tries stp first whenever g.d < 0;
+        // otherwise line_search discards the evaluation): no host round trip between the two launches.
+        const double tag_norm = cg.tag;
+        if (stp_pre != 0.0) {
+          std::swap(cg.g, cg.gp);  // gp = gradient at xk (the pass above was launched with the old pointers)
+          g_swapped = true;
+          rc = cg.evaluate(cg.d);
+          if (rc) return rc;
+          pre_launched = true;
+        }
+        rc = cg.wait_tag(tag_norm);
+        if (rc) return rc;
+        h[0] = cg.hs[12];
+        h[1] = cg.hs[13];
+      } else {
+        rc = cg.finish(2, false, false, h, 4);  // + {max|dk|, dk.dk, s1, s2} -> hs[8..11]
+        if (rc) return rc;
+      }
       dginit = h[0];
       dd = h[1];
       const double mx = cg.hs[8], s1 = cg.hs[10], s2 = cg.hs[11];
@@ -980,25 +1040,41 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     }
     if (lastgoodstep != 0) stp = lastgoodstep;
     int mcinfo = 0, nfev = 0;
-    std::swap(cg.g, cg.gp);  // gp = gradient at xk; the trial evaluations write g
-    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace, stp_pre);
+    if (!g_swapped) std::swap(cg.g, cg.gp);  // gp = gradient at xk; the trial evaluations write g
+    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace, stp_pre, pre_launched);
     if (rc) return rc;
     if (nfev == 0) std::swap(cg.g, cg.gp);  // nothing was evaluated: g stays the gradient at xk, as in mcsrch
     double betak = 0;
+    // One-launch scheme: the direction pass is queued right behind the pass that reduces the beta sums -- beta itself is
+    // formed by that pass's finishing thread (k_beta_dots) -- and runs while the host waits for the sums it needs for
+    // the stopping rules.  (mincg's periodic restart is known beforehand; `direction` was always launched before the
+    // rules are looked at.)
+    const bool chain = cg.fused();
+    const int restart = (res.its > 0 && res.its % (3 + (long long)n) == 0) ? 1 : 0;
     if (mcinfo == 1) {
       // yk = g - gp ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv
+      double* beta_dst = chain ? cg.dscal + 8 : (double*)nullptr;
       if (cg.vec())
         hipLaunchKernelGGL((k_beta_dots<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
-                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false));
+                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart);
       else
         hipLaunchKernelGGL((k_beta_dots<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
-                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false));
-      double h[3];
-      rc = cg.finish(3, false, false, h);
-      if (rc) return rc;
-      const double vv = h[0];
-      betak = dmax(0.0, dmin(h[1] / vv, h[2] / vv));
-      gg = h[1];
+                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart);
+      if (chain) {
+        const double tag_beta = cg.tag;
+        rc = cg.direction(cg.dk, 0.0, false, cg.dscal + 8);  // dn, norms of dn (device)
+        if (rc) return rc;
+        rc = cg.wait_tag(tag_beta);
+        if (rc) return rc;
+        gg = cg.hs[1];
+      } else {
+        double h[3];
+        rc = cg.finish(3, false, false, h);
+        if (rc) return rc;
+        const double vv = h[0];
+        betak = dmax(0.0, dmin(h[1] / vv, h[2] / vv));
+        gg = h[1];
+      }
     } else {
       if (cg.vec())
         hipLaunchKernelGGL((k_dot<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow,
@@ -1006,15 +1082,26 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
       else
         hipLaunchKernelGGL((k_dot<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.g, (const T*)cg.g, n, cg.ow, cg.part,
                            cg.fin_host(false));
-      double h[1];
-      rc = cg.finish(1, false, false, h);
-      if (rc) return rc;
-      gg = h[0];
+      if (chain) {
+        const double tag_gg = cg.tag;
+        rc = cg.direction(cg.dk, 0.0);  // beta = 0
+        if (rc) return rc;
+        rc = cg.wait_tag(tag_gg);
+        if (rc) return rc;
+        gg = cg.hs[0];
+      } else {
+        double h[1];
+        rc = cg.finish(1, false, false, h);
+        if (rc) return rc;
+        gg = h[0];
+      }
     }
-    if (res.its > 0 && res.its % (3 + (long long)n) == 0) betak = 0;
+    if (restart) betak = 0;
     if (mcinfo == 1 || mcinfo == 5) rstimer = rscountdownlen; else rstimer -= 1;
-    rc = cg.direction(cg.dk, betak);  // dn, norms of dn (device)
-    if (rc) return rc;
+    if (!chain) {
+      rc = cg.direction(cg.dk, betak);  // dn, norms of dn (device)
+      if (rc) return rc;
+    }
     const double lastscaledstep = stp * std::sqrt(dd);
     if (mcinfo == 1) lastgoodstep = stp * std::sqrt(dd);
     if (!std::isfinite(gg) || !std::isfinite(f)) { res.type = -8; break; }
