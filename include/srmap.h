@@ -297,7 +297,10 @@ typedef struct {
 
 /* IRLSMapSolver::Solve(initial_estimate) irls_map_solver.cpp:192-265:
  * x0 / x_out are [C][H][W] host doubles.  The iterate, gradient and CG vectors
- * stay on the GPU; only scalars cross PCIe per evaluation. */
+ * stay on the GPU; only scalars cross PCIe per evaluation.  Passes whose inputs are
+ * already on the device are queued without waiting for the host (un-sharded solves);
+ * SRMAP_SOLVER_CHAIN=0 in the environment restores the host-paced order (same
+ * arithmetic, same result bit for bit: a debugging / measurement switch). */
 int srmap_solve(srmap_problem* p, const srmap_irls_options* options,
                 const double* x0, double* x_out, srmap_solve_report* report);
 

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -573,6 +574,11 @@ struct DeviceCG {
   Owned ow{};
   bool reduce_scalars = false;  // row / channel shards: the owned-element sums are all-reduced
   bool published = false;       // the last evaluation's finish kernel published {f, g.d} + tag (fetch_f_gd just waits)
+  // chained passes (run_cg): launches whose inputs are already on the device are queued without waiting for the host.
+  // SRMAP_SOLVER_CHAIN=0 in the environment turns this off (every pass then waits for the host's answer, as up to
+  // round 3): same arithmetic, same results bit for bit -- tests/test_gpu_solve_parity.py compares the two.
+  bool chain_enabled = [] { const char* e = std::getenv("SRMAP_SOLVER_CHAIN"); return !(e && e[0] == '0'); }();
+  bool chained() const { return fused() && chain_enabled; }
   // x, g: current point and gradient; xk/dk: accepted point and direction; dn: next direction;
   // d: normalised direction; gp: the gradient at xk while the line search writes its trial gradients to g (the two
   // buffers swap; mincg's yk = g_{k+1} - g_k is formed on the fly).  The line-search base is xk itself.
@@ -1018,7 +1024,7 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
         // pass, and runs while the host waits for these sums and decides (mcsrch tries stp first whenever g.d < 0;
         // otherwise line_search discards the evaluation): no host round trip between the two launches.
         const double tag_norm = cg.tag;
-        if (stp_pre != 0.0) {
+        if (stp_pre != 0.0 && cg.chained()) {
           std::swap(cg.g, cg.gp);  // gp = gradient at xk (the pass above was launched with the old pointers)
           g_swapped = true;
           rc = cg.evaluate(cg.d);
@@ -1049,7 +1055,7 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     // formed by that pass's finishing thread (k_beta_dots) -- and runs while the host waits for the sums it needs for
     // the stopping rules.  (mincg's periodic restart is known beforehand; `direction` was always launched before the
     // rules are looked at.)
-    const bool chain = cg.fused();
+    const bool chain = cg.chained();
     const int restart = (res.its > 0 && res.its % (3 + (long long)n) == 0) ? 1 : 0;
     if (mcinfo == 1) {
       // yk = g - gp ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv
