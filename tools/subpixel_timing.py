@@ -10,6 +10,7 @@ import srmap
 W = int(sys.argv[sys.argv.index("--hr") + 1]) if "--hr" in sys.argv else 2048
 s, K = 4, 16
 rng = np.random.default_rng(1)
+torch.manual_seed(1)
 for name, frac in (("integer", False), ("sub-pixel", True)):
     shifts = [[k % s + (np.round(rng.uniform(-.5, .5) * 32) / 32 if frac else 0),
                (k // s) % s + (np.round(rng.uniform(-.5, .5) * 32) / 32 if frac else 0)] for k in range(K)]
@@ -29,4 +30,7 @@ for name, frac in (("integer", False), ("sub-pixel", True)):
     t0 = time.perf_counter(); n = 300
     for _ in range(n): p.eval_device(x.data_ptr(), g.data_ptr(), srmap.TERM_ALL)
     torch.cuda.synchronize()
-    print("%-10s shifts: %.1f us / evaluation" % (name, 1e6 * (time.perf_counter() - t0) / n))
+    dt = time.perf_counter() - t0
+    cost = p.eval_device(x.data_ptr(), g.data_ptr(), srmap.TERM_ALL, want_cost=True)
+    print("%-10s shifts: %.1f us / evaluation   (cost %r, sum g %r, sum |g| %r)" % (
+        name, 1e6 * dt / n, float(cost), float(g.sum()), float(g.abs().sum())))
