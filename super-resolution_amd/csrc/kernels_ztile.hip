@@ -58,6 +58,15 @@
 
 // Build-time switch of the measurement builds (tools/exp_build.sh); the product build does not define it.
 //   SRMAP_ZT_ONLY_CFG2  instantiate only k_eval_z<double, 4, 3, BTV, 3> (seconds instead of minutes per variant)
+//   SRMAP_EXP_NOLOAD    TIMING ONLY (results wrong by construction): every global load of a tile workgroup replaced by a
+//                       value formed in registers -- the time no prefetch scheme can beat (profiles/r05_ceiling.txt)
+//   SRMAP_EXP_NOHALO    TIMING ONLY: no halo-row / halo-column passes (what a marching band saves at best)
+#ifndef SRMAP_EXP_NOLOAD
+#define SRMAP_EXP_NOLOAD 0
+#endif
+#ifndef SRMAP_EXP_NOHALO
+#define SRMAP_EXP_NOHALO 0
+#endif
 
 namespace srmap {
 
@@ -159,7 +168,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
     const T* sb = xplane + (inb ? (size_t)grr * A.W + (size_t)gcb * S : (size_t)0);
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
+    for (int pc = 0; pc < S; ++pc) va[it][pc] = SRMAP_EXP_NOLOAD ? (T)(lane + pc + it) * A.lambda : sa[pc];
     if (!XT) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
@@ -178,28 +187,36 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const bool edge = (R0 - rm < 0) || (R0 + C::TH + rm > A.H) || (CJ0 - cm < 0) || (CJ0 + C::CW + cm > A.wl) ||
                     A.cr0 > 0 || A.cr1 < A.H;  // partial tiles (bottom / right) are edge tiles by the first two tests
   const int hrowz = wv == 0 ? -HB : C::TH - 1 + HB;  // halo rows of zh: tile rows -1 (wave 0) and TH (wave 1)
-  const bool has_z_halo = want_data && B > 1 && A.g != nullptr && wv < 2;
+  const bool has_z_halo = !SRMAP_EXP_NOHALO && want_data && B > 1 && A.g != nullptr && wv < 2;
   T ypre2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) ypre2[v] = T(0);
-  if (!SP && want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, CJ0, lane, edge, ybase, ypre);
-  if (!SP && has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
+  if (SRMAP_EXP_NOLOAD) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { ypre[v] = (T)(lane + v) * A.lambda; ypre2[v] = (T)(lane - v) * A.lambda; }
+  } else {
+    if (!SP && want_data) z_row_prefetch<T, S, B, C>(A, wv, R0, CJ0, lane, edge, ybase, ypre);
+    if (!SP && has_z_halo) z_row_prefetch<T, S, B, C>(A, hrowz, R0, CJ0, lane, edge, ybase, ypre2);
+  }
   const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
   T wreg[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
-  if (wplane != nullptr && gr < A.H && gc0 < A.W) {
+  if (SRMAP_EXP_NOLOAD) {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) wreg[pc] = (T)(lane + 2 * pc + 1) * A.lambda;
+  } else if (wplane != nullptr && gr < A.H && gc0 < A.W) {
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)gr * A.W + gc0 + pc];
   }
   // halo row of 2*lambda*w*r this wave evaluates (waves 2 .. 2+RU-1: tile rows -1 .. -RU) and its weights
-  const bool reg_halo_on = want_reg && A.g != nullptr && RU > 0;
+  const bool reg_halo_on = !SRMAP_EXP_NOHALO && want_reg && A.g != nullptr && RU > 0;
   const int hrow = -(wv - 1);  // wave 2 -> -1, wave 3 -> -2
   const bool has_reg_halo = reg_halo_on && wv >= 2 && wv < 2 + RU;
   T whalo[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) whalo[pc] = T(1);
-  if (has_reg_halo && wplane != nullptr && R0 + hrow >= 0 && gc0 < A.W) {
+  if (!SRMAP_EXP_NOLOAD && has_reg_halo && wplane != nullptr && R0 + hrow >= 0 && gc0 < A.W) {
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) whalo[pc] = wplane[(size_t)(R0 + hrow) * A.W + gc0 + pc];
   }
@@ -209,7 +226,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // and with them the workgroup's second barrier, for a memory round trip
   T wcolv = T(1);
   const bool col_task = reg_halo_on && (wv == 4 || wv == 5) && lane < C::TH + RU;
-  if (col_task && wplane != nullptr) {
+  if (!SRMAP_EXP_NOLOAD && col_task && wplane != nullptr) {
     const int hgr = R0 + lane - RU, hgc = C0 - (wv == 4 ? 1 : 2);
     if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
   }
