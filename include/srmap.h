@@ -96,7 +96,7 @@ enum {
  * 2..4, blur size 1 or 3, integer or sub-pixel shifts), else the direct
  * kernels.  TILED forces that family and fails with SRMAP_EUNSUPPORTED when it
  * does not cover the problem. */
-typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2 } srmap_impl;
+typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */
 /* Binds HIP device `device_id`.  Replaces nothing in the reference (it has no

@@ -727,50 +727,19 @@ size_t ztile_partials_needed(const srmap_problem* p) {
   return tiles + ring;
 }
 
-// in-kernel finish of this launch; publish {cost, g.d} to the solver's host words; plain partials of an earlier launch to add
-struct MFin { bool on, publish; const double* xpart; int n_xpart; };
-
 template <typename T, int S, int B, int REGK, int R>
 static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                     const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st, const T* dvec,
-                    double* partials_gd, MFin mfin) {
+                    double* partials_gd, MFin mfin, int border_only = -1) {
+  // border_only >= 0: launch the border blocks alone (the marching kernel evaluates the image; its workgroups hold the
+  // first `border_only` partials)
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
-  A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
-  A.dvec = dvec; A.partials_gd = partials_gd;
-  A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
-  for (int pr = 0; pr < 4; ++pr) {
-    for (int i = 0; i < 8; ++i) A.cntk[pr][i] = z.h_cnt[pr * 8 + i];
-    for (int pc = 0; pc < 4; ++pc) { A.off0[pr][pc] = z.h_off0[pr * 4 + pc]; A.aux0[pr][pc] = z.h_aux0[pr * 4 + pc]; }
-  }
-  A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
-  A.obs_C = p->geo.C;
-  A.E = z.E;
-  A.ring = z.ring;
-  A.cr0 = geo.cr0; A.cr1 = geo.cr1;
-  A.rr0 = geo.rr0; A.rr1 = geo.rr1;
-  A.terms = (int)terms;
-  if (B == 1) { A.blur3[0] = A.blur3[1] = A.blur3[2] = T(1); A.k1s[0] = A.k1s[1] = T(1); }
-  else {
-    const int hb = (B - 1) / 2;
-    A.blur3[0] = (T)p->blur2d[0]; A.blur3[1] = (T)p->blur2d[hb]; A.blur3[2] = (T)p->blur2d[hb * B + hb];
-    A.k1s[0] = (T)p->blur1d[0]; A.k1s[1] = (T)p->blur1d[hb];
-  }
-  A.lambda = T(0);
-  for (int i = 0; i < C::NP; ++i) A.powtab[i] = T(1);
-  if (REGK != 0) {
-    const RegSpec& rs = p->reg[z.reg_index];
-    A.lambda = (T)rs.lambda;
-    if (REGK == 2) for (int i = 0; i < C::NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
-  }
-  A.pwsum = T(0);
-  if (REGK == 2)
-    for (int i = 0; i < R; ++i)
-      for (int j = 0; j < R; ++j)
-        if (i + j > 0) A.pwsum += A.powtab[i + j];
+  fill_zargs<T, S, B, REGK, R>(A, p, geo, obs_c0, terms, x, g, wts, z, partials, dvec, partials_gd);
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
-  const int n_tile_partials = (int)(grid.x * grid.y * grid.z);
+  const int n_tile_partials = border_only >= 0 ? border_only : (int)(grid.x * grid.y * grid.z);
+  if (border_only >= 0) grid.y = 0;
   // border blocks: whole rows of the grid in front of the tiles
   A.bd = (const BorderArgs<T>*)z.d_bd;
   A.nby = 0; A.n_tile_partials = n_tile_partials;
@@ -793,6 +762,13 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.xpart = mfin.xpart; A.n_xpart = mfin.n_xpart;
   if (mfin.on && (size_t)A.n_partials > z.mpart_cap) return set_error(p->ctx, SRMAP_EHIP, "granule capacity");
   A.sel_mode = 0; A.sel0 = 0; A.sel1 = 0;
+  if (border_only >= 0) {
+    *nblocks = nbb * (int)grid.z;
+    if (nbb == 0) return SRMAP_OK;
+    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    return SRMAP_OK;
+  }
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
     A.rbuf = (const T*)p->d_resid;
     A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
@@ -866,12 +842,12 @@ void ztile_preload(const srmap_problem* p) {
 template <typename T, int S, int B>
 static int dispatch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                       const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, hipStream_t st,
-                      const T* dv, double* pgd, MFin mfin) {
-  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+                      const T* dv, double* pgd, MFin mfin, int border_only = -1) {
+  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
+  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
+  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
+  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
+  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
 }
 
 template <typename T>
@@ -929,20 +905,39 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
   mfin.xpart = (mfin.on && sp_data) ? partials - nfwd : nullptr;
   mfin.n_xpart = (mfin.on && sp_data) ? nfwd : 0;
+  // the marching kernel (kernels_zmarch.hip) where it covers the evaluation; SRMAP_IMPL_TILED keeps the 8-row tiles
+  int m_ns = 0, m_rows = 0;
+  const bool march = p->impl != SRMAP_IMPL_TILED && zmarch_covers<T>(p, geo, z, z.regk, z.regr, zterms, g, dv, &m_ns, &m_rows);  // one instance per plan: the terms are run-time switches
+  if (p->impl == SRMAP_IMPL_MARCH && !march) return set_error(p->ctx, SRMAP_EUNSUPPORTED, "the marching kernel does not cover this evaluation");
+  const int m_wgs = march ? m_ns * ((geo.H + m_rows - 1) / m_rows) * geo.C : -1;
+  auto tiles = [&](int border_only) {
 #ifdef SRMAP_ZT_ONLY_CFG2
-  if (sizeof(T) == 8 && S == 4 && B == 3 && regk == 2 && regr == 3)
-    rc = launch_z<double, 4, 3, 2, 3>(p, geo, obs_c0, zterms, (const double*)x, (double*)g, (const double*)wts, z, partials, &nb, st,
-                                      (const double*)dv, pgd, mfin);
-  else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "measurement build: cfg2 instance only");
+    if (sizeof(T) == 8 && S == 4 && B == 3 && regk == 2 && regr == 3)
+      return launch_z<double, 4, 3, 2, 3>(p, geo, obs_c0, zterms, (const double*)x, (double*)g, (const double*)wts, z, partials, &nb, st,
+                                          (const double*)dv, pgd, mfin, border_only);
+    return set_error(p->ctx, SRMAP_EUNSUPPORTED, "measurement build: cfg2 instance only");
 #else
-  if (S == 2 && B == 1) rc = dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-  else if (S == 2 && B == 3) rc = dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-  else if (S == 3 && B == 1) rc = dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-  else if (S == 3 && B == 3) rc = dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-  else if (S == 4 && B == 1) rc = dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-  else if (S == 4 && B == 3) rc = dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-  else return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
+    if (S == 2 && B == 1) return dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
+    if (S == 2 && B == 3) return dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
+    if (S == 3 && B == 1) return dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
+    if (S == 3 && B == 3) return dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
+    if (S == 4 && B == 1) return dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
+    if (S == 4 && B == 3) return dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
+    return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
 #endif
+  };
+  if (march) {
+    int nbord = 0;
+    if ((zterms & SRMAP_TERM_DATA) && z.n_ring > 0) {  // border blocks (ownerless residuals): their own launch for now
+      rc = tiles(m_wgs);
+      if (rc) return rc;
+      nbord = nb;
+    }
+    rc = launch_zmarch<T>(p, geo, obs_c0, zterms, x, g, wts, z, z.regk, z.regr, partials, &nb, st, mfin, m_ns, m_rows, nbord);
+    nb += nbord;
+  } else {
+    rc = tiles(-1);
+  }
   if (rc) return rc;
   if (sp_data) {
     partials -= nfwd;

@@ -255,7 +255,7 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
     if (rc) return rc;
     SRMAP_HIP(p->ctx, hipStreamWaitEvent(st, p->ov_event, 0));
   }
-  if (p->impl == SRMAP_IMPL_TILED && !ztile)
+  if ((p->impl == SRMAP_IMPL_TILED || p->impl == SRMAP_IMPL_MARCH) && !ztile)
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "tiled kernels do not cover this geometry");
   int nparts = 0;
   if (ztile) {
@@ -524,7 +524,7 @@ void srmap_problem_destroy(srmap_problem* p) {
 
 int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
-  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
+  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_MARCH) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
   return SRMAP_OK;
 }

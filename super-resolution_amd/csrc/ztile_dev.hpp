@@ -286,6 +286,10 @@ struct ZArgs {
   double tag;
   const double* xpart;   // plain cost partials of an EARLIER launch on the stream (sub-pixel path: the forward kernel's data
   int n_xpart;           //   cost), complete when this kernel starts: the in-kernel finish adds them, in index order
+  // ---- marching kernel (kernels_zmarch.hip): workgroup -> (strip, band) ----
+  int m_nstrips;         // strips of 64 LR cells per image row
+  int m_band_rows;       // HR rows per band (a multiple of the step height)
+  int m_nbb;             // border tasks: pixels of the border frame per workgroup (0 = none)
 };
 
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
@@ -952,5 +956,60 @@ struct ZPlan {
   size_t mpart_cap = 0;
 };
 
+
+// in-kernel finish of this launch; publish {cost, g.d} to the solver's host words; plain partials of an earlier launch to add
+struct MFin { bool on, publish; const double* xpart; int n_xpart; };
+
+// Kernel arguments shared by the tile kernel and the marching kernel (everything but the grid-dependent fields).
+template <typename T, int S, int B, int REGK, int R>
+static void fill_zargs(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>& A, srmap_problem* p, const Geometry& geo, int obs_c0,
+                       unsigned terms, const T* x, T* g, const T* wts, const ZPlan& z, double* partials, const T* dvec,
+                       double* partials_gd) {
+  using C = ZCfg<T, S, B, REGK, R>;
+  A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
+  A.dvec = dvec; A.partials_gd = partials_gd;
+  A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
+  for (int pr = 0; pr < 4; ++pr) {
+    for (int i = 0; i < 8; ++i) A.cntk[pr][i] = z.h_cnt[pr * 8 + i];
+    for (int pc = 0; pc < 4; ++pc) { A.off0[pr][pc] = z.h_off0[pr * 4 + pc]; A.aux0[pr][pc] = z.h_aux0[pr * 4 + pc]; }
+  }
+  A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h;
+  A.obs_C = p->geo.C;
+  A.E = z.E;
+  A.ring = z.ring;
+  A.cr0 = geo.cr0; A.cr1 = geo.cr1;
+  A.rr0 = geo.rr0; A.rr1 = geo.rr1;
+  A.terms = (int)terms;
+  if (B == 1) { A.blur3[0] = A.blur3[1] = A.blur3[2] = T(1); A.k1s[0] = A.k1s[1] = T(1); }
+  else {
+    const int hb = (B - 1) / 2;
+    A.blur3[0] = (T)p->blur2d[0]; A.blur3[1] = (T)p->blur2d[hb]; A.blur3[2] = (T)p->blur2d[hb * B + hb];
+    A.k1s[0] = (T)p->blur1d[0]; A.k1s[1] = (T)p->blur1d[hb];
+  }
+  A.lambda = T(0);
+  for (int i = 0; i < C::NP; ++i) A.powtab[i] = T(1);
+  if (REGK != 0) {
+    const RegSpec& rs = p->reg[z.reg_index];
+    A.lambda = (T)rs.lambda;
+    if (REGK == 2) for (int i = 0; i < C::NP; ++i) A.powtab[i] = (T)rs.pow_table[i];
+  }
+  A.pwsum = T(0);
+  if (REGK == 2)
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < R; ++j)
+        if (i + j > 0) A.pwsum += A.powtab[i + j];
+  A.m_nstrips = 0; A.m_band_rows = 0; A.m_nbb = 0;
+}
+
+// ---- marching kernel (kernels_zmarch.hip) ----
+// Whether k_eval_m covers this evaluation; *nstrips / *band_rows: its decomposition.
+template <typename T>
+bool zmarch_covers(const srmap_problem* p, const Geometry& geo, const ZPlan& z, int regk, int regr, unsigned terms,
+                   const T* g, const T* dvec, int* nstrips, int* band_rows);
+template <typename T>
+int launch_zmarch(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g, const T* wts,
+                  const ZPlan& z, int regk, int regr, double* partials, int* nblocks, hipStream_t st, MFin mfin,
+                  int nstrips, int band_rows, int n_border_partials);
+void zmarch_preload();
 
 }  // namespace srmap

@@ -16,7 +16,7 @@ OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
 REG_TV, REG_TV3D, REG_BTV = 0, 1, 2
 TERM_DATA, TERM_REG, TERM_ALL = 1, 2, 3
-IMPL_AUTO, IMPL_DIRECT, IMPL_TILED = 0, 1, 2
+IMPL_AUTO, IMPL_DIRECT, IMPL_TILED, IMPL_MARCH = 0, 1, 2, 3
 
 c_double_p = C.POINTER(C.c_double)
 
