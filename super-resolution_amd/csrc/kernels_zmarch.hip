@@ -140,7 +140,11 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
     const bool full = gr >= br0 && gr < br1;
     const bool z_slow = (zrow - rm < 0) || (zrow + 1 + rm > A.H) || col_edge;
     const bool r_slow = (gr + 1 + WIN > A.H) || col_border || gr < 0;
+#ifdef SRMAP_EXP_MFAST   // TIMING ONLY: every row through the interior path (wrong at the image border)
+    const bool slow = false; (void)z_slow; (void)r_slow;
+#else
     const bool slow = z_slow || r_slow;
+#endif
     T ypre[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) ypre[v] = T(0);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
       int cn[S];
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-      if (slow) load_obs_row<T, S, ZC, true>(A, pr, rc, 0, CJ0, lane, ybase, cn, ypre);
+      if (z_slow || slow) load_obs_row<T, S, ZC, true>(A, pr, rc, 0, CJ0, lane, ybase, cn, ypre);
       else load_obs_row<T, S, ZC, false>(A, pr, rc, 0, CJ0, lane, ybase, cn, ypre);
     }
     T wreg[S];

@@ -907,7 +907,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   mfin.n_xpart = (mfin.on && sp_data) ? nfwd : 0;
   // the marching kernel (kernels_zmarch.hip) where it covers the evaluation; SRMAP_IMPL_TILED keeps the 8-row tiles
   int m_ns = 0, m_rows = 0;
-  const bool march = p->impl != SRMAP_IMPL_TILED && zmarch_covers<T>(p, geo, z, z.regk, z.regr, zterms, g, dv, &m_ns, &m_rows);  // one instance per plan: the terms are run-time switches
+  const bool march = p->impl == SRMAP_IMPL_MARCH && zmarch_covers<T>(p, geo, z, z.regk, z.regr, zterms, g, dv, &m_ns, &m_rows);  // one instance per plan: the terms are run-time switches
   if (p->impl == SRMAP_IMPL_MARCH && !march) return set_error(p->ctx, SRMAP_EUNSUPPORTED, "the marching kernel does not cover this evaluation");
   const int m_wgs = march ? m_ns * ((geo.H + m_rows - 1) / m_rows) * geo.C : -1;
   auto tiles = [&](int border_only) {
