@@ -10,6 +10,13 @@
 //     bit-identical to (x[p] - x[q]) * 2^Q of the pre-scaled tile (scaling by a power of two commutes with rounding).
 //   * halo rows of zh / 2*lambda*w*r are evaluated once per BAND (a "virtual step" in front of the first one), not
 //     per 8 rows; a workgroup's launch, argument fetch and address arithmetic are paid once per band.
+//   * the image border costs no second code path: the plan admits frame offsets in [-(S-1), 0] only (the sign convention
+//     of MotionShiftSequence; everything else stays with the tile kernel), for which the reference's per-stage clips
+//     (SURVEY.md section 8a') reduce to (a) zero-filled x outside the image -- the requests simply skip those cells --,
+//     (b) residuals that do not exist: LR row -1 / hl (uniform per wave row) and LR column -1 / wl (lane 0 / 63 of the
+//     first / last strip), (c) window taps of the regulariser beyond the right / bottom edge.  (b) and (c) are handled by
+//     a few selects in the FIX instances of phase 1; filter2D's dropped blur taps of LR row / column 0 fall on
+//     zero-filled x and need nothing.
 #pragma once
 #include "ztile_dev.hpp"
 
@@ -40,7 +47,7 @@ struct MCfg {
   static constexpr int CCL = Z::CCL, CC = Z::CC;
   static constexpr int CRG = PL * CC;
   static constexpr int NCR = REGK ? SR + RU : 1;
-  static constexpr int VW = zmax(RU, (B > 1) ? 2 : 0);  // waves of the virtual step: SR - VW .. SR - 1
+  static constexpr int VW = zmax(RU, HB + ZA);    // waves of the virtual step: SR - VW .. SR - 1
   // pixel windows (relative to the first pixel of the thread's cell)
   static constexpr int P1LO = (B > 1) ? -2 * HB : 0, P1HI = zmax(S - 1 + WIN, S - 1 + 2 * HB);
   static constexpr int P2LO = -RU, P2HI = S - 1;
@@ -71,88 +78,101 @@ __device__ __forceinline__ int mwrap(int v) { return v >= N ? v - N : v; }   // 
 template <int N>
 __device__ __forceinline__ int mwrapn(int v) { return v < 0 ? v + N : v; }   // v in [-N, N)
 
-// sgn / step of a pre-scaled difference, as in ztile_dev.hpp
 template <typename T> __device__ __forceinline__ T m_scale() { return Pre<T>::up(T(1)); }
+
+// What phase 1 of one wave row has to know beyond the interior case (all wave-uniform but mr / lane tests).
+struct P1Ctl {
+  bool do_z, do_r;     // evaluate the data / regulariser part (ALLON instances: both true at compile time)
+  bool count_z;        // the residual row belongs to this band (its cost is counted here)
+  bool full;           // the regulariser row belongs to this band (self term, cost); else 2*lambda*w*r only (halo rows)
+  int rclass;          // residual row: 0 every entry exists, 1 LR row -1 (only io == 1), 2 last LR row (only io == 0), 3 none
+  int io_bits, jo_bits;  // round 0 of the frame table for this wave's row phase: bit pc = io / jo of column phase pc
+  bool strip0, lastst; // first / last strip of the image row
+  int gr, H;
+};
 
 // ---- phase 1 of one wave: regulariser pass 1 for HR row gr and data term (B x, residuals, z, horizontal half of B^T)
 // for HR row zrow = gr + ZA, from the SAME window rows (x rows gr .. gr + WIN).
 //   xb[i]   first granule (+ lane) of x row gr + i
 //   zdst    first granule (+ lane) of the zh row's slot,  cdst: of the 2*lambda*w*r row's slot
-//   do_z / do_r   this wave evaluates the data / regulariser part (uniform)
-//   count_z       the residual row belongs to this band (its cost is counted here)
-//   full          regulariser row belongs to this band (self term, cost); else only 2*lambda*w*r (halo rows)
-// SLOW: rows / strips at the image border -- LR validity masks, dropped blur taps of LR row / column 0, window taps
-// outside the image (the EDGE / BORDER paths of ztile_dev.hpp).
-template <typename T, int S, int B, int REGK, int R, bool SLOW, typename ArgsT>
+//   SCm     2^Q, but 0 in lane 63 of the last strip: window taps that cross into the next cell form their difference
+//           with it (and with x0 * SCm), so they come out as the reference's skipped tap -- a zero difference
+// FIX: rows / strips at the image border (see the head of this file).  ALLON: both parts, every row inside the band.
+template <typename T, int S, int B, int REGK, int R, bool FIX, bool ALLON, typename ArgsT>
 __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&xb)[MCfg<T, S, B, REGK, R>::WIN + 1],
                                          typename Gran<T, 16 / (int)sizeof(T)>::type* zdst,
-                                         typename Gran<T, 16 / (int)sizeof(T)>::type* cdst, bool do_z, bool do_r, bool count_z,
-                                         bool full, bool cost_row, int gr, int zrow, int CJ0, int lane,
-                                         const T* __restrict__ ybase, const T (&ypre)[MCfg<T, S, B, REGK, R>::NV],
-                                         const T (&wv)[S], T (&acc)[S], T (&zown)[S], double& cost_data, double& cost_reg) {
+                                         typename Gran<T, 16 / (int)sizeof(T)>::type* cdst, const P1Ctl& ctl, int lane,
+                                         const T SCm, const T (&ypre)[MCfg<T, S, B, REGK, R>::NV], const T (&wv)[S],
+                                         T (&acc)[S], T (&zown)[S], double& cost_data, double& cost_reg) {
   using C = MCfg<T, S, B, REGK, R>;
-  using ZC = typename C::Z;
   using GT = typename Gran<T, C::G>::type;
   constexpr int HB = C::HB, NV = C::NV, WIN = C::WIN, G = C::G, PL = C::PL;
-  const int gc0 = (CJ0 + lane) * S;
+  const bool do_z = ALLON || ctl.do_z, do_r = ALLON || ctl.do_r;
   const T SC = m_scale<T>();
-  T bx[NV], btop[NV], bleft[NV], bcorner[NV];
+  T bx[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) { bx[v] = T(0); btop[v] = T(0); bleft[v] = T(0); bcorner[v] = T(0); }
-  T x0s[S], rv[S], dv[S];
+  for (int v = 0; v < NV; ++v) bx[v] = T(0);
+  T x0s[S], x0m[S], rv[S], dv[S];
 #pragma unroll
-  for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); x0s[pc] = T(0); }
+  for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); x0s[pc] = T(0); x0m[pc] = T(0); }
+#ifndef SRMAP_EXP_MSPLIT
+#define SRMAP_EXP_MSPLIT 0
+#endif
   constexpr int NROW = zmax(WIN + 1, B);
+  constexpr int NPASS = SRMAP_EXP_MSPLIT ? 2 : 1;   // 2: the window rows are read twice, data term first (fewer live registers)
 #pragma unroll
-  for (int i = 0; i < NROW; ++i) {
-    PWin<T, S, C::XC, C::XCL, C::P1LO, C::P1HI> w;
-    w.load(xb[i < WIN + 1 ? i : WIN]);
-    if (i < B && do_z) {  // blur row a = i of the residual row zrow (x row zrow - HB + a = gr + i when ZA == HB)
-      constexpr int dummy = 0; (void)dummy;
-      const int a = i;
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const bool pz = NPASS == 1 || pass == 0, prg = NPASS == 1 || pass == 1;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
+    for (int i = 0; i < NROW; ++i) {
+      if (NPASS == 2 && pass == 0 && i >= B) continue;
+      if (NPASS == 2 && pass == 1 && i > WIN) continue;
+      PWin<T, S, C::XC, C::XCL, C::P1LO, C::P1HI> w;
+      w.load(xb[i < WIN + 1 ? i : WIN]);
+      if (pz && i < B && do_z) {  // blur row a = i of the residual row (x row zrow - HB + a = gr + i)
 #pragma unroll
-        for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, a, e) * w.at(v + e - 2 * HB);
-        if (SLOW && B > 1) {
-          bleft[v] += blur_tap<B>(A, a, 0) * w.at(v - 2 * HB);
-          if (a == 0) {
+        for (int v = 0; v < NV; ++v) {
 #pragma unroll
-            for (int e = 0; e < B; ++e) btop[v] += blur_tap<B>(A, 0, e) * w.at(v + e - 2 * HB);
-            bcorner[v] = blur_tap<B>(A, 0, 0) * w.at(v - 2 * HB);
-          }
+          for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, i, e) * w.at(v + e - 2 * HB);
         }
       }
-    }
-    if (REGK != 0 && i <= WIN && do_r) {
-      if (i == 0) {
+      if (FIX && prg && REGK == 2 && sizeof(T) == 8 && i < R && i <= WIN && do_r && ctl.gr + i >= ctl.H) {
+        // window row below the image: its taps are the reference's skipped taps = zero differences; the self term in
+        // its (sgn + 1) / 2 form still counts them with 1/2 each (the same additions as the tile kernel's masked path)
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) x0s[pc] = w.at(pc) * SC;
+        for (int pc = 0; pc < S; ++pc) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) dv[pc] += A.powtab[i + j] * T(0.5);
+        }
       }
+      if (prg && REGK != 0 && i <= WIN && do_r && (!FIX || ctl.gr + i < ctl.H)) {  // window rows below the image: skipped taps
+        if (i == 0) {
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) {
-        if (REGK == 2) {
+          for (int pc = 0; pc < S; ++pc) { x0s[pc] = w.at(pc) * SC; x0m[pc] = w.at(pc) * SCm; }
+        }
 #pragma unroll
-          for (int j = 0; j <= R; ++j) {
-            if (i == 0 && j == 0) continue;
-            T d = __builtin_fma(-SC, w.at(pc + j), x0s[pc]);   // (x[p] - x[q]) * 2^Q, one rounding
-            if (SLOW) d = ((gr + i < A.H) && (gc0 + pc + j < A.W)) ? d : T(0);
-            rv[pc] += A.powtab[i + j] * absv(d);
-            if (i < R && j < R) {
-              if (sizeof(T) == 8) dv[pc] += A.powtab[i + j] * step_pre<T>(d);
-              else dv[pc] += sgn_pre<T>(d, A.powtab[i + j]);
+        for (int pc = 0; pc < S; ++pc) {
+          if (REGK == 2) {
+#pragma unroll
+            for (int j = 0; j <= R; ++j) {
+              if (i == 0 && j == 0) continue;
+              // (x[p] - x[q]) * 2^Q, one rounding; taps into the next cell through the masked scale
+              const T d = (FIX && pc + j >= S) ? __builtin_fma(-SCm, w.at(pc + j), x0m[pc]) : __builtin_fma(-SC, w.at(pc + j), x0s[pc]);
+              rv[pc] += A.powtab[i + j] * absv(d);
+              if (i < R && j < R) {
+                if (sizeof(T) == 8) dv[pc] += A.powtab[i + j] * step_pre<T>(d);
+                else dv[pc] += sgn_pre<T>(d, A.powtab[i + j]);
+              }
             }
+          } else if (i == 1) {
+            const T dyv = __builtin_fma(SC, w.at(pc), -x0s[pc]);
+            rv[pc] = absv(dyv) + rv[pc];
+            dv[pc] = dv[pc] - sgn_pre<T>(dyv, T(1));
+          } else if (i == 0) {
+            const T dxv = (FIX && pc + 1 >= S) ? __builtin_fma(SCm, w.at(pc + 1), -x0m[pc]) : __builtin_fma(SC, w.at(pc + 1), -x0s[pc]);
+            rv[pc] = absv(dxv);
+            dv[pc] = -sgn_pre<T>(dxv, T(1));
           }
-        } else if (i == 1) {
-          T dyv = __builtin_fma(SC, w.at(pc), -x0s[pc]);
-          if (SLOW) dyv = (gr + 1 < A.H) ? dyv : T(0);
-          rv[pc] = absv(dyv) + rv[pc];
-          dv[pc] = dv[pc] - sgn_pre<T>(dyv, T(1));
-        } else if (i == 0) {
-          T dxv = __builtin_fma(SC, w.at(pc + 1), -x0s[pc]);
-          if (SLOW) dxv = (gc0 + pc + 1 < A.W) ? dxv : T(0);
-          rv[pc] = absv(dxv);
-          dv[pc] = -sgn_pre<T>(dxv, T(1));
         }
       }
     }
@@ -160,19 +180,26 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
   // ---- regulariser: 2*lambda*w*r, self term, cost (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
   if (REGK != 0 && do_r) {
     T cr2v[S];
+    const bool full = ALLON || ctl.full;
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
       const T r = Pre<T>::down(rv[pc]);
       const T c = A.lambda * wv[pc];
-      T cr2 = T(2) * c * r;
-      const bool in_img = (unsigned)gr < (unsigned)A.H && (unsigned)(gc0 + pc) < (unsigned)A.W;
+      const T cr2 = T(2) * c * r;
       if (REGK == 2 && sizeof(T) == 8) dv[pc] = T(2) * dv[pc] - A.pwsum;
-      const T selfv = cr2 * dv[pc];
-      acc[pc] += full ? selfv : T(0);
-      const double cd = (in_img && cost_row && full) ? (double)c * (double)r * (double)r : 0.0;
-      cost_reg += cd;
-      if (!in_img || (REGK == 2 && gr == 0 && gc0 + pc == 0)) cr2 = T(0);
+      if (full) {  // uniform
+        acc[pc] += cr2 * dv[pc];
+        cost_reg += (double)c * (double)r * (double)r;
+      }
       cr2v[pc] = cr2;
+    }
+    if (FIX) {
+      if (ctl.gr < 0) {  // rows above the image (halo rows of the top band)
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) cr2v[pc] = T(0);
+      }
+      // the absolute pixel (0,0) is skipped as a source (btv_regularizer.cpp:143-146)
+      if (REGK == 2 && ctl.gr == 0 && ctl.strip0) cr2v[0] = (lane == 0) ? T(0) : cr2v[0];
     }
 #pragma unroll
     for (int pl = 0; pl < PL; ++pl) {
@@ -184,67 +211,28 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
   }
   // ---- data term: residuals of the frames whose LR grid hits each pixel (objective_data_term.cpp:15-75) ----
   if (do_z) {
-    int rc, pr;
-    row_phase<S>(zrow, rc, pr);
-    int cn[S];
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) cn[pc] = A.cntk[pr][pc];
-    const int mmax = A.cntk[pr][S];
-    const int mfull = SLOW ? 0 : A.cntk[pr][S + 1];
     T z[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) z[v] = T(0);
-    for (int t = 0; t < mmax; ++t) {
-      T yv[NV];
-      if (t == 0) {
+    double cz = 0.0;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) yv[v] = ypre[v];
-      } else {
-        load_obs_row<T, S, ZC, SLOW>(A, pr, rc, t, CJ0, lane, ybase, cn, yv);
+    for (int v = 0; v < NV; ++v) {
+      const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+      const bool own = pcv >= 0 && pcv < S;
+      T rr = bx[v] - ypre[v];
+      if (FIX) {
+        const int io = (ctl.io_bits >> pc) & 1, jo = (ctl.jo_bits >> pc) & 1;
+        const bool ok_u = ctl.rclass == 0 || (ctl.rclass == 1 && io == 1) || (ctl.rclass == 2 && io == 0);  // uniform
+        bool bad = !ok_u;
+        if (dc < 0) bad = bad || (ctl.strip0 && jo == 0 && lane == 0);                 // LR column -1
+        if (dc > 0) bad = bad || (ctl.lastst && lane == 63);                            // LR column >= wl
+        if (dc == 0) bad = bad || (ctl.lastst && jo == 1 && lane == 63);
+        rr = bad ? T(0) : rr;
       }
-      if (!SLOW && t < mfull) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int pcv = v - HB;
-          const T rr = bx[v] - yv[v];
-          z[v] += rr;
-          if (pcv >= 0 && pcv < S && count_z) cost_data += (double)rr * (double)rr;
-        }
-        continue;
-      }
-      const size_t slot = (size_t)(t * S + pr) * S;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-        const bool own = pcv >= 0 && pcv < S;
-        if (t < cn[pc]) {  // uniform
-          T rr;
-          if (!SLOW) {
-            rr = bx[v] - yv[v];
-            z[v] += rr;
-            if (own && count_z) cost_data += (double)rr * (double)rr;
-          } else {
-            const ZEntry e = (t == 0) ? aux0_at(A, pr, pc) : ctab(A.aux, slot + pc);
-            const int i = rc + e.io, j = CJ0 + lane + dc + e.jo;
-            T bxv = bx[v];
-            if (B > 1) {
-              // filter2D's zero padding acts on the warped image: LR row 0 loses blur tap row 0, LR column 0 tap column 0
-              const bool j0 = j == 0;
-              if (i == 0) bxv = bxv - btop[v] - (j0 ? bleft[v] - bcorner[v] : T(0));
-              else bxv = bxv - (j0 ? bleft[v] : T(0));
-            }
-            rr = bxv - yv[v];
-            rr = ((unsigned)i < (unsigned)A.hl && (unsigned)j < (unsigned)A.wl) ? rr : T(0);  // no such LR pixel
-            z[v] += rr;
-            if (own && count_z && S * i >= A.cr0 && S * i < A.cr1) {
-              const bool in_img = zrow < A.H && gc0 + (own ? pcv : 0) < A.W;
-              const double rd = (double)(in_img ? rr : T(0));
-              cost_data += rd * (double)rr;
-            }
-          }
-        }
-      }
+      z[v] += rr;
+      if (own) cz += (double)rr * (double)rr;
     }
+    if (ctl.count_z) cost_data += cz;  // uniform
     if (B == 1) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) zown[pc] = z[pc];
@@ -311,7 +299,7 @@ __device__ __forceinline__ void m_phase2(const ArgsT& A, const typename Gran<T, 
                                          const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&zb)[B], bool want_data, bool want_reg,
                                          const T (&zown)[S], T (&acc)[S]) {
   using C = MCfg<T, S, B, REGK, R>;
-  constexpr int RU = C::RU, G = C::G;
+  constexpr int RU = C::RU;
   const T SC = m_scale<T>();
   if (want_data) {
     const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
