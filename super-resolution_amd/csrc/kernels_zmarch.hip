@@ -23,6 +23,12 @@
 #ifndef SRMAP_EXP_MDBG
 #define SRMAP_EXP_MDBG 0
 #endif
+// SRMAP_EXP_MCLOCK: TIMING ONLY -- lanes 0 / 1 of every wave overwrite their gradient pixels of a row with the s_memtime
+// stamps of the step's phase boundaries (tools/march_clock.py reads them back out of g)
+#ifndef SRMAP_EXP_MCLOCK
+#define SRMAP_EXP_MCLOCK 0
+#endif
+#define MSTAMP(k) do { if (SRMAP_EXP_MCLOCK) stamp[k] = (double)(long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 namespace srmap {
 
@@ -40,17 +46,56 @@ __device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)
 // workgroup barrier for LDS traffic only (no release fence over global memory: the g stores stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The numeric constants a phase needs, fetched from the kernel-argument segment AT THE START OF THAT PHASE through a
+// pointer the compiler cannot see through: read from the by-value argument they were hoisted out of the step loop and
+// held in ~40 scalar registers across it -- with the loop's own state that was 70 - 90 spilled SGPRs, a chain of
+// v_writelane / v_readlane at the head of every step.
+template <typename T, int B, int NP>
+struct MKonst {
+  T blur3[3], k1s[2], lambda, powtab[NP], pwsum;
+  int W, H;
+};
+typedef const char __attribute__((address_space(4))) * kptr_t;
+template <typename U>
+__device__ __forceinline__ U kload(kptr_t kp, size_t off) {
+  typedef const U __attribute__((address_space(4))) * CP;
+  return *(CP)(kp + off);
+}
+template <typename T, int B, int NP, typename ArgsT>
+__device__ __forceinline__ MKonst<T, B, NP> load_konst(kptr_t kp) {
+  asm volatile("" : "+s"(kp));
+  MKonst<T, B, NP> K;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) K.blur3[i] = kload<T>(kp, offsetof(ArgsT, blur3) + i * sizeof(T));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) K.k1s[i] = kload<T>(kp, offsetof(ArgsT, k1s) + i * sizeof(T));
+  K.lambda = kload<T>(kp, offsetof(ArgsT, lambda));
+#pragma unroll
+  for (int i = 0; i < NP; ++i) K.powtab[i] = kload<T>(kp, offsetof(ArgsT, powtab) + i * sizeof(T));
+  K.pwsum = kload<T>(kp, offsetof(ArgsT, pwsum));
+  K.W = kload<int>(kp, offsetof(ArgsT, W));
+  K.H = kload<int>(kp, offsetof(ArgsT, H));
+  return K;
+}
+
 template <typename T, int S, int B, int REGK, int R, bool WD>
 __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
   using C = MCfg<T, S, B, REGK, R>;
   using GT = typename Gran<T, C::G>::type;
+  using ArgsT = ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>;
+  using KT = MKonst<T, B, C::NP>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU, WIN = C::WIN, SR = C::SR, G = C::G, ZA = C::ZA;
+  const kptr_t kargs = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   static_assert(SR % S == 0, "a wave keeps its row phase from step to step");
   __shared__ GT xs[C::NXR * C::XRG];
   __shared__ GT zs[C::NZR * C::ZRG];
   __shared__ GT cs[C::NCR * C::CRG];
+  __shared__ GT hs[C::NHR];   // left halo columns of 2*lambda*w*r: one granule (the neighbour cell's last pixels) per row
   __shared__ double red[2][C::NW];
 
+  double ostamp[6] = {0, 0, 0, 0, 0, 0};
+#define OSTAMP(k) do { if (SRMAP_EXP_MCLOCK) ostamp[k] = (double)(long long)__builtin_amdgcn_s_memtime(); } while (0)
+  OSTAMP(0);
   const int lane0 = threadIdx.x & 63;
   const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int lane = lane0, wv = wv0;
@@ -122,7 +167,7 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
     }
     for (int q = wv; q < C::XWIN; q += C::NW) request_row(br0 - C::XLO + q, q);
     // first strip: the left halo columns of 2*lambda*w*r lie outside the image -- zero once, no column task
-    if (REGK != 0 && strip0 && threadIdx.x < C::NCR * C::PL) cs[(threadIdx.x / C::PL) * C::CRG + (threadIdx.x % C::PL) * C::CC] = zv;
+    if (threadIdx.x < C::NHR) hs[threadIdx.x] = zv;
   }
 
   // ---- per-wave constants: the row phase of the wave's residual row never changes (SR % S == 0) ----
@@ -135,156 +180,266 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
     io_bits |= (A.aux0[pr][pc].io & 1) << pc;
     jo_bits |= (A.aux0[pr][pc].jo & 1) << pc;
   }
-  T acc[S], zown[S];
-  double cost_data = 0.0, cost_reg = 0.0;
-  vm_wait_all();
-  lds_barrier();
-
-  // ring positions of this wave's rows, advanced by SR per step: x row r -> (16 n + wv + XLO) mod NXR, zh row r + ZA
-  // -> (16 n + wv + ZA + HB) mod NZR, 2*lambda*w*r row r -> (16 n + wv + RU) mod NCR
-  int sx = mwrapn<C::NXR>(wv - SR + C::XLO), sz = mwrapn<C::NZR>(wv - SR + ZA + HB), sc = mwrapn<C::NCR>(wv - SR + RU);
-  int sxn = (C::XWIN + wv) % C::NXR;        // slot of the row this wave requests for the next step
-  int nrow = br0 - C::XLO + C::XWIN + wv;   // and its HR row
+  // residuals that do not exist, as bits over the thread's NV pixel slots: entries of LR row rc + 1 (io == 1), of LR cell
+  // + 1 (jo == 1) among the own pixels; lane 0 of the first strip loses slot 0 when its entry has jo == 0 (LR column -1),
+  // lane 63 of the last strip its last slot and the own slots with jo == 1 (LR column wl)
+  int m_io1 = 0, m_jo1own = 0;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int pcv = v - HB, pc = posmod(pcv, S);
+    m_io1 |= ((io_bits >> pc) & 1) << v;
+    if (pcv >= 0 && pcv < S) m_jo1own |= ((jo_bits >> pc) & 1) << v;
+  }
+  const int c_lane0 = (strip0 && HB > 0 && ((jo_bits >> (S - 1)) & 1) == 0) ? 1 : 0;
+  const int c_lane63 = lastst ? (m_jo1own | (HB > 0 ? (1 << (NV - 1)) : 0)) : 0;
+  const bool edge_strip = strip0 || lastst;
   const bool terms_all = want_data && want_reg;
+  const int H = A.H;
 
-  for (int n = -1; n < nsteps; ++n) {
-    // Everything below that depends only on the lane / the wave index is RE-DERIVED per step: the values are made
-    // opaque here so that the compiler cannot hoist those computations out of the loop -- hoisted, they became dozens of
-    // loop-carried registers, the allocator's spill candidates (scratch round trips in front of the requests,
-    // v_writelane / v_readlane chains at the head of every step).
-    asm volatile("" : "+v"(lane));
-    asm volatile("" : "+s"(wv));
-    const unsigned gcoff = (unsigned)(C0 + S * lane);
-    const int r0 = br0 + SR * n;
-    const int gr = r0 + wv, zrow = gr + ZA;
-    const bool virt = n < 0;
-    // ---- head: next step's new x rows straight into LDS; this step's observations and weights into registers ----
-    if (!virt) {
-      if (n + 1 < nsteps && !(SRMAP_EXP_MDBG & 16)) request_row(nrow, sxn);
-      nrow += SR;
-      sxn = mwrap<C::NXR>(sxn + SR);
-    }
-    const T SCm = (lastst && lane == 63) ? T(0) : m_scale<T>();
-    P1Ctl ctl;
-    // residual rows br0 - HB .. br1 - 1 + HB, regulariser rows br0 - RU .. br1 - 1
-    ctl.do_z = want_data && (!virt || wv >= SR - (HB + ZA));
-    ctl.do_r = want_reg && (!virt || wv >= SR - RU);
-    ctl.count_z = zrow >= br0 && zrow < br1;
-    ctl.full = !virt;
-    ctl.rclass = zrow < 0 ? 1 : (zrow >= A.H ? 3 : (zrow >= A.H - S ? 2 : 0));
-    ctl.io_bits = io_bits; ctl.jo_bits = jo_bits;
-    ctl.strip0 = strip0; ctl.lastst = lastst;
-    ctl.gr = gr; ctl.H = A.H;
-    const bool need_fix = strip0 || lastst || ctl.rclass != 0 || gr < 0 || gr + WIN >= A.H;
-    T ypre[NV];
-    T dbgv[S] = {};
+  // Inputs of one wave row through registers: observations of residual row zrow (round 0 of the frame table), IRLS
+  // weights of regulariser row gr.  FIXR: rows / strips at the image border -- entries without an LR row get any valid
+  // address, element indices are clamped into the LR row (phase 1 masks those values).
+  auto load_inputs = [&](int gr, bool do_z, bool do_r, bool fixr, T (&ypre)[NV], T (&wreg)[S]) {
+    const int zrow = gr + ZA;
 #pragma unroll
     for (int v = 0; v < NV; ++v) ypre[v] = T(0);
-    if (ctl.do_z && !(SRMAP_EXP_MDBG & 1)) {
-      const int rc = (zrow >= 0) ? zrow / S : -((-zrow + S - 1) / S);
-      const long long yrow = (long long)rc * A.wl + CJ0;
-      const T* yp[S];
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) {
-        const int io = (io_bits >> pc) & 1;
-        const bool ok_u = ctl.rclass == 0 || (ctl.rclass == 1 && io == 1) || (ctl.rclass == 2 && io == 0);
-        yp[pc] = (ok_u && !(SRMAP_EXP_MDBG & 32)) ? ybase + (yoff[pc] + yrow) : ybase + (CJ0 + 1);   // no such LR row: any address that stays valid under the +-1 below
-        if (SRMAP_EXP_MDBG & 128) dbgv[pc] = (T)(yoff[pc] + yrow) + (ok_u ? T(0) : T(0.5));   // an entry without LR row: any valid address
-      }
-      // every address stays inside its LR row [0, wl): the element index lane + dc is clamped to [-jo, wl - 1 - jo - CJ0]
-      // (the values of clamped lanes are masked in phase 1: no such LR pixel)
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-        const int jo = (jo_bits >> pc) & 1;
-        const unsigned hi = lastst ? (unsigned)(63 - jo - (dc > 0 ? 1 : 0)) : 63u;   // uniform
-        unsigned idx = (unsigned)lane < hi ? (unsigned)lane : hi;
-        if (dc < 0) idx = (unsigned)lane + ((strip0 && jo == 0 && lane == 0) ? 1u : 0u);
-        ypre[v] = (SRMAP_EXP_MDBG & 64) ? yp[pc][(unsigned)lane] : (yp[pc] + dc)[idx];
-      }
-    }
-    T wreg[S];
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
-    if (ctl.do_r && wplane != nullptr && gr >= 0 && !(SRMAP_EXP_MDBG & 2)) {
+    if (do_z) {
+      const int rc = (zrow >= 0) ? zrow / S : -((-zrow + S - 1) / S);
+      const long long yrow = (long long)rc * A.wl + CJ0;
+      if (!fixr) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+          ypre[v] = (ybase + (yoff[pc] + yrow) + dc)[(unsigned)lane];
+        }
+      } else {
+        const int rclass = zrow < 0 ? 1 : (zrow >= H ? 3 : (zrow >= H - S ? 2 : 0));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
+          const int io = (io_bits >> pc) & 1, jo = (jo_bits >> pc) & 1;
+          const bool ok_u = rclass == 0 || (rclass == 1 && io == 1) || (rclass == 2 && io == 0);
+          const T* yp = ok_u ? ybase + (yoff[pc] + yrow) : ybase + (CJ0 + 1);   // no such LR row: any address valid under +-1
+          const unsigned hi = lastst ? (unsigned)(63 - jo - (dc > 0 ? 1 : 0)) : 63u;   // uniform
+          unsigned idx = (unsigned)lane < hi ? (unsigned)lane : hi;
+          if (dc < 0) idx = (unsigned)lane + ((strip0 && jo == 0 && lane == 0) ? 1u : 0u);
+          ypre[v] = (yp + dc)[idx];
+        }
+      }
+    }
+    if (do_r && wplane != nullptr && gr >= 0) {
       const T* wrow = wplane + (size_t)gr * A.W;
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) wreg[pc] = wrow[gcoff + pc];
+      for (int pc = 0; pc < S; ++pc) wreg[pc] = wrow[(unsigned)(C0 + S * lane) + pc];
     }
-    // left halo columns of 2*lambda*w*r: waves 4 / 5 (columns -1 / -2), one row per lane
-    const bool col_task = !(SRMAP_EXP_MDBG & 4) && want_reg && RU > 0 && !strip0 && (wv == 4 || wv == 5) && (wv - 4) < RU;
+  };
+  auto make_ctl = [&](int gr, bool do_z, bool do_r) {
+    P1Ctl ctl;
+    const int zrow = gr + ZA;
+    ctl.do_z = do_z; ctl.do_r = do_r;
+    ctl.count_z = zrow >= br0 && zrow < br1;
+    ctl.full = gr >= br0;
+    const int allv = (1 << NV) - 1;
+    const int ubad = zrow < 0 ? (allv & ~m_io1) : (zrow >= H ? allv : (zrow >= H - S ? m_io1 : 0));   // uniform
+    ctl.badbits = ubad | (lane == 0 ? c_lane0 : 0) | (lane == 63 ? c_lane63 : 0);
+    ctl.zero00 = gr == 0 && strip0;
+    ctl.gr = gr; ctl.H = H;
+    return ctl;
+  };
+  // left halo columns of 2*lambda*w*r (pixels of the neighbour strip's last cell: recomputed here), one row per lane:
+  // rows rfirst + lane, lane < nrows, column C0 + COL (wave cw: COL = -1 - cw); into the halo ring hs
+  auto col_task = [&](int cw, int rfirst, int nrows, T wcol) {
+    if (lane < nrows) {
+      const int q0 = rfirst - (br0 - C::XLO);            // ring numbering of the first row (uniform, >= 0)
+      const int s0 = mwrap<C::NXR>(q0 % C::NXR + lane);  // nrows <= NXR
+      int xe[WIN + 1];
+#pragma unroll
+      for (int i = 0; i <= WIN; ++i) xe[i] = mwrap<C::NXR>(s0 + i) * (C::XRG * G);
+      const int hq = (rfirst - br0 + SR) % C::NHR + lane;  // halo ring: row r -> (r - br0 + SR) mod NHR; no wrap inside a task
+      const T* xsT = reinterpret_cast<const T*>(xs);
+      T* hsT = reinterpret_cast<T*>(hs);
+      const KT K = load_konst<T, B, C::NP, ArgsT>(kargs);
+      const int crow = rfirst + lane;
+      const int ce = (hq < C::NHR ? hq : hq - C::NHR) * G;
+      const bool cb = rfirst + nrows + WIN > K.H;
+      if (cw == 0) {
+        if (cb) m_halo_col<T, S, B, REGK, R, -1, true>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 1);
+        else m_halo_col<T, S, B, REGK, R, -1, false>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 1);
+      } else if (RU >= 2) {
+        if (cb) m_halo_col<T, S, B, REGK, R, (RU >= 2 ? -2 : -1), true>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 2);
+        else m_halo_col<T, S, B, REGK, R, (RU >= 2 ? -2 : -1), false>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 2);
+      }
+    }
+  };
+  const bool col_on = want_reg && RU > 0 && !strip0;
+
+  T acc[S], zown[S];
+  T ypre[NV], wreg[S];
+  double cost = 0.0;
+  OSTAMP(1);
+  // ---- virtual step: halo rows of zh (br0 - HB .. br0 + ZA - 1) and of 2*lambda*w*r (br0 - RU .. br0 - 1) by the last
+  // waves; halo columns of the first step's rows by waves 0 / 1.  Every input (these rows', step 0's) is requested
+  // BEFORE the wait for the window: one memory round trip for the whole prologue ----
+  {
+    const int grv = br0 - SR + wv;
+    const bool vz = want_data && wv >= SR - (HB + ZA), vr = want_reg && wv >= SR - RU;
+    T ypv[NV], wrv[S];
+    if (vz || vr) load_inputs(grv, vz, vr, true, ypv, wrv);
     T wcol = T(1);
-    const int crow = r0 + lane;  // lane < SR: row of this step (virtual step: only its last RU rows)
-    const bool col_lane = col_task && lane < SR && (!virt || lane >= SR - RU);
-    if (col_lane && wplane != nullptr && crow >= 0) wcol = wplane[(size_t)crow * A.W + (C0 - (wv == 4 ? 1 : 2))];
+    const bool colv = col_on && wv < RU;
+    if (colv) {
+      const int crow = br0 - RU + lane;
+      if (lane < SR + RU && wplane != nullptr && crow >= 0) wcol = wplane[(size_t)crow * A.W + (C0 - 1 - wv)];
+    }
+    load_inputs(br0 + wv, want_data, want_reg, edge_strip || br0 + wv + zmax(WIN, S + ZA) >= H, ypre, wreg);
+    // ---- border tasks: cost of the residuals whose z position lies OUTSIDE the image (they have no owner pixel;
+    // ztile_dev.hpp, "Border blocks").  The pixels of the border frame are dealt to the workgroups' waves 4 .. 11, one
+    // pixel per lane, and evaluated here, under the wait for the window (two memory round trips: table entry, then the
+    // residual's B * B + 1 loads).  The plan admits non-positive frame offsets only: no in-image corrections. ----
+    if (A.m_nbt > 0 && want_data && wv >= 4 && wv < 12) {
+      const int nwg = (int)gridDim.x;
+      double cb = 0.0;
+      for (int t = ((int)blockIdx.x * 8 + (wv - 4)) * 64 + lane; t < A.m_nbt; t += nwg * 512) {
+        int qr, qc;
+        ring_pixel(t, A.W, H, A.ring, qr, qc);
+        if ((unsigned)qr < (unsigned)H && (unsigned)qc < (unsigned)A.W) continue;  // (inside: nothing to correct under this plan)
+        const int rc = dfdiv(qr, S), cc = dfdiv(qc, S);
+        const ZEntry e = A.aux[(size_t)((qr - rc * S) * S + (qc - cc * S))];       // round 0 = the phase's only entry
+        const int i = rc + e.io, j = cc + e.jo;
+        if ((unsigned)i >= (unsigned)A.hl || (unsigned)j >= (unsigned)A.wl) continue;
+        const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
+        const double r = (double)border_residual<T, S, B>(A, A.W, H, A.wl, xplane, ybase + (size_t)e.k * A.obs_C * nl, ox, oy, i, j);
+        cb += r * r;
+      }
+      cost += (double)(S * S) * cb;
+    }
+    vm_wait_all();
+    lds_barrier();
+    OSTAMP(2);
+    if (vz || vr) {
+      pin(ypv);
+      pin(wrv);
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) { acc[pc] = T(0); zown[pc] = T(0); }
+      const T SCm = (lastst && lane == 63) ? T(0) : m_scale<T>();
+      const GT* xb[WIN + 1];
+      const int sxv = wv - SR + C::XLO;  // >= 0 for these waves
+#pragma unroll
+      for (int i = 0; i <= WIN; ++i) xb[i] = xs + (sxv + i) * C::XRG + lane;
+      GT* zdst = zs + mwrapn<C::NZR>(wv - SR + ZA + HB) * C::ZRG + lane;
+      GT* cdst = cs + mwrapn<C::NCR>(wv - SR + RU) * C::CRG + lane;
+      const P1Ctl ctl = make_ctl(grv, vz, vr);
+      const KT K = load_konst<T, B, C::NP, ArgsT>(kargs);
+      m_phase1<T, S, B, REGK, R, true, false>(K, xb, zdst, cdst, ctl, lane, SCm, ypv, wrv, acc, zown, cost);
+    }
+    if (colv) col_task(wv, br0 - RU, SR + RU, wcol);
+    lds_barrier();
+  }
+
+  // ---- loop state: ring positions of this wave's rows, advanced by SR per step: x row r -> (16 n + wv + XLO) mod NXR,
+  // zh row r + ZA -> (16 n + wv + ZA + HB) mod NZR, 2*lambda*w*r row r -> (16 n + wv + RU) mod NCR, halo ring row r ->
+  // (16 n + wv + SR) mod NHR ----
+  OSTAMP(3);
+  int sx = wv + C::XLO, sz = (wv + ZA + HB) % C::NZR, sc = (wv + RU) % C::NCR, sh = (wv + SR) % C::NHR;
+  int sxn = (C::XWIN + wv) % C::NXR;        // slot of the row this wave requests for the next step
+  int nrow = br0 - C::XLO + C::XWIN + wv;   // and its HR row
+
+  for (int n = 0; n < nsteps; ++n) {
+    asm volatile("" : "+v"(lane));   // lane-only values are re-derived per step (hoisted, they were the first spill candidates)
+    double stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MSTAMP(0);
+    const int gr = br0 + SR * n + wv;
+    // the inputs requested at the end of the previous step are complete HERE (the compiler's own wait sits in front of
+    // these pins); everything the step requests below is direct-to-LDS and waited for by hand
+    pin(ypre);
+    pin(wreg);
+    // ---- head: the x rows step n + 1 adds to the window, straight into the ring slots step n - 1 released ----
+    if (n + 1 < nsteps && !(SRMAP_EXP_MDBG & 16)) request_row(nrow, sxn);
+    nrow += SR;
+    sxn = mwrap<C::NXR>(sxn + SR);
+    T wcol = T(1);   // weight of the halo-column pixel this lane evaluates under phase 2 (waves 0 / 1), next step's rows
+    const bool col_next = col_on && wv < RU && n + 1 < nsteps;
+    if (col_next && lane < SR && wplane != nullptr) wcol = wplane[(size_t)(gr - wv + SR + lane) * A.W + (C0 - 1 - wv)];
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) { acc[pc] = T(0); zown[pc] = T(0); }
-
+    const bool need_fix = edge_strip || gr + zmax(WIN, S + ZA) >= H;
+    MSTAMP(1);
     // ---- phase 1 ----
-    if (ctl.do_z || ctl.do_r) {
+    {
+      const T SCm = (lastst && lane == 63) ? T(0) : m_scale<T>();
       const GT* xb[WIN + 1];
 #pragma unroll
       for (int i = 0; i <= WIN; ++i) xb[i] = xs + mwrap<C::NXR>(sx + i) * C::XRG + lane;
       GT* zdst = zs + sz * C::ZRG + lane;
       GT* cdst = cs + sc * C::CRG + lane;
-#ifndef SRMAP_EXP_MVAR
-#define SRMAP_EXP_MVAR 7
-#endif
-      if ((SRMAP_EXP_MVAR & 1) && !virt && terms_all && !need_fix)
-        m_phase1<T, S, B, REGK, R, false, true>(A, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost_data, cost_reg);
-      else if ((SRMAP_EXP_MVAR & 2) && !virt && terms_all)
-        m_phase1<T, S, B, REGK, R, true, true>(A, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost_data, cost_reg);
-      else if (SRMAP_EXP_MVAR & 4)
-        m_phase1<T, S, B, REGK, R, true, false>(A, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost_data, cost_reg);
-    }
-    if (col_lane) {
-      // per-lane slots of rows crow .. crow + WIN and of the 2*lambda*w*r row (uniform base + lane, one wrap each)
-      int xe[WIN + 1];
-      const int sxb = mwrapn<C::NXR>(sx - wv), scb = mwrapn<C::NCR>(sc - wv);  // slots of the step's first row
-      int s0 = mwrap<C::NXR>(sxb + lane);
-#pragma unroll
-      for (int i = 0; i <= WIN; ++i) xe[i] = mwrap<C::NXR>(s0 + i) * (C::XRG * G);
-      const int ce = mwrap<C::NCR>(scb + lane) * (C::CRG * G);
-      const T* xsT = reinterpret_cast<const T*>(xs);
-      T* csT = reinterpret_cast<T*>(cs);
-      const bool cb = r0 + SR + WIN > A.H;
-      if (wv == 4) {
-        if (cb) m_halo_col<T, S, B, REGK, R, -1, true>(A, xsT, csT, wcol, xe, ce, crow, C0 - 1);
-        else m_halo_col<T, S, B, REGK, R, -1, false>(A, xsT, csT, wcol, xe, ce, crow, C0 - 1);
-      } else if (RU >= 2) {
-        if (cb) m_halo_col<T, S, B, REGK, R, (RU >= 2 ? -2 : -1), true>(A, xsT, csT, wcol, xe, ce, crow, C0 - 2);
-        else m_halo_col<T, S, B, REGK, R, (RU >= 2 ? -2 : -1), false>(A, xsT, csT, wcol, xe, ce, crow, C0 - 2);
+      const KT K = load_konst<T, B, C::NP, ArgsT>(kargs);
+      if (terms_all && !need_fix) {
+        P1Ctl ctl;
+        ctl.count_z = gr + ZA < br1;
+        m_phase1<T, S, B, REGK, R, false, true>(K, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
+      } else if (terms_all) {
+        const P1Ctl ctl = make_ctl(gr, true, true);
+        m_phase1<T, S, B, REGK, R, true, true>(K, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
+      } else {
+        const P1Ctl ctl = make_ctl(gr, want_data, want_reg);
+        m_phase1<T, S, B, REGK, R, true, false>(K, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
       }
     }
-    vm_wait_all();   // this step's inputs are consumed; the x rows requested at the head have landed long since
+    MSTAMP(2);
+    vm_wait_all();   // the x rows requested at the head have landed long since (and the halo-column weight)
+    MSTAMP(3);
     lds_barrier();
+    MSTAMP(4);
 
     // ---- phase 2 ----
-    if (!virt) {
+    {
       const GT* xb2[RU + 1];
       const GT* cb2[RU + 1];
+      const GT* hb2[RU + 1];
       const GT* zb2[B];
 #pragma unroll
       for (int i = 0; i <= RU; ++i) {
         xb2[i] = xs + mwrapn<C::NXR>(sx - i) * C::XRG + lane;
         cb2[i] = cs + mwrapn<C::NCR>(sc - i) * C::CRG + lane;
+        hb2[i] = hs + mwrapn<C::NHR>(sh - i);
       }
 #pragma unroll
       for (int a = 0; a < B; ++a) zb2[a] = zs + mwrapn<C::NZR>(sz - ZA - HB + a) * C::ZRG + lane;  // zh row gr - HB + a
-      m_phase2<T, S, B, REGK, R>(A, xb2, cb2, zb2, want_data, want_reg, zown, acc);
+      {
+        const KT K = load_konst<T, B, C::NP, ArgsT>(kargs);
+        m_phase2<T, S, B, REGK, R>(K, xb2, cb2, hb2, zb2, lane, want_data, want_reg, zown, acc);
+      }
       T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W;
+      MSTAMP(5);
+      if (SRMAP_EXP_MCLOCK) {
+        if (lane == 0) { acc[0] = (T)stamp[0]; acc[1] = (T)stamp[1]; acc[2] = (T)stamp[2]; acc[3] = (T)stamp[3]; }
+        if (lane == 1) { acc[0] = (T)stamp[4]; acc[1] = (T)stamp[5]; }
+      }
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) if (!(SRMAP_EXP_MDBG & 8)) __builtin_nontemporal_store((SRMAP_EXP_MDBG & 128) ? dbgv[pc] : acc[pc], &dst[gcoff + pc]);
-      lds_barrier();
+      for (int pc = 0; pc < S; ++pc) __builtin_nontemporal_store(acc[pc], &dst[(unsigned)(C0 + S * lane) + pc]);
     }
+    // under the other waves' phase 2 (waves 0 / 1 finish theirs first): halo columns of the NEXT step's rows, and this
+    // wave's inputs of the next step -- both in front of the barrier, where the workgroup's arithmetic covers them
+    if (col_next) col_task(wv, gr - wv + SR, SR, wcol);
     sx = mwrap<C::NXR>(sx + SR);
     sz = (sz + SR) % C::NZR;   // uniform: scalar arithmetic
     sc = (sc + SR) % C::NCR;
+    sh = (sh + SR) % C::NHR;
+    if (n + 1 < nsteps) load_inputs(gr + SR, want_data, want_reg, edge_strip || gr + SR + zmax(WIN, S + ZA) >= H, ypre, wreg);
+    lds_barrier();
   }
 
+  OSTAMP(4);
+  if (SRMAP_EXP_MCLOCK && lane == 2) {
+    T* dst = A.g + (size_t)ch * N + (size_t)(br0 + wv) * A.W + (unsigned)(C0 + S * lane);
+    dst[0] = (T)ostamp[0]; dst[1] = (T)ostamp[1]; dst[2] = (T)ostamp[2]; dst[3] = (T)ostamp[3];
+    dst[4] = (T)ostamp[4];
+  }
   // ---- cost partial of this workgroup ----
   {
-    const double cw = wave_sum_d((double)(S * S) * cost_data + cost_reg);
+    const double cw = wave_sum_d(cost);
     if (lane == 0) red[0][wv] = cw;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -348,6 +503,7 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   const int nbands = (geo.H + band_rows - 1) / band_rows;
   dim3 grid(nstrips * nbands, geo.C, 1);
   A.m_nstrips = nstrips; A.m_band_rows = band_rows;
+  A.m_nbt = ((terms & SRMAP_TERM_DATA) && z.n_ring > 0) ? z.n_ring : 0;
   A.bd = (const BorderArgs<T>*)z.d_bd;
   A.rbuf = nullptr; A.spw = z.d_spw; A.Dr = z.Dr;
   A.mpart = z.d_mpart;

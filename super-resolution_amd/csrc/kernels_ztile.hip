@@ -909,7 +909,6 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   int m_ns = 0, m_rows = 0;
   const bool march = p->impl == SRMAP_IMPL_MARCH && zmarch_covers<T>(p, geo, z, z.regk, z.regr, zterms, g, dv, &m_ns, &m_rows);  // one instance per plan: the terms are run-time switches
   if (p->impl == SRMAP_IMPL_MARCH && !march) return set_error(p->ctx, SRMAP_EUNSUPPORTED, "the marching kernel does not cover this evaluation");
-  const int m_wgs = march ? m_ns * ((geo.H + m_rows - 1) / m_rows) * geo.C : -1;
   auto tiles = [&](int border_only) {
 #ifdef SRMAP_ZT_ONLY_CFG2
     if (sizeof(T) == 8 && S == 4 && B == 3 && regk == 2 && regr == 3)
@@ -926,15 +925,8 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
 #endif
   };
-  if (march) {
-    int nbord = 0;
-    if ((zterms & SRMAP_TERM_DATA) && z.n_ring > 0) {  // border blocks (ownerless residuals): their own launch for now
-      rc = tiles(m_wgs);
-      if (rc) return rc;
-      nbord = nb;
-    }
-    rc = launch_zmarch<T>(p, geo, obs_c0, zterms, x, g, wts, z, z.regk, z.regr, partials, &nb, st, mfin, m_ns, m_rows, nbord);
-    nb += nbord;
+  if (march) {  // border tasks (ownerless residuals) ride inside the marching workgroups' prologue
+    rc = launch_zmarch<T>(p, geo, obs_c0, zterms, x, g, wts, z, z.regk, z.regr, partials, &nb, st, mfin, m_ns, m_rows, 0);
   } else {
     rc = tiles(-1);
   }

@@ -44,8 +44,9 @@ struct MCfg {
   static constexpr int NXR = XWIN + SR;           // ring: window + the next step's SR new rows
   static constexpr int ZRG = PL * CW;
   static constexpr int NZR = (B > 1) ? SR + 2 * HB : 1;
-  static constexpr int CCL = Z::CCL, CC = Z::CC;
+  static constexpr int CCL = 0, CC = CW;          // the left halo columns live in their own small ring (hs)
   static constexpr int CRG = PL * CC;
+  static constexpr int NHR = 3 * SR;              // halo ring rows: this step's SR + RU and the next step's SR; SR | NHR
   static constexpr int NCR = REGK ? SR + RU : 1;
   static constexpr int VW = zmax(RU, HB + ZA);    // waves of the virtual step: SR - VW .. SR - 1
   // pixel windows (relative to the first pixel of the thread's cell)
@@ -80,14 +81,23 @@ __device__ __forceinline__ int mwrapn(int v) { return v < 0 ? v + N : v; }   // 
 
 template <typename T> __device__ __forceinline__ T m_scale() { return Pre<T>::up(T(1)); }
 
-// What phase 1 of one wave row has to know beyond the interior case (all wave-uniform but mr / lane tests).
+// Pin a set of accumulators at this point of the program: what was computed into them so far is complete here, and no
+// memory access moves across (the compiler otherwise gathers the LDS reads of ALL window rows of a pass at its head --
+// 80 registers of window data -- and spills around them; __builtin_amdgcn_sched_barrier alone did not stop it).
+template <typename T, int N>
+__device__ __forceinline__ void pin(T (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]) : : "memory");
+}
+
+// What phase 1 of one wave row has to know beyond the interior case.
 struct P1Ctl {
   bool do_z, do_r;     // evaluate the data / regulariser part (ALLON instances: both true at compile time)
   bool count_z;        // the residual row belongs to this band (its cost is counted here)
   bool full;           // the regulariser row belongs to this band (self term, cost); else 2*lambda*w*r only (halo rows)
-  int rclass;          // residual row: 0 every entry exists, 1 LR row -1 (only io == 1), 2 last LR row (only io == 0), 3 none
-  int io_bits, jo_bits;  // round 0 of the frame table for this wave's row phase: bit pc = io / jo of column phase pc
-  bool strip0, lastst; // first / last strip of the image row
+  int badbits;         // PER LANE: bit v set = the residual of pixel v of this thread's NV does not exist (LR row -1 / hl:
+                       // the same bits in every lane; LR column -1 / wl: lane 0 / 63 of the first / last strip)
+  bool zero00;         // this row is image row 0 of the first strip: lane 0's first pixel is the absolute pixel (0,0)
   int gr, H;
 };
 
@@ -103,136 +113,45 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
                                          typename Gran<T, 16 / (int)sizeof(T)>::type* zdst,
                                          typename Gran<T, 16 / (int)sizeof(T)>::type* cdst, const P1Ctl& ctl, int lane,
                                          const T SCm, const T (&ypre)[MCfg<T, S, B, REGK, R>::NV], const T (&wv)[S],
-                                         T (&acc)[S], T (&zown)[S], double& cost_data, double& cost_reg) {
+                                         T (&acc)[S], T (&zown)[S], double& cost) {
   using C = MCfg<T, S, B, REGK, R>;
   using GT = typename Gran<T, C::G>::type;
   constexpr int HB = C::HB, NV = C::NV, WIN = C::WIN, G = C::G, PL = C::PL;
   const bool do_z = ALLON || ctl.do_z, do_r = ALLON || ctl.do_r;
   const T SC = m_scale<T>();
-  T bx[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) bx[v] = T(0);
-  T x0s[S], x0m[S], rv[S], dv[S];
-#pragma unroll
-  for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); x0s[pc] = T(0); x0m[pc] = T(0); }
-#ifndef SRMAP_EXP_MSPLIT
-#define SRMAP_EXP_MSPLIT 0
-#endif
-  constexpr int NROW = zmax(WIN + 1, B);
-  constexpr int NPASS = SRMAP_EXP_MSPLIT ? 2 : 1;   // 2: the window rows are read twice, data term first (fewer live registers)
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    const bool pz = NPASS == 1 || pass == 0, prg = NPASS == 1 || pass == 1;
-#pragma unroll
-    for (int i = 0; i < NROW; ++i) {
-      if (NPASS == 2 && pass == 0 && i >= B) continue;
-      if (NPASS == 2 && pass == 1 && i > WIN) continue;
-      PWin<T, S, C::XC, C::XCL, C::P1LO, C::P1HI> w;
-      w.load(xb[i < WIN + 1 ? i : WIN]);
-      if (pz && i < B && do_z) {  // blur row a = i of the residual row (x row zrow - HB + a = gr + i)
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#pragma unroll
-          for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, i, e) * w.at(v + e - 2 * HB);
-        }
-      }
-      if (FIX && prg && REGK == 2 && sizeof(T) == 8 && i < R && i <= WIN && do_r && ctl.gr + i >= ctl.H) {
-        // window row below the image: its taps are the reference's skipped taps = zero differences; the self term in
-        // its (sgn + 1) / 2 form still counts them with 1/2 each (the same additions as the tile kernel's masked path)
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) {
-#pragma unroll
-          for (int j = 0; j < R; ++j) dv[pc] += A.powtab[i + j] * T(0.5);
-        }
-      }
-      if (prg && REGK != 0 && i <= WIN && do_r && (!FIX || ctl.gr + i < ctl.H)) {  // window rows below the image: skipped taps
-        if (i == 0) {
-#pragma unroll
-          for (int pc = 0; pc < S; ++pc) { x0s[pc] = w.at(pc) * SC; x0m[pc] = w.at(pc) * SCm; }
-        }
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) {
-          if (REGK == 2) {
-#pragma unroll
-            for (int j = 0; j <= R; ++j) {
-              if (i == 0 && j == 0) continue;
-              // (x[p] - x[q]) * 2^Q, one rounding; taps into the next cell through the masked scale
-              const T d = (FIX && pc + j >= S) ? __builtin_fma(-SCm, w.at(pc + j), x0m[pc]) : __builtin_fma(-SC, w.at(pc + j), x0s[pc]);
-              rv[pc] += A.powtab[i + j] * absv(d);
-              if (i < R && j < R) {
-                if (sizeof(T) == 8) dv[pc] += A.powtab[i + j] * step_pre<T>(d);
-                else dv[pc] += sgn_pre<T>(d, A.powtab[i + j]);
-              }
-            }
-          } else if (i == 1) {
-            const T dyv = __builtin_fma(SC, w.at(pc), -x0s[pc]);
-            rv[pc] = absv(dyv) + rv[pc];
-            dv[pc] = dv[pc] - sgn_pre<T>(dyv, T(1));
-          } else if (i == 0) {
-            const T dxv = (FIX && pc + 1 >= S) ? __builtin_fma(SCm, w.at(pc + 1), -x0m[pc]) : __builtin_fma(SC, w.at(pc + 1), -x0s[pc]);
-            rv[pc] = absv(dxv);
-            dv[pc] = -sgn_pre<T>(dxv, T(1));
-          }
-        }
-      }
-    }
-  }
-  // ---- regulariser: 2*lambda*w*r, self term, cost (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
-  if (REGK != 0 && do_r) {
-    T cr2v[S];
-    const bool full = ALLON || ctl.full;
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      const T r = Pre<T>::down(rv[pc]);
-      const T c = A.lambda * wv[pc];
-      const T cr2 = T(2) * c * r;
-      if (REGK == 2 && sizeof(T) == 8) dv[pc] = T(2) * dv[pc] - A.pwsum;
-      if (full) {  // uniform
-        acc[pc] += cr2 * dv[pc];
-        cost_reg += (double)c * (double)r * (double)r;
-      }
-      cr2v[pc] = cr2;
-    }
-    if (FIX) {
-      if (ctl.gr < 0) {  // rows above the image (halo rows of the top band)
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) cr2v[pc] = T(0);
-      }
-      // the absolute pixel (0,0) is skipped as a source (btv_regularizer.cpp:143-146)
-      if (REGK == 2 && ctl.gr == 0 && ctl.strip0) cr2v[0] = (lane == 0) ? T(0) : cr2v[0];
-    }
-#pragma unroll
-    for (int pl = 0; pl < PL; ++pl) {
-      GT o;
-#pragma unroll
-      for (int e = 0; e < G; ++e) o[e] = cr2v[pl * G + e];
-      cdst[pl * C::CC + C::CCL] = o;
-    }
-  }
-  // ---- data term: residuals of the frames whose LR grid hits each pixel (objective_data_term.cpp:15-75) ----
+  // ---- data term first (its registers -- B x at NV pixels, the observations -- are free again before the regulariser
+  // pass starts: the window rows are read twice, the kernel stays clear of the 128-register line) ----
+  // residuals of the frames whose LR grid hits each pixel (objective_data_term.cpp:15-75)
   if (do_z) {
-    T z[NV];
+    T bx[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) z[v] = T(0);
+    for (int v = 0; v < NV; ++v) bx[v] = T(0);
+    // window rows double-buffered by hand, a scheduling barrier per row: left alone the scheduler issues the reads of ALL
+    // rows of a pass first (80 registers of window data) and the allocator spills around them
+    PWin<T, S, C::XC, C::XCL, C::P1LO, (S - 1 + 2 * HB)> wd[2];
+    wd[0].load(xb[0]);
+#pragma unroll
+    for (int i = 0; i < B; ++i) {  // blur row a = i of the residual row (x row zrow - HB + a = gr + i)
+      if (i + 1 < B) wd[(i + 1) & 1].load(xb[i + 1]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, i, e) * wd[i & 1].at(v + e - 2 * HB);
+      }
+      pin(bx);
+    }
+    T z[NV];
     double cz = 0.0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
       const bool own = pcv >= 0 && pcv < S;
       T rr = bx[v] - ypre[v];
-      if (FIX) {
-        const int io = (ctl.io_bits >> pc) & 1, jo = (ctl.jo_bits >> pc) & 1;
-        const bool ok_u = ctl.rclass == 0 || (ctl.rclass == 1 && io == 1) || (ctl.rclass == 2 && io == 0);  // uniform
-        bool bad = !ok_u;
-        if (dc < 0) bad = bad || (ctl.strip0 && jo == 0 && lane == 0);                 // LR column -1
-        if (dc > 0) bad = bad || (ctl.lastst && lane == 63);                            // LR column >= wl
-        if (dc == 0) bad = bad || (ctl.lastst && jo == 1 && lane == 63);
-        rr = bad ? T(0) : rr;
-      }
-      z[v] += rr;
+      if (FIX) rr = ((ctl.badbits >> v) & 1) ? T(0) : rr;   // no such LR pixel
+      z[v] = rr;
       if (own) cz += (double)rr * (double)rr;
     }
-    if (ctl.count_z) cost_data += cz;  // uniform
+    if (ctl.count_z) cost += (double)(S * S) * cz;  // uniform
     if (B == 1) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) zown[pc] = z[pc];
@@ -253,6 +172,98 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
       }
     }
   }
+  __builtin_amdgcn_sched_barrier(0);   // (the scheduler would merge the two passes again)
+  // ---- regulariser pass 1 (tv_regularizer.cpp:110-170, btv_regularizer.cpp:19-136) ----
+  if (REGK != 0 && do_r) {
+    T x0s[S], rv[S], dv[S];
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); x0s[pc] = T(0); }
+    PWin<T, S, C::XC, C::XCL, 0, S - 1 + WIN> wr[2];
+    wr[0].load(xb[0]);
+#pragma unroll
+    for (int i = 0; i <= WIN; ++i) {
+      if (i + 1 <= WIN) wr[(i + 1) & 1].load(xb[i + 1]);   // (rows below the image hold zeros: read, not used)
+      if (FIX && ctl.gr + i >= ctl.H) {
+        // window row below the image: its taps are the reference's skipped taps = zero differences; the self term in
+        // its (sgn + 1) / 2 form still counts them with 1/2 each (the same additions as the tile kernel's masked path)
+        if (REGK == 2 && sizeof(T) == 8 && i < R) {
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) dv[pc] += A.powtab[i + j] * T(0.5);
+          }
+        }
+        continue;
+      }
+      const auto& w = wr[i & 1];
+      if (i == 0) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) x0s[pc] = w.at(pc) * SC;
+      }
+      // taps that cross into the next cell: in lane 63 of the last strip they lie beyond the image = the reference's
+      // skipped taps = zero differences; formed with the masked scale SCm (0 there, 2^Q elsewhere) they come out so
+      T mR = T(1);
+      if (FIX) mR = Pre<T>::down(SCm);
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) {
+        T x0m = x0s[pc];
+        if (FIX && pc + (REGK == 2 ? R : 1) >= S) x0m = x0s[pc] * mR;
+        if (REGK == 2) {
+#pragma unroll
+          for (int j = 0; j <= R; ++j) {
+            if (i == 0 && j == 0) continue;
+            // (x[p] - x[q]) * 2^Q, one rounding
+            const T d = (FIX && pc + j >= S) ? __builtin_fma(-SCm, w.at(pc + j), x0m) : __builtin_fma(-SC, w.at(pc + j), x0s[pc]);
+            rv[pc] += A.powtab[i + j] * absv(d);
+            if (i < R && j < R) {
+              if (sizeof(T) == 8) dv[pc] += A.powtab[i + j] * step_pre<T>(d);
+              else dv[pc] += sgn_pre<T>(d, A.powtab[i + j]);
+            }
+          }
+        } else if (i == 1) {
+          const T dyv = __builtin_fma(SC, w.at(pc), -x0s[pc]);
+          rv[pc] = absv(dyv) + rv[pc];
+          dv[pc] = dv[pc] - sgn_pre<T>(dyv, T(1));
+        } else if (i == 0) {
+          const T dxv = (FIX && pc + 1 >= S) ? __builtin_fma(SCm, w.at(pc + 1), -x0m) : __builtin_fma(SC, w.at(pc + 1), -x0s[pc]);
+          rv[pc] = absv(dxv);
+          dv[pc] = -sgn_pre<T>(dxv, T(1));
+        }
+      }
+      pin(rv);
+      pin(dv);
+    }
+    // 2*lambda*w*r, self term, cost
+    T cr2v[S];
+    const bool full = ALLON || ctl.full;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      const T r = Pre<T>::down(rv[pc]);
+      const T c = A.lambda * wv[pc];
+      const T cr2 = T(2) * c * r;
+      if (REGK == 2 && sizeof(T) == 8) dv[pc] = T(2) * dv[pc] - A.pwsum;
+      if (full) {  // uniform
+        acc[pc] += cr2 * dv[pc];
+        cost += (double)c * (double)r * (double)r;
+      }
+      cr2v[pc] = cr2;
+    }
+    if (FIX) {
+      if (ctl.gr < 0) {  // rows above the image (halo rows of the top band)
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) cr2v[pc] = T(0);
+      }
+      // the absolute pixel (0,0) is skipped as a source (btv_regularizer.cpp:143-146)
+      if (REGK == 2 && ctl.zero00) cr2v[0] = (lane == 0) ? T(0) : cr2v[0];
+    }
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl) {
+      GT o;
+#pragma unroll
+      for (int e = 0; e < G; ++e) o[e] = cr2v[pl * G + e];
+      cdst[pl * C::CC + C::CCL] = o;
+    }
+  }
 }
 
 // 2*lambda*w*r of ONE left-halo-column pixel (column COL < 0 relative to the strip), one row per lane.
@@ -263,7 +274,6 @@ __device__ __forceinline__ void m_halo_col(const ArgsT& A, const T* __restrict__
   using C = MCfg<T, S, B, REGK, R>;
   constexpr int WIN = C::WIN, G = C::G;
   auto xel = [](int p) constexpr { return ((posmod(floordiv(p, G) * G, S) / G) * C::XC + C::XCL + floordiv(floordiv(p, G) * G, S)) * G + posmod(p, G); };
-  auto cel = [](int p) constexpr { return ((posmod(floordiv(p, G) * G, S) / G) * C::CC + C::CCL + floordiv(floordiv(p, G) * G, S)) * G + posmod(p, G); };
   const T SC = m_scale<T>();
   T cr2 = T(0);
   if (gr >= 0 && gr < A.H && gc >= 0 && gc < A.W && !(REGK == 2 && gr == 0 && gc == 0)) {
@@ -287,16 +297,18 @@ __device__ __forceinline__ void m_halo_col(const ArgsT& A, const T* __restrict__
     }
     cr2 = T(2) * (A.lambda * wt) * Pre<T>::down(r);
   }
-  cs[ce + cel(COL)] = cr2;
+  cs[ce + posmod(COL, G)] = cr2;   // halo ring: one granule per row, the pixel's place inside its granule
 }
 
 // ---- phase 2 of one wave (HR row gr): vertical half of B^T, regulariser pass 2 (tv_regularizer.cpp:172-203,
 // btv_regularizer.cpp:137-162); acc holds the self term of pass 1 on entry, the gradient on exit ----
-//   xb[i] / cb[i]  first granule (+ lane) of x / 2*lambda*w*r row gr - i;  zb[a]: of zh row gr - HB + a
+//   xb[i] / cb[i]  first granule (+ lane) of x / 2*lambda*w*r row gr - i;  zb[a]: of zh row gr - HB + a;  hb[i]: the halo
+//   ring's granule of row gr - i (pixels left of the strip)
 template <typename T, int S, int B, int REGK, int R, typename ArgsT>
 __device__ __forceinline__ void m_phase2(const ArgsT& A, const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&xb)[MCfg<T, S, B, REGK, R>::RU + 1],
                                          const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&cb)[MCfg<T, S, B, REGK, R>::RU + 1],
-                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&zb)[B], bool want_data, bool want_reg,
+                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&hb)[MCfg<T, S, B, REGK, R>::RU + 1],
+                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&zb)[B], int lane, bool want_data, bool want_reg,
                                          const T (&zown)[S], T (&acc)[S]) {
   using C = MCfg<T, S, B, REGK, R>;
   constexpr int RU = C::RU;
@@ -330,7 +342,11 @@ __device__ __forceinline__ void m_phase2(const ArgsT& A, const typename Gran<T, 
       PWin<T, S, C::XC, C::XCL, C::P2LO, C::P2HI> xw;
       PWin<T, S, C::CC, C::CCL, C::P2LO, C::P2HI> cw;
       xw.load(xb[i]);
-      cw.load(cb[i]);
+      // the granule left of the strip (lane 0) comes from the halo ring: one select on the address
+      static_assert(C::P2LO >= -C::G && C::P2LO < 0, "the left window reaches one granule into the neighbour cell");
+      cw.g[0] = *((lane == 0) ? hb[i] : cb[i] + cw.gidx(cw.GLO));
+#pragma unroll
+      for (int gi = 1; gi < cw.NG; ++gi) cw.g[gi] = cb[i][cw.gidx(cw.GLO + gi)];
       if (i == 0) {
 #pragma unroll
         for (int pc = 0; pc < S; ++pc) x0s[pc] = xw.at(pc) * SC;

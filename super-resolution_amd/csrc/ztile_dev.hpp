@@ -289,7 +289,7 @@ struct ZArgs {
   // ---- marching kernel (kernels_zmarch.hip): workgroup -> (strip, band) ----
   int m_nstrips;         // strips of 64 LR cells per image row
   int m_band_rows;       // HR rows per band (a multiple of the step height)
-  int m_nbb;             // border tasks: pixels of the border frame per workgroup (0 = none)
+  int m_nbt;             // border tasks: pixels of the border frame (0 = none), dealt to the workgroups
 };
 
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
@@ -998,7 +998,7 @@ static void fill_zargs(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>& A, srmap_problem
     for (int i = 0; i < R; ++i)
       for (int j = 0; j < R; ++j)
         if (i + j > 0) A.pwsum += A.powtab[i + j];
-  A.m_nstrips = 0; A.m_band_rows = 0; A.m_nbb = 0;
+  A.m_nstrips = 0; A.m_band_rows = 0; A.m_nbt = 0;
 }
 
 // ---- marching kernel (kernels_zmarch.hip) ----
