@@ -28,7 +28,7 @@
 #ifndef SRMAP_EXP_MCLOCK
 #define SRMAP_EXP_MCLOCK 0
 #endif
-#define MSTAMP(k) do { if (SRMAP_EXP_MCLOCK) stamp[k] = (double)(long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define MSTAMP(k) do { if (SRMAP_EXP_MCLOCK) stamp[k] = (double)(long long)(__builtin_amdgcn_s_memtime() - tbase); } while (0)
 
 namespace srmap {
 
@@ -78,12 +78,17 @@ __device__ __forceinline__ MKonst<T, B, NP> load_konst(kptr_t kp) {
   return K;
 }
 
-template <typename T, int S, int B, int REGK, int R, bool WD>
-__global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
-  using C = MCfg<T, S, B, REGK, R>;
+#ifndef SRMAP_EXP_MWG8
+#define SRMAP_EXP_MWG8 2   // resident 8-wave workgroups per CU (f32 instances)
+#endif
+template <typename T, int S, int B, int REGK, int R, int NW, bool WD>
+__global__ __launch_bounds__(64 * NW, (NW == 16 ? 4 : 2 * SRMAP_EXP_MWG8)) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
+  using C = MCfg<T, S, B, REGK, R, NW>;
   using GT = typename Gran<T, C::G>::type;
   using ArgsT = ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>;
   using KT = MKonst<T, B, C::NP>;
+  using W0T = PWin<T, S, C::XC, C::XCL, C::P1LO, C::P1HI>;
+  using W2T = PWin<T, S, C::XC, C::XCL, C::P2LO, C::P2HI>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU, WIN = C::WIN, SR = C::SR, G = C::G, ZA = C::ZA;
   const kptr_t kargs = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   static_assert(SR % S == 0, "a wave keeps its row phase from step to step");
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
   __shared__ double red[2][C::NW];
 
   double ostamp[6] = {0, 0, 0, 0, 0, 0};
-#define OSTAMP(k) do { if (SRMAP_EXP_MCLOCK) ostamp[k] = (double)(long long)__builtin_amdgcn_s_memtime(); } while (0)
+  const unsigned long long tbase = SRMAP_EXP_MCLOCK ? __builtin_amdgcn_s_memtime() : 0ull;   // stamps are relative to the wave's entry
+#define OSTAMP(k) do { if (SRMAP_EXP_MCLOCK) ostamp[k] = (double)(long long)(__builtin_amdgcn_s_memtime() - tbase); } while (0)
   OSTAMP(0);
   const int lane0 = threadIdx.x & 63;
   const int wv0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
   const int strip = (int)blockIdx.x % A.m_nstrips, band = (int)blockIdx.x / A.m_nstrips;
   const int ch = blockIdx.y;
   const bool strip0 = strip == 0, lastst = strip == A.m_nstrips - 1;
+  const bool edge_strip_c = strip0 || lastst;
   const int CJ0 = strip * C::CW, C0 = CJ0 * S;
   const int br0 = band * A.m_band_rows;   // multiples of SR; the plan admits H % SR == 0 only
   const int br1 = (br0 + A.m_band_rows < A.H) ? br0 + A.m_band_rows : A.H;
@@ -113,16 +120,18 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
   const bool want_reg = REGK != 0 && (A.terms & SRMAP_TERM_REG) != 0;
   const T* wplane = (want_reg && A.w) ? A.w + (size_t)ch * N : nullptr;
 
-  // ---- x-row requests: granule gi = 64 k + lane of a row -> (plane, cell).  The per-lane byte offsets are re-derived from
-  // the lane's own column at every request (a few 32-bit operations per step; kept in registers across the step they were
-  // the allocator's first spill candidates, and a spilled offset puts a scratch round trip in front of the request) ----
+  // ---- x-row requests: granule gi = 64 k + lane of a row -> (plane, cell).  With gi = 64 k + lane, plane = gi / XC,
+  // cell = CJ0 - XCL + gi % XC the byte offset inside the row is an affine function of the lane per (k, plane): it is
+  // re-derived from the lane at every request (a handful of 32-bit operations; kept in registers across the step the
+  // offsets were the allocator's first spill candidates, and a spilled offset puts a scratch round trip in front of the
+  // request).  Cells outside the image are skipped (their LDS granules were zeroed once: warp zero fill). ----
   auto req_geom = [&](int k, bool& ok, bool& cok, unsigned& vo) {
     const int gi = 64 * k + lane;
     const int plane = gi >= C::XC ? (gi >= 2 * C::XC ? 2 : 1) : 0;   // PL <= 2 planes (+ guard)
     const int cellpos = gi - plane * C::XC;
     const int cell = CJ0 - C::XCL + cellpos;
     ok = gi < C::XRG;
-    cok = ok && (unsigned)cell < (unsigned)A.wl;
+    cok = ok && (edge_strip_c ? (unsigned)cell < (unsigned)A.wl : true);
     vo = (unsigned)((cell * S + plane * G) * (int)sizeof(T));
   };
   // request HR row `row` of x into ring slot `slot` (rows outside the image read as zero: warp zero fill)
@@ -193,6 +202,16 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
   const int c_lane0 = (strip0 && HB > 0 && ((jo_bits >> (S - 1)) & 1) == 0) ? 1 : 0;
   const int c_lane63 = lastst ? (m_jo1own | (HB > 0 ? (1 << (NV - 1)) : 0)) : 0;
   const bool edge_strip = strip0 || lastst;
+  // carried input pointers of this wave: observations of the residual row (per column phase), weights of the regulariser
+  // row; set for the virtual step's row br0 - SR + wv, advanced by SR rows per step
+  const T* ypn[S];
+  {
+    const int zr = br0 - SR + wv + ZA;
+    const int rc = (zr >= 0) ? zr / S : -((-zr + S - 1) / S);
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) ypn[pc] = ybase + (yoff[pc] + ((long long)rc * A.wl + CJ0));
+  }
+  const T* wrn = wplane != nullptr ? wplane + (ptrdiff_t)(br0 - SR + wv) * A.W : nullptr;
   const bool terms_all = want_data && want_reg;
   const int H = A.H;
 
@@ -206,13 +225,12 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) wreg[pc] = T(1);
     if (do_z) {
-      const int rc = (zrow >= 0) ? zrow / S : -((-zrow + S - 1) / S);
-      const long long yrow = (long long)rc * A.wl + CJ0;
       if (!fixr) {
+        // interior: the S row pointers of this wave (carried from step to step, advanced by a constant) + the lane
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
-          ypre[v] = (ybase + (yoff[pc] + yrow) + dc)[(unsigned)lane];
+          ypre[v] = (ypn[pc] + dc)[(unsigned)lane];
         }
       } else {
         const int rclass = zrow < 0 ? 1 : (zrow >= H ? 3 : (zrow >= H - S ? 2 : 0));
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
           const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
           const int io = (io_bits >> pc) & 1, jo = (jo_bits >> pc) & 1;
           const bool ok_u = rclass == 0 || (rclass == 1 && io == 1) || (rclass == 2 && io == 0);
-          const T* yp = ok_u ? ybase + (yoff[pc] + yrow) : ybase + (CJ0 + 1);   // no such LR row: any address valid under +-1
+          const T* yp = ok_u ? ypn[pc] : ybase + (CJ0 + 1);   // no such LR row: any address valid under +-1
           const unsigned hi = lastst ? (unsigned)(63 - jo - (dc > 0 ? 1 : 0)) : 63u;   // uniform
           unsigned idx = (unsigned)lane < hi ? (unsigned)lane : hi;
           if (dc < 0) idx = (unsigned)lane + ((strip0 && jo == 0 && lane == 0) ? 1u : 0u);
@@ -230,10 +248,15 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
       }
     }
     if (do_r && wplane != nullptr && gr >= 0) {
-      const T* wrow = wplane + (size_t)gr * A.W;
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) wreg[pc] = wrow[(unsigned)(C0 + S * lane) + pc];
+      for (int pc = 0; pc < S; ++pc) wreg[pc] = wrn[(unsigned)(C0 + S * lane) + pc];
     }
+  };
+  // advance the carried row pointers by `rows` HR rows (a multiple of S)
+  auto advance_inputs = [&](int rows) {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) ypn[pc] += (long long)(rows / S) * A.wl;
+    if (wrn != nullptr) wrn += (size_t)rows * A.W;
   };
   auto make_ctl = [&](int gr, bool do_z, bool do_r) {
     P1Ctl ctl;
@@ -265,11 +288,11 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
       const int ce = (hq < C::NHR ? hq : hq - C::NHR) * G;
       const bool cb = rfirst + nrows + WIN > K.H;
       if (cw == 0) {
-        if (cb) m_halo_col<T, S, B, REGK, R, -1, true>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 1);
-        else m_halo_col<T, S, B, REGK, R, -1, false>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 1);
+        if (cb) m_halo_col<T, S, B, REGK, R, NW, -1, true>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 1);
+        else m_halo_col<T, S, B, REGK, R, NW, -1, false>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 1);
       } else if (RU >= 2) {
-        if (cb) m_halo_col<T, S, B, REGK, R, (RU >= 2 ? -2 : -1), true>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 2);
-        else m_halo_col<T, S, B, REGK, R, (RU >= 2 ? -2 : -1), false>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 2);
+        if (cb) m_halo_col<T, S, B, REGK, R, NW, (RU >= 2 ? -2 : -1), true>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 2);
+        else m_halo_col<T, S, B, REGK, R, NW, (RU >= 2 ? -2 : -1), false>(K, xsT, hsT, wcol, xe, ce, crow, C0 - 2);
       }
     }
   };
@@ -293,15 +316,16 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
       const int crow = br0 - RU + lane;
       if (lane < SR + RU && wplane != nullptr && crow >= 0) wcol = wplane[(size_t)crow * A.W + (C0 - 1 - wv)];
     }
+    advance_inputs(SR);
     load_inputs(br0 + wv, want_data, want_reg, edge_strip || br0 + wv + zmax(WIN, S + ZA) >= H, ypre, wreg);
     // ---- border tasks: cost of the residuals whose z position lies OUTSIDE the image (they have no owner pixel;
-    // ztile_dev.hpp, "Border blocks").  The pixels of the border frame are dealt to the workgroups' waves 4 .. 11, one
+    // ztile_dev.hpp, "Border blocks").  The pixels of the border frame are dealt to the middle half of each workgroup's waves, one
     // pixel per lane, and evaluated here, under the wait for the window (two memory round trips: table entry, then the
     // residual's B * B + 1 loads).  The plan admits non-positive frame offsets only: no in-image corrections. ----
-    if (A.m_nbt > 0 && want_data && wv >= 4 && wv < 12) {
+    if (A.m_nbt > 0 && want_data && wv >= NW / 4 && wv < NW / 4 + NW / 2) {
       const int nwg = (int)gridDim.x;
       double cb = 0.0;
-      for (int t = ((int)blockIdx.x * 8 + (wv - 4)) * 64 + lane; t < A.m_nbt; t += nwg * 512) {
+      for (int t = ((int)blockIdx.x * (NW / 2) + (wv - NW / 4)) * 64 + lane; t < A.m_nbt; t += nwg * (NW / 2) * 64) {
         int qr, qc;
         ring_pixel(t, A.W, H, A.ring, qr, qc);
         if ((unsigned)qr < (unsigned)H && (unsigned)qc < (unsigned)A.W) continue;  // (inside: nothing to correct under this plan)
@@ -332,10 +356,11 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
       GT* cdst = cs + mwrapn<C::NCR>(wv - SR + RU) * C::CRG + lane;
       const P1Ctl ctl = make_ctl(grv, vz, vr);
       const KT K = load_konst<T, B, C::NP, ArgsT>(kargs);
-      m_phase1<T, S, B, REGK, R, true, false>(K, xb, zdst, cdst, ctl, lane, SCm, ypv, wrv, acc, zown, cost);
+      W0T w0v;
+      w0v.load(xb[0]);
+      m_phase1<T, S, B, REGK, R, NW, true, true, false>(K, xb, zdst, cdst, w0v, ctl, lane, SCm, ypv, wrv, acc, zown, cost);
     }
     if (colv) col_task(wv, br0 - RU, SR + RU, wcol);
-    lds_barrier();
   }
 
   // ---- loop state: ring positions of this wave's rows, advanced by SR per step: x row r -> (16 n + wv + XLO) mod NXR,
@@ -345,9 +370,27 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
   int sx = wv + C::XLO, sz = (wv + ZA + HB) % C::NZR, sc = (wv + RU) % C::NCR, sh = (wv + SR) % C::NHR;
   int sxn = (C::XWIN + wv) % C::NXR;        // slot of the row this wave requests for the next step
   int nrow = br0 - C::XLO + C::XWIN + wv;   // and its HR row
+  // What a phase needs beyond its inputs is prepared IN FRONT of the barrier that opens it -- LDS row addresses, the
+  // phase's constants, the first window rows (x does not depend on the other waves' phase) -- under the arithmetic of
+  // the waves still in the previous phase.  Behind a barrier all sixteen waves run the same code at once: whatever
+  // stands there is paid sixteen times on the one scalar unit (profiles/r05_march_clock.txt: 0.7 .. 3.4 K cycles of
+  // "head" per step before this reordering).
+  const GT* xb[WIN + 1];
+  GT* zdst;
+  GT* cdst;
+  W0T w0;
+  auto prep_p1 = [&]() {
+    asm volatile("" : "+v"(lane));   // lane-only values are re-derived per step (hoisted, they were the first spill candidates)
+#pragma unroll
+    for (int i = 0; i <= WIN; ++i) xb[i] = xs + mwrap<C::NXR>(sx + i) * C::XRG + lane;
+    zdst = zs + sz * C::ZRG + lane;
+    cdst = cs + sc * C::CRG + lane;
+    w0.load(xb[0]);
+  };
+  prep_p1();
+  lds_barrier();
 
   for (int n = 0; n < nsteps; ++n) {
-    asm volatile("" : "+v"(lane));   // lane-only values are re-derived per step (hoisted, they were the first spill candidates)
     double stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     MSTAMP(0);
     const int gr = br0 + SR * n + wv;
@@ -369,24 +412,35 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
     // ---- phase 1 ----
     {
       const T SCm = (lastst && lane == 63) ? T(0) : m_scale<T>();
-      const GT* xb[WIN + 1];
-#pragma unroll
-      for (int i = 0; i <= WIN; ++i) xb[i] = xs + mwrap<C::NXR>(sx + i) * C::XRG + lane;
-      GT* zdst = zs + sz * C::ZRG + lane;
-      GT* cdst = cs + sc * C::CRG + lane;
-      const KT K = load_konst<T, B, C::NP, ArgsT>(kargs);
+      const KT K1 = load_konst<T, B, C::NP, ArgsT>(kargs);
+      const bool row_fix = gr + zmax(WIN, S + ZA) >= H;   // the image's last rows
       if (terms_all && !need_fix) {
         P1Ctl ctl;
         ctl.count_z = gr + ZA < br1;
-        m_phase1<T, S, B, REGK, R, false, true>(K, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
-      } else if (terms_all) {
+        m_phase1<T, S, B, REGK, R, NW, false, false, true>(K1, xb, zdst, cdst, w0, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
+      } else if (terms_all && !row_fix) {   // first / last strip, rows away from the bottom edge: column fix-ups only
         const P1Ctl ctl = make_ctl(gr, true, true);
-        m_phase1<T, S, B, REGK, R, true, true>(K, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
+        m_phase1<T, S, B, REGK, R, NW, true, false, true>(K1, xb, zdst, cdst, w0, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
       } else {
         const P1Ctl ctl = make_ctl(gr, want_data, want_reg);
-        m_phase1<T, S, B, REGK, R, true, false>(K, xb, zdst, cdst, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
+        m_phase1<T, S, B, REGK, R, NW, true, true, false>(K1, xb, zdst, cdst, w0, ctl, lane, SCm, ypre, wreg, acc, zown, cost);
       }
     }
+    // ---- in front of barrier 1: phase 2's addresses and the row of x it starts with ----
+    const GT* xb2[RU + 1];
+    const GT* cb2[RU + 1];
+    const GT* hb2[RU + 1];
+    const GT* zb2[B];
+#pragma unroll
+    for (int i = 0; i <= RU; ++i) {
+      xb2[i] = xs + mwrapn<C::NXR>(sx - i) * C::XRG + lane;
+      cb2[i] = cs + mwrapn<C::NCR>(sc - i) * C::CRG + lane;
+      hb2[i] = hs + mwrapn<C::NHR>(sh - i);
+    }
+#pragma unroll
+    for (int a = 0; a < B; ++a) zb2[a] = zs + mwrapn<C::NZR>(sz - ZA - HB + a) * C::ZRG + lane;  // zh row gr - HB + a
+    W2T xw0;
+    xw0.load(xb2[0]);
     MSTAMP(2);
     vm_wait_all();   // the x rows requested at the head have landed long since (and the halo-column weight)
     MSTAMP(3);
@@ -395,22 +449,14 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
 
     // ---- phase 2 ----
     {
-      const GT* xb2[RU + 1];
-      const GT* cb2[RU + 1];
-      const GT* hb2[RU + 1];
-      const GT* zb2[B];
-#pragma unroll
-      for (int i = 0; i <= RU; ++i) {
-        xb2[i] = xs + mwrapn<C::NXR>(sx - i) * C::XRG + lane;
-        cb2[i] = cs + mwrapn<C::NCR>(sc - i) * C::CRG + lane;
-        hb2[i] = hs + mwrapn<C::NHR>(sh - i);
-      }
-#pragma unroll
-      for (int a = 0; a < B; ++a) zb2[a] = zs + mwrapn<C::NZR>(sz - ZA - HB + a) * C::ZRG + lane;  // zh row gr - HB + a
-      {
-        const KT K = load_konst<T, B, C::NP, ArgsT>(kargs);
-        m_phase2<T, S, B, REGK, R>(K, xb2, cb2, hb2, zb2, lane, want_data, want_reg, zown, acc);
-      }
+      const KT K2 = load_konst<T, B, C::NP, ArgsT>(kargs);
+      // the NEXT step's inputs are requested in the MIDDLE of phase 2 (behind its data part): phase 1 has consumed this
+      // step's, the registers are free, the waves of a SIMD pass this point one after the other (80 KB of loads per step
+      // are ~1.3 K cycles of the CU's vector-memory path), and the loads have the rest of the step to land
+      m_phase2<T, S, B, REGK, R, NW>(K2, xb2, cb2, hb2, zb2, xw0, lane, want_data, want_reg, zown, acc, [&]() {
+        advance_inputs(SR);
+        if (n + 1 < nsteps) load_inputs(gr + SR, want_data, want_reg, edge_strip || gr + SR + zmax(WIN, S + ZA) >= H, ypre, wreg);
+      });
       T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W;
       MSTAMP(5);
       if (SRMAP_EXP_MCLOCK) {
@@ -420,14 +466,15 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) __builtin_nontemporal_store(acc[pc], &dst[(unsigned)(C0 + S * lane) + pc]);
     }
-    // under the other waves' phase 2 (waves 0 / 1 finish theirs first): halo columns of the NEXT step's rows, and this
-    // wave's inputs of the next step -- both in front of the barrier, where the workgroup's arithmetic covers them
+    // under the other waves' phase 2 (waves 0 / 1 finish theirs first): halo columns of the NEXT step's rows, this
+    // wave's inputs and phase-1 preparation of the next step -- all in front of the barrier, where the workgroup's
+    // arithmetic covers them
     if (col_next) col_task(wv, gr - wv + SR, SR, wcol);
     sx = mwrap<C::NXR>(sx + SR);
     sz = (sz + SR) % C::NZR;   // uniform: scalar arithmetic
     sc = (sc + SR) % C::NCR;
     sh = (sh + SR) % C::NHR;
-    if (n + 1 < nsteps) load_inputs(gr + SR, want_data, want_reg, edge_strip || gr + SR + zmax(WIN, S + ZA) >= H, ypre, wreg);
+    if (n + 1 < nsteps) prep_p1();
     lds_barrier();
   }
 
@@ -461,15 +508,23 @@ __global__ __launch_bounds__(1024, 1) void k_eval_m(ZArgs<T, B, ZCfg<T, S, B, RE
 // ---------------------------------------------------------------------------------------------------------
 // host side
 
+// waves per workgroup and resident workgroups per CU of the instance a dtype runs: f64 fills the LDS with one 16-wave
+// workgroup (152 KB of rings); f32 rings are half as wide, and two independent 8-wave workgroups -- each other's cover
+// for barrier and request waits, which a single workgroup has nothing to fill with -- fit with room to spare
+#ifndef SRMAP_EXP_MNW32
+#define SRMAP_EXP_MNW32 8
+#endif
+template <typename T> struct MShape { static constexpr int NW = sizeof(T) == 8 ? 16 : SRMAP_EXP_MNW32; static constexpr int WG_PER_CU = (NW == 16 ? 1 : SRMAP_EXP_MWG8); };
+
 template <typename T>
 bool zmarch_covers(const srmap_problem* p, const Geometry& geo, const ZPlan& z, int regk, int regr, unsigned terms,
                    const T* g, const T* dvec, int* nstrips, int* band_rows) {
   if (z.subpix || dvec != nullptr || g == nullptr) return false;
-  if (sizeof(T) != 8) return false;
   if (geo.s != 4 || geo.b != 3 || regk != 2 || regr != 3) return false;
   if (p->ov_hook != nullptr) return false;
   if (geo.rr0 != 0 || geo.rr1 != geo.H || geo.cr0 != 0 || geo.cr1 != geo.H) return false;
-  if (geo.W % (64 * geo.s) != 0 || geo.H % 16 != 0) return false;
+  constexpr int SR = MShape<T>::NW;
+  if (geo.W % (64 * geo.s) != 0 || geo.H % SR != 0) return false;
   // every pixel phase owns exactly one residual (K = S * S frames on distinct phases), frame offsets in [-(S-1), 0]:
   // the image border then needs the selects of the FIX instances only (zmarch_dev.hpp)
   if (z.MS != 1) return false;
@@ -484,12 +539,13 @@ bool zmarch_covers(const srmap_problem* p, const Geometry& geo, const ZPlan& z, 
   if (p->ctx->num_cus <= 0) return false;
   (void)terms;
   const int ns = geo.w / 64;
-  // bands: as many workgroups as CUs (one resident workgroup each), rows in multiples of the step
-  int nb = p->ctx->num_cus / ns;
+  // bands: as many workgroups as the chip holds at once (resident for the whole launch), rows in multiples of the step
+  int nb = p->ctx->num_cus * MShape<T>::WG_PER_CU / ns;
   if (nb < 1) nb = 1;
   int rows = (geo.H + nb - 1) / nb;
-  rows = (rows + 15) / 16 * 16;
-  if (rows < 32) return false;
+  rows = (rows + SR - 1) / SR * SR;
+  if (rows < 2 * SR) rows = 2 * SR;   // small images: fewer workgroups than the chip holds (a band amortises its prologue)
+  if (rows > geo.H) rows = geo.H;
   *nstrips = ns; *band_rows = rows;
   return true;
 }
@@ -498,6 +554,7 @@ template <typename T, int S, int B, int REGK, int R>
 static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g, const T* wts,
                     const ZPlan& z, double* partials, int* nblocks, hipStream_t st, MFin mfin, int nstrips, int band_rows, int nbord) {
   using ZC = ZCfg<T, S, B, REGK, R>;
+  constexpr int NW = MShape<T>::NW;
   ZArgs<T, B, ZC::NP> A;
   fill_zargs<T, S, B, REGK, R>(A, p, geo, obs_c0, terms, x, g, wts, z, partials, (const T*)nullptr, (double*)nullptr);
   const int nbands = (geo.H + band_rows - 1) / band_rows;
@@ -515,11 +572,11 @@ static int launch_m(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.nby = 0;
   A.n_tile_partials = (int)(grid.x * grid.y);
   A.mfinish = mfin.on ? 1 : 0;
-  A.n_partials = A.n_tile_partials + nbord;   // border blocks of the launch in front publish behind the workgroups
+  A.n_partials = A.n_tile_partials + nbord;
   A.pub = nullptr;
   A.xpart = mfin.xpart; A.n_xpart = mfin.n_xpart;
   if (mfin.on && (size_t)A.n_partials > z.mpart_cap) return set_error(p->ctx, SRMAP_EHIP, "granule capacity");
-  hipLaunchKernelGGL((k_eval_m<T, S, B, REGK, R, false>), grid, dim3(1024), 0, st, A);
+  hipLaunchKernelGGL((k_eval_m<T, S, B, REGK, R, NW, false>), grid, dim3(64 * NW), 0, st, A);
   *nblocks = A.n_tile_partials;
   SRMAP_HIP(p->ctx, hipGetLastError());
   return SRMAP_OK;
@@ -530,17 +587,12 @@ int launch_zmarch(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned te
                   const ZPlan& z, int regk, int regr, double* partials, int* nblocks, hipStream_t st, MFin mfin,
                   int nstrips, int band_rows, int nbord) {
   (void)regk; (void)regr;
-  return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no marching kernel for this dtype");
-}
-template <>
-int launch_zmarch<double>(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const double* x, double* g,
-                          const double* wts, const ZPlan& z, int regk, int regr, double* partials, int* nblocks,
-                          hipStream_t st, MFin mfin, int nstrips, int band_rows, int nbord) {
-  (void)regk; (void)regr;
-  return launch_m<double, 4, 3, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nblocks, st, mfin, nstrips, band_rows, nbord);
+  return launch_m<T, 4, 3, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nblocks, st, mfin, nstrips, band_rows, nbord);
 }
 template int launch_zmarch<float>(srmap_problem*, const Geometry&, int, unsigned, const float*, float*, const float*,
                                   const ZPlan&, int, int, double*, int*, hipStream_t, MFin, int, int, int);
+template int launch_zmarch<double>(srmap_problem*, const Geometry&, int, unsigned, const double*, double*, const double*,
+                                   const ZPlan&, int, int, double*, int*, hipStream_t, MFin, int, int, int);
 template bool zmarch_covers<float>(const srmap_problem*, const Geometry&, const ZPlan&, int, int, unsigned, const float*,
                                    const float*, int*, int*);
 template bool zmarch_covers<double>(const srmap_problem*, const Geometry&, const ZPlan&, int, int, unsigned, const double*,
@@ -548,7 +600,8 @@ template bool zmarch_covers<double>(const srmap_problem*, const Geometry&, const
 
 void zmarch_preload() {
   hipFuncAttributes attr;
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_m<double, 4, 3, 2, 3, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_m<double, 4, 3, 2, 3, 16, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_m<float, 4, 3, 2, 3, MShape<float>::NW, false>));
 }
 
 }  // namespace srmap

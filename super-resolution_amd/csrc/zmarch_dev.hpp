@@ -23,10 +23,10 @@
 namespace srmap {
 namespace {
 
-template <typename T, int S, int B, int REGK, int R>
+template <typename T, int S, int B, int REGK, int R, int NW_>
 struct MCfg {
   using Z = ZCfg<T, S, B, REGK, R>;
-  static constexpr int NW = 16;               // waves = HR rows per step
+  static constexpr int NW = NW_;              // waves = HR rows per step (16: one workgroup per CU; 8: several)
   static constexpr int NT = 64 * NW;
   static constexpr int SR = NW;
   static constexpr int CW = 64;
@@ -107,14 +107,18 @@ struct P1Ctl {
 //   zdst    first granule (+ lane) of the zh row's slot,  cdst: of the 2*lambda*w*r row's slot
 //   SCm     2^Q, but 0 in lane 63 of the last strip: window taps that cross into the next cell form their difference
 //           with it (and with x0 * SCm), so they come out as the reference's skipped tap -- a zero difference
-// FIX: rows / strips at the image border (see the head of this file).  ALLON: both parts, every row inside the band.
-template <typename T, int S, int B, int REGK, int R, bool FIX, bool ALLON, typename ArgsT>
-__device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&xb)[MCfg<T, S, B, REGK, R>::WIN + 1],
+// FIX: strips at the image border -- residuals without an LR pixel (badbits), window taps beyond the right edge (SCm),
+// the absolute pixel (0,0).  FIXR (with FIX): rows at the image border too -- window rows below the image, rows above
+// it.  ALLON: both parts, every row inside the band.  (See the head of this file.)
+template <typename T, int S, int B, int REGK, int R, int NW, bool FIX, bool FIXR, bool ALLON, typename ArgsT>
+__device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&xb)[MCfg<T, S, B, REGK, R, NW>::WIN + 1],
                                          typename Gran<T, 16 / (int)sizeof(T)>::type* zdst,
-                                         typename Gran<T, 16 / (int)sizeof(T)>::type* cdst, const P1Ctl& ctl, int lane,
-                                         const T SCm, const T (&ypre)[MCfg<T, S, B, REGK, R>::NV], const T (&wv)[S],
+                                         typename Gran<T, 16 / (int)sizeof(T)>::type* cdst,
+                                         const PWin<T, S, MCfg<T, S, B, REGK, R, NW>::XC, MCfg<T, S, B, REGK, R, NW>::XCL, MCfg<T, S, B, REGK, R, NW>::P1LO, MCfg<T, S, B, REGK, R, NW>::P1HI>& w0,
+                                         const P1Ctl& ctl, int lane,
+                                         const T SCm, const T (&ypre)[MCfg<T, S, B, REGK, R, NW>::NV], const T (&wv)[S],
                                          T (&acc)[S], T (&zown)[S], double& cost) {
-  using C = MCfg<T, S, B, REGK, R>;
+  using C = MCfg<T, S, B, REGK, R, NW>;
   using GT = typename Gran<T, C::G>::type;
   constexpr int HB = C::HB, NV = C::NV, WIN = C::WIN, G = C::G, PL = C::PL;
   const bool do_z = ALLON || ctl.do_z, do_r = ALLON || ctl.do_r;
@@ -128,15 +132,15 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
     for (int v = 0; v < NV; ++v) bx[v] = T(0);
     // window rows double-buffered by hand, a scheduling barrier per row: left alone the scheduler issues the reads of ALL
     // rows of a pass first (80 registers of window data) and the allocator spills around them
+    // (row 0 arrives preloaded -- w0, requested in front of the step barrier)
     PWin<T, S, C::XC, C::XCL, C::P1LO, (S - 1 + 2 * HB)> wd[2];
-    wd[0].load(xb[0]);
 #pragma unroll
     for (int i = 0; i < B; ++i) {  // blur row a = i of the residual row (x row zrow - HB + a = gr + i)
       if (i + 1 < B) wd[(i + 1) & 1].load(xb[i + 1]);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
 #pragma unroll
-        for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, i, e) * wd[i & 1].at(v + e - 2 * HB);
+        for (int e = 0; e < B; ++e) bx[v] += blur_tap<B>(A, i, e) * (i == 0 ? w0.at(v + e - 2 * HB) : wd[i & 1].at(v + e - 2 * HB));
       }
       pin(bx);
     }
@@ -179,11 +183,12 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); x0s[pc] = T(0); }
     PWin<T, S, C::XC, C::XCL, 0, S - 1 + WIN> wr[2];
-    wr[0].load(xb[0]);
+#pragma unroll
+    for (int p0 = 0; p0 <= S - 1 + WIN; ++p0) wr[0].g[floordiv(p0, G) - wr[0].GLO][posmod(p0, G)] = w0.at(p0);   // (register renaming)
 #pragma unroll
     for (int i = 0; i <= WIN; ++i) {
       if (i + 1 <= WIN) wr[(i + 1) & 1].load(xb[i + 1]);   // (rows below the image hold zeros: read, not used)
-      if (FIX && ctl.gr + i >= ctl.H) {
+      if (FIXR && ctl.gr + i >= ctl.H) {
         // window row below the image: its taps are the reference's skipped taps = zero differences; the self term in
         // its (sgn + 1) / 2 form still counts them with 1/2 each (the same additions as the tile kernel's masked path)
         if (REGK == 2 && sizeof(T) == 8 && i < R) {
@@ -249,7 +254,7 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
       cr2v[pc] = cr2;
     }
     if (FIX) {
-      if (ctl.gr < 0) {  // rows above the image (halo rows of the top band)
+      if (FIXR && ctl.gr < 0) {  // rows above the image (halo rows of the top band)
 #pragma unroll
         for (int pc = 0; pc < S; ++pc) cr2v[pc] = T(0);
       }
@@ -268,10 +273,10 @@ __device__ __forceinline__ void m_phase1(const ArgsT& A, const typename Gran<T, 
 
 // 2*lambda*w*r of ONE left-halo-column pixel (column COL < 0 relative to the strip), one row per lane.
 //   xe[i]  per-lane ELEMENT offset of x row gr + i's slot,  ce: of the 2*lambda*w*r row's slot (xs / cs as T arrays)
-template <typename T, int S, int B, int REGK, int R, int COL, bool BORDER, typename ArgsT>
+template <typename T, int S, int B, int REGK, int R, int NW, int COL, bool BORDER, typename ArgsT>
 __device__ __forceinline__ void m_halo_col(const ArgsT& A, const T* __restrict__ xs, T* __restrict__ cs, T wt,
-                                           const int (&xe)[MCfg<T, S, B, REGK, R>::WIN + 1], int ce, int gr, int gc) {
-  using C = MCfg<T, S, B, REGK, R>;
+                                           const int (&xe)[MCfg<T, S, B, REGK, R, NW>::WIN + 1], int ce, int gr, int gc) {
+  using C = MCfg<T, S, B, REGK, R, NW>;
   constexpr int WIN = C::WIN, G = C::G;
   auto xel = [](int p) constexpr { return ((posmod(floordiv(p, G) * G, S) / G) * C::XC + C::XCL + floordiv(floordiv(p, G) * G, S)) * G + posmod(p, G); };
   const T SC = m_scale<T>();
@@ -304,15 +309,34 @@ __device__ __forceinline__ void m_halo_col(const ArgsT& A, const T* __restrict__
 // btv_regularizer.cpp:137-162); acc holds the self term of pass 1 on entry, the gradient on exit ----
 //   xb[i] / cb[i]  first granule (+ lane) of x / 2*lambda*w*r row gr - i;  zb[a]: of zh row gr - HB + a;  hb[i]: the halo
 //   ring's granule of row gr - i (pixels left of the strip)
-template <typename T, int S, int B, int REGK, int R, typename ArgsT>
-__device__ __forceinline__ void m_phase2(const ArgsT& A, const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&xb)[MCfg<T, S, B, REGK, R>::RU + 1],
-                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&cb)[MCfg<T, S, B, REGK, R>::RU + 1],
-                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&hb)[MCfg<T, S, B, REGK, R>::RU + 1],
-                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&zb)[B], int lane, bool want_data, bool want_reg,
-                                         const T (&zown)[S], T (&acc)[S]) {
-  using C = MCfg<T, S, B, REGK, R>;
+template <typename T, int S, int B, int REGK, int R, int NW, typename ArgsT, typename Mid>
+__device__ __forceinline__ void m_phase2(const ArgsT& A, const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&xb)[MCfg<T, S, B, REGK, R, NW>::RU + 1],
+                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&cb)[MCfg<T, S, B, REGK, R, NW>::RU + 1],
+                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&hb)[MCfg<T, S, B, REGK, R, NW>::RU + 1],
+                                         const typename Gran<T, 16 / (int)sizeof(T)>::type* const (&zb)[B],
+                                         const PWin<T, S, MCfg<T, S, B, REGK, R, NW>::XC, MCfg<T, S, B, REGK, R, NW>::XCL, MCfg<T, S, B, REGK, R, NW>::P2LO, MCfg<T, S, B, REGK, R, NW>::P2HI>& xw0,
+                                         int lane, bool want_data, bool want_reg,
+                                         const T (&zown)[S], T (&acc)[S], Mid&& mid) {
+  using C = MCfg<T, S, B, REGK, R, NW>;
   constexpr int RU = C::RU;
   const T SC = m_scale<T>();
+  const bool reg_on = REGK != 0 && RU > 0 && want_reg;
+  // every read of the data part and row 0 of the regulariser part go out together (one LDS round trip, not four)
+  PWin<T, S, C::CW, 0, 0, S - 1> zw[B];
+  PWin<T, S, C::XC, C::XCL, C::P2LO, C::P2HI> xw;
+  PWin<T, S, C::CC, C::CCL, C::P2LO, C::P2HI> cw;
+  // the granule left of the strip (lane 0) comes from the halo ring: one select on the address
+  static_assert(RU == 0 || (C::P2LO >= -C::G && C::P2LO < 0), "the left window reaches one granule into the neighbour cell");
+  auto load_c = [&](int i, PWin<T, S, C::CC, C::CCL, C::P2LO, C::P2HI>& w) {
+    w.g[0] = *((lane == 0) ? hb[i] : cb[i] + w.gidx(w.GLO));
+#pragma unroll
+    for (int gi = 1; gi < w.NG; ++gi) w.g[gi] = cb[i][w.gidx(w.GLO + gi)];
+  };
+  if (B > 1 && want_data) {
+#pragma unroll
+    for (int a = 0; a < B; ++a) zw[a].load(zb[a]);
+  }
+  if (reg_on) load_c(0, cw);
   if (want_data) {
     const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
     T zz[S];
@@ -324,33 +348,22 @@ __device__ __forceinline__ void m_phase2(const ArgsT& A, const typename Gran<T, 
       for (int pc = 0; pc < S; ++pc) zz[pc] = T(0);
 #pragma unroll
       for (int a = 0; a < B; ++a) {
-        PWin<T, S, C::CW, 0, 0, S - 1> w;
-        w.load(zb[a]);
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) zz[pc] += k1_tap<B>(A, a) * w.at(pc);
+        for (int pc = 0; pc < S; ++pc) zz[pc] += k1_tap<B>(A, a) * zw[a].at(pc);
       }
     }
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) acc[pc] += sc * zz[pc];
   }
-  if (REGK != 0 && RU > 0 && want_reg) {
+  pin(acc);
+  mid();
+  if (reg_on) {
     T x0s[S], sum[S];
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) sum[pc] = T(0);
+    for (int pc = 0; pc < S; ++pc) { sum[pc] = T(0); x0s[pc] = xw0.at(pc) * SC; }
 #pragma unroll
     for (int i = 0; i <= RU; ++i) {
-      PWin<T, S, C::XC, C::XCL, C::P2LO, C::P2HI> xw;
-      PWin<T, S, C::CC, C::CCL, C::P2LO, C::P2HI> cw;
-      xw.load(xb[i]);
-      // the granule left of the strip (lane 0) comes from the halo ring: one select on the address
-      static_assert(C::P2LO >= -C::G && C::P2LO < 0, "the left window reaches one granule into the neighbour cell");
-      cw.g[0] = *((lane == 0) ? hb[i] : cb[i] + cw.gidx(cw.GLO));
-#pragma unroll
-      for (int gi = 1; gi < cw.NG; ++gi) cw.g[gi] = cb[i][cw.gidx(cw.GLO + gi)];
-      if (i == 0) {
-#pragma unroll
-        for (int pc = 0; pc < S; ++pc) x0s[pc] = xw.at(pc) * SC;
-      }
+      if (i > 0) { xw.load(xb[i]); load_c(i, cw); }
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) {
         if (REGK == 2) {
@@ -359,14 +372,16 @@ __device__ __forceinline__ void m_phase2(const ArgsT& A, const typename Gran<T, 
             for (int j = 0; j < R; ++j) {
               if (i == 0 && j == 0) continue;
               // -sgn(x[q] - x[p]) * alpha^(i+j) * 2 c[q] r[q],  q = p - (i, j)
-              sum[pc] += cw.at(pc - j) * sgn_pre<T>(__builtin_fma(-SC, xw.at(pc - j), x0s[pc]), A.powtab[i + j]);
+              const T xq = (i == 0) ? xw0.at(pc - j) : xw.at(pc - j);
+              sum[pc] += cw.at(pc - j) * sgn_pre<T>(__builtin_fma(-SC, xq, x0s[pc]), A.powtab[i + j]);
             }
           }
         } else {
-          if (i == 0) sum[pc] += cw.at(pc - 1) * sgn_pre<T>(__builtin_fma(-SC, xw.at(pc - 1), x0s[pc]), T(1));
+          if (i == 0) sum[pc] += cw.at(pc - 1) * sgn_pre<T>(__builtin_fma(-SC, xw0.at(pc - 1), x0s[pc]), T(1));
           else sum[pc] += cw.at(pc) * sgn_pre<T>(__builtin_fma(-SC, xw.at(pc), x0s[pc]), T(1));
         }
       }
+      pin(sum);
     }
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) acc[pc] += sum[pc];

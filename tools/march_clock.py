@@ -8,13 +8,16 @@ import srmap
 W = 2048; s = 4; K = 16
 shifts = [[k % s, (k // s) % s] for k in range(K)]
 ctx = srmap.Context(0)
-p = srmap.Problem(ctx, W, W, 1, K, s, shifts, 3, 1.0, srmap.F64); p.set_impl(srmap.IMPL_MARCH)
-y = torch.rand((K, 1, W // s, W // s), dtype=torch.float64, device="cuda"); x = torch.rand((1, W, W), dtype=torch.float64, device="cuda")
+f32 = "--dtype" in sys.argv and sys.argv[sys.argv.index("--dtype") + 1] == "f32"
+td = torch.float32 if f32 else torch.float64
+SR = int(sys.argv[sys.argv.index("--sr") + 1]) if "--sr" in sys.argv else 16
+p = srmap.Problem(ctx, W, W, 1, K, s, shifts, 3, 1.0, srmap.F32 if f32 else srmap.F64); p.set_impl(srmap.IMPL_MARCH)
+y = torch.rand((K, 1, W // s, W // s), dtype=td, device="cuda"); x = torch.rand((1, W, W), dtype=td, device="cuda")
 p.set_observations_device(y.data_ptr()); r = p.add_regularizer(srmap.REG_BTV, 0.01, 3, 0.5); p.update_irls_weights_device(r, x.data_ptr())
 g = torch.empty_like(x)
 for _ in range(300): p.eval_device(x.data_ptr(), g.data_ptr(), srmap.TERM_ALL)
 torch.cuda.synchronize()
-G = g.cpu().numpy()[0]
+G = g.cpu().double().numpy()[0]
 names = ["head (requests issued)", "phase 1", "wait vmcnt", "barrier 1", "phase 2 (to the store)", "store + barrier 2 + loop edge"]
 rows = np.arange(W)
 for strips, label in (([1, 2, 3, 4, 5, 6], "interior strips"), ([0], "first strip"), ([7], "last strip")):
@@ -43,7 +46,7 @@ for st in range(8):
     c0 = st * 256 + 8
     O.append(np.stack([G[:, c0 + k] for k in range(5)], axis=1).reshape(W // 64, 64, 5)[:, :16, :])
 O = np.stack(O)   # [strip, band, wave, stamp]
-t0 = O[..., 0].min()
+t0 = 0.0   # stamps are relative to each wave's own kernel entry
 print("== outside the loop (cycles, mean over workgroups and waves; relative to the chip's first kernel-entry stamp)")
 for k, nm in enumerate(["kernel entry", "window requested", "window landed + barrier", "virtual step + inputs of step 0 + barrier", "loop done"]):
     print("  %-44s %8.0f  (min %7.0f max %7.0f)" % (nm, (O[..., k] - t0).mean(), (O[..., k] - t0).min(), (O[..., k] - t0).max()))
