@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // purpose: the compiler's builtin brackets the request with s_waitcnt vmcnt(0) and waits for it in front of every
 // barrier; here the one wait is placed by hand in front of the step's first barrier.
 __device__ __forceinline__ void dma16(unsigned voff, const void* base, unsigned lds) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // workgroup barrier for LDS traffic only (no release fence over global memory: the g stores stay in flight)
