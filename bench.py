@@ -98,6 +98,29 @@ def pmc_traffic(dtype):
     return None, None
 
 
+def limiter_evidence(dtype, dev_ms_per_step):
+    """What bounds the dominant kernel according to the newest committed counter profile of this command
+    (profiles/rNN_evalz_<dtype>_pmc.json, rocprofv3 --pmc): VALU-busy fraction of the step and the share of their life
+    the waves spend parked -- stored counters (bench.py cannot profile itself) against THIS run's step time."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_evalz_%s_pmc.json" % dtype)), reverse=True):
+        try:
+            with open(path) as f:
+                c = json.load(f)["counters_mean_per_launch"]
+            # one VALU instruction occupies its SIMD ~1.8 ns at sustained clocks (f64 and select / compare class,
+            # profiles/r02_valu_rate.txt); 1024 SIMDs
+            valu_us = c["SQ_INSTS_VALU"] / 1024.0 * 1.8e-3
+            return {"valu_busy_frac": valu_us / (dev_ms_per_step * 1e3),
+                    "wave_parked_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                    "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
+                    "note": "valu_busy_frac = SQ_INSTS_VALU / 1024 SIMDs x 1.8 ns per instruction over this run's device time per "
+                            "step; wave_parked_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (barriers and s_waitcnt)",
+                    "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(cfg, lr, x0, wts, budget_s=7.0):
     """Oracle (CPU restatement of the reference) on a bounded crop of the same workload, scaled by pixel count:
     1 thread (the reference is single-threaded), then one independent crop per core (the image split in tiles)."""
@@ -116,7 +139,10 @@ def cpu_baseline(cfg, lr, x0, wts, budget_s=7.0):
         return prob, np.ascontiguousarray(x0[:1, r0 * s:r0 * s + ch, c0 * s:c0 * s + ch])
 
     # ---- one core ----
-    crop_lr = min(256, lr.shape[-1])  # LR crop 256x256 -> HR 1024x1024 (~0.65 s per evaluation)
+    # single-channel workloads (cfg2): the FULL size, >= 5 evaluations (~2.6 s each); the larger
+    # multi-channel configurations keep a crop scaled by pixel count
+    full = cfg["C"] == 1 and lr.shape[-1] * s <= 2048
+    crop_lr = lr.shape[-1] if full else min(256, lr.shape[-1])  # crop: LR 256x256 -> HR 1024x1024 (~0.65 s per evaluation)
     prob, x = make(crop_lr, 0, 0)
     t0 = time.perf_counter()
     n = 0
@@ -124,15 +150,17 @@ def cpu_baseline(cfg, lr, x0, wts, budget_s=7.0):
         prob.objective(x)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 40:
+        if (el > budget_s and (not full or n >= 5)) or n >= 40:
             break
     per_eval_crop = el / n
     ch = crop_lr * s
     frac = (ch * ch) / float(W * H * cfg["C"])
     per_eval_full = per_eval_crop / frac
     out = {"value": 1.0 / per_eval_full, "unit": "MAP gradient iterations/s", "cores": 1, "kind": "port",
-           "sample": "%d evaluations of a %dx%d HR crop (%d frames, same blur/BTV), %.2f s each, scaled by pixel count "
-                     "x%.0f to the full workload" % (n, ch, ch, K, per_eval_crop, 1 / frac),
+           "sample": ("%d evaluations of the FULL %dx%d workload (%d frames, same blur/BTV), %.2f s each" % (n, ch, ch, K, per_eval_crop))
+                     if full else
+                     ("%d evaluations of a %dx%d HR crop (%d frames, same blur/BTV), %.2f s each, scaled by pixel count "
+                      "x%.0f to the full workload" % (n, ch, ch, K, per_eval_crop, 1 / frac)),
            "ms_per_step": per_eval_full * 1e3}
     # ---- all cores: one tile of the image per thread (ctypes releases the GIL inside the C oracle) ----
     cores = os.cpu_count() or 1
@@ -193,7 +221,9 @@ def main():
                     help="N > 1: rows = HR row bands + halo exchange of x (default, strong scaling; the frame variant is timed "
                          "in the same run); frames = only the frame variant; channels = N independent channels, no "
                          "collective (weak scaling, the reference's split_channels semantics)")
-    ap.add_argument("--impl", choices=["auto", "direct", "tiled"], default="auto")
+    ap.add_argument("--impl", choices=["auto", "direct", "tiled", "march"], default="auto",
+                    help="auto = the library's choice (the 8-row tile kernel where it covers the problem); march = the marching kernel "
+                         "(kernels_zmarch.hip; opt-in, profiles/r05_march.txt)")
     ap.add_argument("--hr", type=int, default=0, help="override the HR size of the configuration (testing)")
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
                     help="ablation only: evaluate a subset of the objective terms")
@@ -253,7 +283,7 @@ def main():
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     E = 8 if args.dtype == "f64" else 4
     terms = {"all": srmap.TERM_ALL, "data": srmap.TERM_DATA, "reg": srmap.TERM_REG}[args.terms]
-    impl = {"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED}[args.impl]
+    impl = {"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED, "march": srmap.IMPL_MARCH}[args.impl]
     ctx = srmap.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream
@@ -299,7 +329,7 @@ def main():
             cfg["hr"] = args.hr
         return cfg
 
-    def run(cfg, shard, steps, warmup, only_rank0=False, n_problems=1):
+    def run(cfg, shard, steps, warmup, only_rank0=False, n_problems=1, dt=None):
         """Build this rank's part of the workload `cfg` under `shard` and time it.  only_rank0: rank 0 alone evaluates
         the whole problem (the N = 1 reference of a strong-scaling block) while the other ranks wait.  n_problems > 1:
         that many independent copies of the problem evaluated in rotation (the HBM-fed leg: from three copies on a
@@ -307,6 +337,7 @@ def main():
         Returns wall seconds per step (max over the ranks that ran), device ms per step on this rank, timed steps, ..."""
         s, K, C = cfg["s"], cfg["K"], cfg["C"]
         W = H = cfg["hr"]
+        r_dtype, r_tdtype = (dtype, tdtype) if dt is None else dt   # (the labelled f32 block runs beside an f64 line)
         blur_k, blur_s = cfg["blur"]  # 0 = no blur module
         shifts_all = [[k % s, (k // s) % s] for k in range(K)]
         solo = only_rank0 or world == 1
@@ -325,7 +356,7 @@ def main():
             (r0, r1), (e0, e1) = bands[rank]
             Hloc = e1 - e0
         Cloc = 1 if (shard == "channels" and not solo) else C
-        probs = [srmap.Problem(ctx, W, Hloc, Cloc, len(frame_ids), s, shifts, blur_k, blur_s, dtype) for _ in range(n_problems)]
+        probs = [srmap.Problem(ctx, W, Hloc, Cloc, len(frame_ids), s, shifts, blur_k, blur_s, r_dtype) for _ in range(n_problems)]
         prob = probs[0]
         # synthetic data, seeded; channel = rank under channel sharding
         gt = synth_ground_truth(W, H, max(C, world if shard == "channels" else 1))
@@ -357,7 +388,7 @@ def main():
                 if rank > 0:
                     (u0, u1), (ue0, ue1) = bands[rank - 1]
                     sd.send_up_rows = ue1 - u1
-        xs = [torch.from_numpy(x0).to(dev, tdtype).contiguous() for _ in range(n_problems)]
+        xs = [torch.from_numpy(x0).to(dev, r_tdtype).contiguous() for _ in range(n_problems)]
         gs = [torch.empty_like(x) for x in xs]
         turn = [0]
 
@@ -449,6 +480,21 @@ def main():
                            "Infinity Cache when its turn comes again, so every step streams its algorithmic bytes from HBM; "
                            "untimed for `value`"}
 
+    # ---- the other precision on the same clock (N = 1): a labelled extra block, never `value` ----
+    other_prec = None
+    if world == 1 and args.terms == "all":
+        o_name = "f32" if args.dtype == "f64" else "f64"
+        o_dt = (srmap.F32, torch.float32) if o_name == "f32" else (srmap.F64, torch.float64)
+        o_E = 4 if o_name == "f32" else 8
+        o = run(cfg, "none", max(200, args.steps // 4), min(args.warmup, 60), dt=o_dt)
+        o_bytes = b_alg_of(cfg, cfg["C"]) * o_E / E
+        other_prec = {"dtype": o_name, "value": 1.0 / o["wall_per_step"], "unit": "MAP gradient iterations/s",
+                      "ms_per_step": o["wall_per_step"] * 1e3, "device_ms_per_step": o["dev_ms_per_step"],
+                      "timed_steps": o["timed_steps"], "algorithmic_bytes_per_step": o_bytes,
+                      "roofline_frac": o_bytes / (o["dev_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "note": "same workload, same run, the other arithmetic type (f64 is the parity mode = the reference's "
+                              "arithmetic; f32 storage and arithmetic with f64 cost reductions); not part of `value`"}
+
     # ---- configs[2] block: the configuration of the curve that is large enough to scale (rows, strong scaling) ----
     cfg3_block = None
     if args.config == "cfg2" and not args.no_cfg3 and args.shard != "channels" and args.terms == "all":
@@ -502,6 +548,11 @@ def main():
                        "parity_mode": args.dtype == "f64"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # `bound` names the roofline the path is PRICED against (its algorithmic bytes over HBM); what
+                         # limits the kernel at this size is not bandwidth: counter traffic ~1.05x algorithmic at < half of
+                         # peak -- the waves are parked (barriers, request and LDS waits) a third of their life
+                         "limited_by": "latency/occupancy (not bandwidth)",
+                         "limiter_evidence": limiter_evidence(args.dtype, res["dev_ms_per_step"]),
                          "residency": "one problem re-evaluated every step: its %.0f MB working set stays in the 256 MiB Infinity "
                                       "Cache between steps (the contract's step); `hbm_fed` is the same step with the inputs "
                                       "coming from HBM" % (b_alg * share / 1e6),
@@ -511,13 +562,15 @@ def main():
                                             "FETCH_SIZE correction of MI355X_MICROARCH.md") if traffic_src else None,
                          "algorithmic_bytes_per_step": b_alg * share,
                          "kernel": "whole evaluation (every kernel of one step: k_eval_z with its in-kernel reduction), HIP "
-                                   "events on the launch stream; the dominant kernel alone is in profiles/r04_bench_*_kernel_stats.csv"},
+                                   "events on the launch stream; the dominant kernel alone is in profiles/r05_bench_*_kernel_stats.csv"},
         }
         if second is not None:
             out["frames_variant"] = {"value": 1.0 / second["wall_per_step"], "unit": "MAP gradient iterations/s",
                                      "ms_per_step": second["wall_per_step"] * 1e3, "scaling": "strong",
                                      "device_ms_per_step": second["dev_ms_per_step"], "timed_steps": second["timed_steps"],
                                      "collective_per_step": collective["frames"]}
+        if other_prec is not None:
+            out[other_prec["dtype"]] = other_prec
         if cfg3_block is not None:
             out["cfg3"] = cfg3_block
         if world == 1 and not args.no_cpu_baseline:
