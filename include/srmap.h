@@ -126,6 +126,9 @@ typedef struct {
 int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* desc,
                          srmap_problem** out);
 void srmap_problem_destroy(srmap_problem* p);
+/* Under frame sharding (srmap_eval_sharded_device / srmap_solve_sharded with SRMAP_SHARD_FRAMES) this call and the
+ * regulariser calls (add / clear) are COLLECTIVE: every rank makes them in the same order between the same
+ * evaluations -- the ranks agree by an all-reduce on how the regulariser is split whenever one of them changes. */
 int srmap_problem_set_impl(srmap_problem* p, int impl /* srmap_impl */);
 /* The family the next evaluation will run (SRMAP_IMPL_DIRECT / TILED): how a caller learns that AUTO fell
  * back to the direct kernels (geometry outside the tile kernels' coverage, or a sub-pixel shift on a 1/32-px
@@ -280,6 +283,10 @@ typedef struct {
   int split_channels;                    /* 0 */
   int max_num_irls_iterations;           /* 20 */
   double irls_cost_difference_threshold; /* 1e-5 */
+  int host_paced_passes;                 /* 0.  No reference counterpart: 1 = every CG pass waits for the host's
+                                            answer before the next is queued (the order up to round 3) instead of
+                                            chaining the passes whose inputs are already on the device.  Same
+                                            arithmetic, same result bit for bit: a debugging / measurement switch. */
 } srmap_irls_options;
 void srmap_irls_options_default(srmap_irls_options* o);
 
@@ -298,9 +305,9 @@ typedef struct {
 /* IRLSMapSolver::Solve(initial_estimate) irls_map_solver.cpp:192-265:
  * x0 / x_out are [C][H][W] host doubles.  The iterate, gradient and CG vectors
  * stay on the GPU; only scalars cross PCIe per evaluation.  Passes whose inputs are
- * already on the device are queued without waiting for the host (un-sharded solves);
- * SRMAP_SOLVER_CHAIN=0 in the environment restores the host-paced order (same
- * arithmetic, same result bit for bit: a debugging / measurement switch). */
+ * already on the device are queued without waiting for the host (un-sharded solves;
+ * options->host_paced_passes = 1 restores the host-paced order).  The library reads no
+ * environment variable. */
 int srmap_solve(srmap_problem* p, const srmap_irls_options* options,
                 const double* x0, double* x_out, srmap_solve_report* report);
 

@@ -88,6 +88,7 @@ struct Fin {
   int pub_n;
   double* tag_slot;
   double tag;
+  double* timeout_flag;   // sticky device word: a reduction gave up waiting for a block (srmap_solve reports it)
 };
 
 // Block partials of up to 3 sums (row 0 a max when max0).  Two-launch scheme: part[k * gridDim.x + blockIdx.x].
@@ -113,6 +114,7 @@ __device__ __forceinline__ bool block_partials3(double s0, double s1, double s2,
   if (fin.gran == nullptr || (int)blockIdx.x != nbk - 1) return false;
   __syncthreads();  // red[] is reused below
   double v0 = 0, v1 = 0, v2 = 0;
+  bool timed_out = false;
   for (int i = threadIdx.x; i < nbk; i += 256) {
     unsigned long long a0 = 0, a1 = 0, a2 = 0;  // +0.0 for absent rows
     // bounded like the tile kernel's finisher (~2 s): a block that never publishes ends the pass with NaN sums (the
@@ -122,9 +124,10 @@ __device__ __forceinline__ bool block_partials3(double s0, double s1, double s2,
       if (rows > 1) a1 = ld_dev(fin.gran + (size_t)nbk + i);
       if (rows > 2) a2 = ld_dev(fin.gran + (size_t)2 * nbk + i);
       if (a0 != kArm && a1 != kArm && a2 != kArm) break;
-      if (spins > (1u << 22)) break;  // kArm is a NaN pattern: the sums become NaN
+      if (spins > (1u << 22)) { timed_out = true; break; }
       if (spins < 64) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
     }
+    if (timed_out) continue;   // NOT re-armed: a block that arrives late must not publish into a fresh slot
     if (rows > 0) st_dev(fin.gran + i, kArm);  // re-armed for the next pass
     if (rows > 1) st_dev(fin.gran + (size_t)nbk + i, kArm);
     if (rows > 2) st_dev(fin.gran + (size_t)2 * nbk + i, kArm);
@@ -136,9 +139,17 @@ __device__ __forceinline__ bool block_partials3(double s0, double s1, double s2,
   v0 = max0 ? wmax(v0) : wsum(v0);
   v1 = wsum(v1);
   v2 = wsum(v2);
+  // a time-out anywhere in the block makes EVERY row NaN (fmax would drop a NaN partial of the max row): the host's
+  // stopping rules end the solve, srmap_solve reports SRMAP_EHIP (sticky word fin.timeout_flag) and re-initialises the granules
+  const bool any_to = __syncthreads_or(timed_out ? 1 : 0) != 0;
   if (lane == 0) { red[0][wid] = v0; red[1][wid] = v1; red[2][wid] = v2; }
   __syncthreads();
   if (threadIdx.x != 0) return false;
+  if (any_to) {
+    const double qn = __builtin_nan("");
+    red[0][0] = qn; red[1][0] = qn; red[2][0] = qn;
+    if (fin.timeout_flag != nullptr) fin.timeout_flag[0] = 1.0;
+  }
   const double t0 = max0 ? fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))
                          : (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
   const double t1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
@@ -503,10 +514,12 @@ int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsi
     // The split is a COLLECTIVE decision: a rank whose own frame subset has no tile plan (a shift on a 1/32-px rounding
     // tie, a per-rank SRMAP_IMPL_DIRECT, ...) cannot evaluate a band, and if it went its own way the regulariser would
     // be counted twice or not at all.  The ranks agree once (minimum of their flags over the communicator; cached on
-    // the problem until its plan, implementation choice, term set or communicator changes); any rank that cannot
-    // band-split sends everybody to reg_rank.
+    // the problem until its plan generation -- bumped by every re-plan and every srmap_problem_set_impl --, term set or
+    // communicator changes); any rank that cannot band-split sends everybody to reg_rank.  The agreement is itself a
+    // collective: under frame sharding srmap_problem_set_impl and the regulariser calls are COLLECTIVE too (every rank
+    // makes them in the same order between the same evaluations; include/srmap.h), or one rank would enter it alone.
     const bool mine = ztile_reg_band_ok(p, terms);
-    if (p->band_comm != (const void*)c || p->band_terms != terms || p->band_impl != p->impl || p->band_plan != p->zplan) {
+    if (p->band_comm != (const void*)c || p->band_terms != terms || p->band_gen != p->plan_gen) {
       double flag = mine ? 0.0 : 1.0;  // max over the ranks of "I cannot" == 0  <=>  every rank can
       SRMAP_HIP(p->ctx, hipMemcpyAsync(p->d_cost + 7, &flag, sizeof(double), hipMemcpyHostToDevice, st));
       rc = comm_allreduce(c, p->d_cost + 7, 1, SRMAP_F64, 1, st);
@@ -514,7 +527,7 @@ int shard_eval(srmap_problem* p, srmap_comm* c, const srmap_shard_desc* sd, unsi
       SRMAP_HIP(p->ctx, hipMemcpyAsync(&flag, p->d_cost + 7, sizeof(double), hipMemcpyDeviceToHost, st));
       SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
       p->band_all = flag == 0.0;
-      p->band_comm = c; p->band_terms = terms; p->band_impl = p->impl; p->band_plan = p->zplan;
+      p->band_comm = c; p->band_terms = terms; p->band_gen = p->plan_gen;
     }
     const bool band = mine && p->band_all;
     if (band) {
@@ -575,10 +588,12 @@ struct DeviceCG {
   bool reduce_scalars = false;  // row / channel shards: the owned-element sums are all-reduced
   bool published = false;       // the last evaluation's finish kernel published {f, g.d} + tag (fetch_f_gd just waits)
   // chained passes (run_cg): launches whose inputs are already on the device are queued without waiting for the host.
-  // SRMAP_SOLVER_CHAIN=0 in the environment turns this off (every pass then waits for the host's answer, as up to
-  // round 3): same arithmetic, same results bit for bit -- tests/test_gpu_solve_parity.py compares the two.
-  bool chain_enabled = [] { const char* e = std::getenv("SRMAP_SOLVER_CHAIN"); return !(e && e[0] == '0'); }();
-  bool chained() const { return fused() && chain_enabled; }
+  // srmap_irls_options::host_paced_passes turns this off (every pass then waits for the host's answer, as up to
+  // round 3): same arithmetic, same results bit for bit -- tests/test_gpu_solve_parity.py compares the two.  Chaining
+  // applies to un-sharded solves only: under frame sharding a speculative first-trial evaluation would queue a
+  // gradient + cost all-reduce that every rank has to match before the host has decided to keep it.
+  bool chain_enabled = true;
+  bool chained() const { return fused() && chain_enabled && (shard == nullptr || comm == nullptr); }
   // x, g: current point and gradient; xk/dk: accepted point and direction; dn: next direction;
   // d: normalised direction; gp: the gradient at xk while the line search writes its trial gradients to g (the two
   // buffers swap; mincg's yk = g_{k+1} - g_k is formed on the fly).  The line-search base is xk itself.
@@ -658,6 +673,7 @@ struct DeviceCG {
     if (fused()) {
       tag += 1.0;
       f.gran = gran; f.out = out ? out : hs; f.cost_src = with_cost ? (const double*)p->d_cost : nullptr;
+      f.timeout_flag = dscal + 15;
       f.pub_src = pub_src; f.pub_dst = pub_dst; f.pub_n = pub_n;
       f.tag_slot = hs + 15; f.tag = tag;
     }
@@ -754,7 +770,7 @@ struct DeviceCG {
   int direction(const T* dk_or_null, double beta, bool publish_cost = false, const double* beta_dev = nullptr) {
     Fin f{};
     if (fused()) {
-      f.gran = gran; f.out = dscal + 4;
+      f.gran = gran; f.out = dscal + 4; f.timeout_flag = dscal + 15;
       if (publish_cost) {
         tag += 1.0;
         f.pub_src = (const double*)p->d_cost; f.pub_dst = hs; f.pub_n = 1;  // hs[0] = f, then hs[1..2] = the norms
@@ -1185,6 +1201,7 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
   hipStream_t st = p->ctx->stream;
   DeviceCG<T> cg;
   cg.p = p; cg.st = st; cg.n = npts; cg.comm = comm; cg.shard = shard;
+  cg.chain_enabled = o.host_paced_passes == 0;
   cg.ow.on = 0; cg.ow.e0 = 0; cg.ow.e1 = npts; cg.ow.W = geo.W; cg.ow.H = geo.H; cg.ow.r0 = 0; cg.ow.r1 = geo.H;
   if (mode == SRMAP_SHARD_ROWS) { cg.ow.on = 1; cg.ow.r0 = shard->own_row0; cg.ow.r1 = shard->own_row1; cg.reduce_scalars = true; }
   if (mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) {
@@ -1251,6 +1268,21 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
   rep.waits = cg.waits;
   p->view_c0 = saved_c0;
   p->view_C = saved_C;
+  {
+    // A reduction that gave up waiting for a workgroup (the tile kernel's in-kernel finish: sticky word d_cost[6]; a CG
+    // pass: dscal[15]) left NaN sums behind -- the stopping rules ended the run -- and its granules un-re-armed.  The
+    // evaluations inside a solve never look at the word (they pass no cost pointer): look now, re-initialise, report.
+    double flags[2] = {0.0, 0.0};
+    (void)hipStreamSynchronize(st);
+    if (p->d_cost) (void)hipMemcpy(&flags[0], p->d_cost + 6, sizeof(double), hipMemcpyDeviceToHost);
+    if (cg.dscal) (void)hipMemcpy(&flags[1], cg.dscal + 15, sizeof(double), hipMemcpyDeviceToHost);
+    if (flags[0] != 0.0 || flags[1] != 0.0) {
+      (void)hipDeviceSynchronize();
+      ztile_rearm(p);
+      if (p->d_cost) (void)hipMemset(p->d_cost + 6, 0, sizeof(double));
+      if (rc == SRMAP_OK) rc = set_error(p->ctx, SRMAP_EHIP, "a device-side reduction timed out waiting for a workgroup during the solve (device fault or a wedged queue)");
+    }
+  }
   cg.release();
   if (report) *report = rep;
   return rc;

@@ -505,6 +505,7 @@ int srmap_problem_create(srmap_ctx* ctx, const srmap_problem_desc* d, srmap_prob
   // context's (non-blocking) stream and wait, so no legacy-stream work is left behind the creation
   if (hipMemsetAsync(p->d_cost, 0, sizeof(double) * 8, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
     return fail(set_error(ctx, SRMAP_EHIP, "clearing the cost scalars failed"));
+  p->plan_gen++;
   if (ztile_plan(p)) ztile_preload(p);
   *out = p;
   return SRMAP_OK;
@@ -526,6 +527,7 @@ int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
   if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_MARCH) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
+  p->plan_gen++;
   return SRMAP_OK;
 }
 
@@ -614,6 +616,7 @@ int srmap_add_regularizer(srmap_problem* p, int kind, double lambda, int btv_ran
   }
   if (reg_index) *reg_index = p->nreg;
   p->nreg++;
+  p->plan_gen++;
   if (ztile_plan(p)) ztile_preload(p);
   return SRMAP_OK;
 }
@@ -622,6 +625,7 @@ int srmap_clear_regularizers(srmap_problem* p) {
   if (!p) return SRMAP_EINVAL;
   for (int r = 0; r < p->nreg; ++r) if (p->reg[r].weights) { (void)hipFree(p->reg[r].weights); p->reg[r].weights = nullptr; }
   p->nreg = 0;
+  p->plan_gen++;
   if (ztile_plan(p)) ztile_preload(p);
   return SRMAP_OK;
 }
@@ -834,6 +838,7 @@ void srmap_irls_options_default(srmap_irls_options* o) {
   o->split_channels = 0;
   o->max_num_irls_iterations = 20;
   o->irls_cost_difference_threshold = 1.0e-5;
+  o->host_paced_passes = 0;
 }
 
 int srmap_solve_sharded(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard,

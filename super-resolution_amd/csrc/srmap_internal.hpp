@@ -126,9 +126,10 @@ struct srmap_problem {
   // frame sharding: whether EVERY rank of the communicator can evaluate the regulariser of a row band (agreed once by an
   // all-reduce, solver.hip shard_eval); the key it was agreed for
   const void* band_comm = nullptr;
-  const void* band_plan = nullptr;
+  unsigned long long plan_gen = 1;   // bumped whenever the tile plan or the implementation choice changes (a freed and
+                                     // re-allocated plan can come back at the same address: pointer identity is no key)
+  unsigned long long band_gen = 0;   // generation the agreement below was reached for
   unsigned band_terms = 0;
-  int band_impl = -1;
   bool band_all = false;
   int nreg = 0;
   srmap::RegSpec reg[srmap::kMaxRegularizers];

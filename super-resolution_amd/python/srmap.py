@@ -40,7 +40,8 @@ class IrlsOptions(C.Structure):
                 ("parameter_variation_threshold", C.c_double),
                 ("split_channels", C.c_int),
                 ("max_num_irls_iterations", C.c_int),
-                ("irls_cost_difference_threshold", C.c_double)]
+                ("irls_cost_difference_threshold", C.c_double),
+                ("host_paced_passes", C.c_int)]
 
 
 class SolveReport(C.Structure):

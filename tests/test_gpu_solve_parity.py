@@ -96,10 +96,10 @@ def test_cfg2_class_solve_matches_oracle(sr, ctx, impl):
     assert psnr_ref < psnr0  # the reference objective's minimiser fits the noise: the drop is the reference's behaviour
 
 
-def test_chained_passes_equal_host_paced_passes(sr, ctx, monkeypatch):
+def test_chained_passes_equal_host_paced_passes(sr, ctx):
     """The solver queues passes whose inputs are already on the device without waiting for the host (the first trial
     evaluation behind the normalisation pass, the direction pass behind the beta sums: csrc/solver.hip run_cg).  With
-    SRMAP_SOLVER_CHAIN=0 every pass waits for the host as before: the two must agree bit for bit."""
+    srmap_irls_options.host_paced_passes = 1 every pass waits for the host as before: the two must agree bit for bit."""
     import bench
     s, K, W, H = 4, 16, 256, 256
     shifts = [[k % s, (k // s) % s] for k in range(K)]
@@ -110,13 +110,13 @@ def test_chained_passes_equal_host_paced_passes(sr, ctx, monkeypatch):
     x0 = bench.bilinear_upsample(lr[0], s)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SRMAP_SOLVER_CHAIN", mode)
         p = sr.Problem(ctx, W, H, 1, K, s, shifts, 3, 1.0, sr.F64)
         p.set_observations(lr)
         p.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
         opts = sr.default_irls_options()
         opts.max_num_irls_iterations = 3
         opts.max_num_solver_iterations = 30
+        opts.host_paced_passes = 0 if mode == "1" else 1
         x, rep = p.solve(x0, opts)
         out[mode] = (x, rep.irls_rounds, rep.cg_iterations, rep.evaluations, rep.final_cost)
     assert out["1"][1:] == out["0"][1:]

@@ -13,6 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="f64"); ap.add_argument("--hr", type=int, default=2048)
     ap.add_argument("--irls", type=int, default=2); ap.add_argument("--cg", type=int, default=20)
+    ap.add_argument("--host-paced", action="store_true", help="srmap_irls_options.host_paced_passes = 1 (every CG pass waits for the host)")
     a = ap.parse_args()
     S, K, W = 4, 16, a.hr
     gt = bench.synth_ground_truth(W, W, 1)
@@ -28,6 +29,7 @@ def main():
     opts = srmap.default_irls_options()
     opts.max_num_irls_iterations = a.irls
     opts.max_num_solver_iterations = a.cg
+    opts.host_paced_passes = 1 if a.host_paced else 0
     for attempt in range(2):  # the second solve is the steady state (no first-launch code loading)
         t0 = time.perf_counter()
         x, rep = prob.solve(x0, opts)
