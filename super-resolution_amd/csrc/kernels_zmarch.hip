@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 ? 4 : 2 * SRMAP_EXP_MWG8)) void 
 #ifndef SRMAP_EXP_MNW32
 #define SRMAP_EXP_MNW32 8
 #endif
-template <typename T> struct MShape { static constexpr int NW = sizeof(T) == 8 ? 16 : SRMAP_EXP_MNW32; static constexpr int WG_PER_CU = (NW == 16 ? 1 : SRMAP_EXP_MWG8); };
+template <typename T> struct MShape { static constexpr int NW = SRMAP_EXP_MTILE ? 8 : (sizeof(T) == 8 ? 16 : SRMAP_EXP_MNW32); static constexpr int WG_PER_CU = (NW == 16 ? 1 : SRMAP_EXP_MWG8); };
 
 template <typename T>
 bool zmarch_covers(const srmap_problem* p, const Geometry& geo, const ZPlan& z, int regk, int regr, unsigned terms,
@@ -545,6 +545,7 @@ bool zmarch_covers(const srmap_problem* p, const Geometry& geo, const ZPlan& z, 
   int rows = (geo.H + nb - 1) / nb;
   rows = (rows + SR - 1) / SR * SR;
   if (rows < 2 * SR) rows = 2 * SR;   // small images: fewer workgroups than the chip holds (a band amortises its prologue)
+  if (SRMAP_EXP_MTILE) rows = SR;
   if (rows > geo.H) rows = geo.H;
   *nstrips = ns; *band_rows = rows;
   return true;
@@ -600,7 +601,7 @@ template bool zmarch_covers<double>(const srmap_problem*, const Geometry&, const
 
 void zmarch_preload() {
   hipFuncAttributes attr;
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_m<double, 4, 3, 2, 3, 16, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_m<double, 4, 3, 2, 3, MShape<double>::NW, false>));
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_m<float, 4, 3, 2, 3, MShape<float>::NW, false>));
 }
 

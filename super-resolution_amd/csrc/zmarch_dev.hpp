@@ -41,7 +41,10 @@ struct MCfg {
   static constexpr int XLO = zmax(RU, (B > 1) ? 2 * HB : 0);   // x rows above the step's first row
   static constexpr int XHI = zmax(WIN, ZA + HB);               // x rows below the step's last row
   static constexpr int XWIN = XLO + SR + XHI;     // x rows a step reads
-  static constexpr int NXR = XWIN + SR;           // ring: window + the next step's SR new rows
+#ifndef SRMAP_EXP_MTILE
+#define SRMAP_EXP_MTILE 0   // measurement: 8-row bands of ONE step (a tile decomposition on the marching kernel's data path)
+#endif
+  static constexpr int NXR = SRMAP_EXP_MTILE ? XWIN : XWIN + SR;   // ring: window + the next step's SR new rows
   static constexpr int ZRG = PL * CW;
   static constexpr int NZR = (B > 1) ? SR + 2 * HB : 1;
   static constexpr int CCL = 0, CC = CW;          // the left halo columns live in their own small ring (hs)
