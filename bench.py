@@ -109,11 +109,12 @@ def limiter_evidence(dtype, dev_ms_per_step):
                 c = json.load(f)["counters_mean_per_launch"]
             # one VALU instruction occupies its SIMD ~1.8 ns at sustained clocks (f64 and select / compare class,
             # profiles/r02_valu_rate.txt); 1024 SIMDs
-            valu_us = c["SQ_INSTS_VALU"] / 1024.0 * 1.8e-3
+            per_inst_ns = 1.8 if dtype == "f64" else 1.3   # f32: fma / add ~1.0 ns, select / compare / med3 ~1.8 ns
+            valu_us = c["SQ_INSTS_VALU"] / 1024.0 * per_inst_ns * 1e-3
             return {"valu_busy_frac": valu_us / (dev_ms_per_step * 1e3),
                     "wave_parked_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                     "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
-                    "note": "valu_busy_frac = SQ_INSTS_VALU / 1024 SIMDs x 1.8 ns per instruction over this run's device time per "
+                    "note": "valu_busy_frac = SQ_INSTS_VALU / 1024 SIMDs x 1.8 ns (f64) / 1.3 ns (f32) per instruction over this run's device time per "
                             "step; wave_parked_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (barriers and s_waitcnt)",
                     "source": os.path.relpath(path, ROOT)}
         except Exception:
@@ -228,6 +229,7 @@ def main():
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
                     help="ablation only: evaluate a subset of the objective terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-precision", action="store_true", help="skip the labelled block of the other arithmetic type (profiling runs)")
     ap.add_argument("--no-hbm-fed", action="store_true", help="skip the HBM-fed leg of the roofline (N = 1)")
     ap.add_argument("--no-cfg3", action="store_true",
                     help="skip the configs[2] block (rows strong scaling of the 16-frame RGB 4096x4096 problem) that a "
@@ -482,7 +484,7 @@ def main():
 
     # ---- the other precision on the same clock (N = 1): a labelled extra block, never `value` ----
     other_prec = None
-    if world == 1 and args.terms == "all":
+    if world == 1 and args.terms == "all" and not args.no_other_precision:
         o_name = "f32" if args.dtype == "f64" else "f64"
         o_dt = (srmap.F32, torch.float32) if o_name == "f32" else (srmap.F64, torch.float64)
         o_E = 4 if o_name == "f32" else 8

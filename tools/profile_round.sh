@@ -8,8 +8,8 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for d in f64 f32; do
-  B="python $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hbm-fed --no-cfg3 --dtype $d"
-  BK="python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-hbm-fed --no-cfg3 --dtype $d"
+  B="python $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hbm-fed --no-cfg3 --no-other-precision --dtype $d"
+  BK="python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-hbm-fed --no-cfg3 --no-other-precision --dtype $d"
   timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$d -o kt -- $BK > $out/kt_$d.log 2>&1
   timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch_$d -o pmc -- $B > /dev/null 2>&1
   timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write_$d -o pmc -- $B > /dev/null 2>&1
