@@ -285,8 +285,10 @@ typedef struct {
   double irls_cost_difference_threshold; /* 1e-5 */
   int host_paced_passes;                 /* 0.  No reference counterpart: 1 = every CG pass waits for the host's
                                             answer before the next is queued (the order up to round 3) instead of
-                                            chaining the passes whose inputs are already on the device.  Same
-                                            arithmetic, same result bit for bit: a debugging / measurement switch. */
+                                            chaining the passes whose inputs are already on the device, and every
+                                            trial point of the line search is formed by its own n-vector pass
+                                            instead of inside the evaluation.  Same arithmetic, same result bit
+                                            for bit: a debugging / measurement switch. */
 } srmap_irls_options;
 void srmap_irls_options_default(srmap_irls_options* o);
 

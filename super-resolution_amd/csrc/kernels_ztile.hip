@@ -111,7 +111,10 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (A.sel_mode == 1) return;
     const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
     const BorderArgs<T>& Bd = *A.bd;
-    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
+    if (bidx * C::NT < Bd.n_ring) {
+      if (WD && A.fold_xk != nullptr) border_block<T, S, B, C::NT, WD, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
+      else border_block<T, S, B, C::NT, WD, false>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
+    }
     else if (threadIdx.x == 0) {
       const int nbb = A.nby * gridDim.x;
       put_partial<WD>(A, (size_t)A.n_tile_partials + (size_t)blockIdx.z * nbb + bidx, 0.0, 0.0);
@@ -140,7 +143,8 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   const int ch = blockIdx.z;
   const size_t N = (size_t)A.W * A.H;
   const size_t nl = (size_t)A.wl * A.hl;
-  const T* xplane = A.x + (size_t)ch * N;
+  const bool fold = WD && A.fold_xk != nullptr;   // uniform: the window is xk + stp * d (solver line search)
+  const T* xplane = (fold ? A.fold_xk : A.x) + (size_t)ch * N;
   const int gr = R0 + wv;          // global HR row of this thread
   const int gc0 = C0 + S * lane;   // first global HR column of this thread
   const int cellg = CJ0 + lane;
@@ -156,6 +160,9 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
   // served two lanes each)
   constexpr bool XT = SRMAP_EXP_XT != 0 && ARI >= 2 && (C::NW - 1) + (ARI - 1) * C::NW >= C::XR && C::XR * EXTRA <= 64;
   T va[ARI][S], vb[ARI][S], ma[ARI], mb[ARI];
+  T vda[WD ? ARI : 1][S], vdb[WD ? ARI : 1][S];   // WD: the direction at the window's elements (fold)
+  bool owna[ARI] = {}, ownb[ARI] = {};
+  size_t xoa[ARI] = {}, xob[ARI] = {};
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
     const bool xt_slot = XT && it == ARI - 1 && wv == C::NW - 1;  // uniform
@@ -172,6 +179,28 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (!XT) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
+    }
+    if (WD) {  // the direction at the same elements (requested with the window; combined when the window goes to LDS)
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) { vda[it][pc] = T(0); vdb[it][pc] = T(0); }
+      if (fold) {
+        const T* dpl = A.dvec + (size_t)ch * N;
+        const T* da = dpl + (sa - xplane);
+        const T* db = dpl + (sb - xplane);
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) vda[it][pc] = da[pc];
+        if (!XT) {
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) vdb[it][pc] = db[pc];
+        }
+        // where the window element is one of the tile's OWN pixels (not a halo element, inside the image) the trial point
+        // is also written out: the solver's x holds it after the evaluation, as after k_axpy_out
+        const int orow = row - C::HU;
+        owna[it] = ina && orow >= 0 && orow < C::TH && gca >= CJ0 && gca < CJ0 + C::CW;
+        ownb[it] = inb && orow >= 0 && orow < C::TH && gcb >= CJ0 && gcb < CJ0 + C::CW;
+        xoa[it] = (size_t)grr * A.W + (size_t)gca * S;
+        xob[it] = (size_t)grr * A.W + (size_t)gcb * S;
+      }
     }
     // scale 2^Q inside the image, 0 outside: applied as ONE multiply when the tile goes to LDS -- a select on the
     // loaded value makes the compiler wait for this row group before it requests the next one
@@ -231,6 +260,26 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 :
     if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
   }
 
+  if (WD && fold) {  // trial point: x = xk + stp * d, element by element the expression of solver.hip's k_axpy_out
+    T* xout = A.fold_x + (size_t)ch * N;
+#pragma unroll
+    for (int it = 0; it < ARI; ++it) {
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) va[it][pc] = va[it][pc] + A.fold_stp * vda[it][pc];
+      if (owna[it]) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) xout[xoa[it] + pc] = va[it][pc];
+      }
+      if (!XT) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) vb[it][pc] = vb[it][pc] + A.fold_stp * vdb[it][pc];
+        if (ownb[it]) {
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) xout[xob[it] + pc] = vb[it][pc];
+        }
+      }
+    }
+  }
   // ---------------- x tile -> LDS, polyphase ----------------
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
@@ -718,6 +767,18 @@ bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms) {
   return active == 1;
 }
 
+bool ztile_can_fold(const srmap_problem* p) {
+  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
+  if (!z || z->subpix || p->impl == SRMAP_IMPL_DIRECT || p->impl == SRMAP_IMPL_MARCH || p->ov_hook != nullptr) return false;
+  for (int r = 0; r < p->nreg; ++r)   // as launch_eval_ztile's `more_regs`: the tile launch must produce the whole gradient
+    if (!(z->regk != 0 && r == z->reg_index) && p->reg[r].lambda > 0.0) return false;
+  const Geometry& g = p->geo;
+  const int C = p->view_C > 0 ? p->view_C : g.C;
+  const size_t est_parts = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * C +
+                           (z->n_ring > 0 ? (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * C : (size_t)0);
+  return est_parts <= kMaxFusedPartials;
+}
+
 size_t ztile_partials_needed(const srmap_problem* p) {
   const Geometry& g = p->geo;
   const size_t tiles = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * g.C;
@@ -736,6 +797,9 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
   fill_zargs<T, S, B, REGK, R>(A, p, geo, obs_c0, terms, x, g, wts, z, partials, dvec, partials_gd);
+  if (dvec != nullptr && p->eval_fold_xk != nullptr) {  // line search: the point is xk + stp * d; its own pixels go to x
+    A.fold_xk = (const T*)p->eval_fold_xk; A.fold_x = const_cast<T*>(x); A.fold_stp = (T)p->eval_fold_stp;
+  }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
   const int n_tile_partials = border_only >= 0 ? border_only : (int)(grid.x * grid.y * grid.z);
@@ -891,6 +955,8 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     if (rc) return rc;
     partials += nfwd;
   }
+  if (p->eval_fold_xk != nullptr && !(with_d && p->impl != SRMAP_IMPL_MARCH && p->ov_hook == nullptr))
+    return set_error(p->ctx, SRMAP_EINVAL, "internal: a folded trial point needs the tile kernel's g.d instance (ztile_can_fold)");
   const T* dv = with_d ? (const T*)p->eval_dvec : nullptr;
   double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
   p->gd_valid = false;

@@ -709,7 +709,11 @@ struct DeviceCG {
   // objective at x: g <- gradient; the cost stays on the device (finish(with_cost) fetches it).  With a direction
   // the tile kernel may produce g.d in the same pass (p->gd_valid; not under frame sharding, where the local
   // gradient is only a partial sum).
-  int evaluate(const T* dir = nullptr, T* at = nullptr) {  // at: the point (default x)
+  // the line search may hand its trial point to the evaluation as (xk, stp): un-sharded solves on the tile kernel's
+  // g.d instance (ztile_can_fold); decided once per CG run
+  bool foldable = false;
+  bool fold_enabled = true;   // srmap_irls_options::host_paced_passes also forms every trial point by its own pass (the A/B of the fold)
+  int evaluate(const T* dir = nullptr, T* at = nullptr, const T* fold_xk = nullptr, double fold_stp = 0.0) {  // at: the point (default x)
     evaluations++;
     const int mode = (comm && shard && comm_world(comm) > 1) ? shard->mode : SRMAP_SHARD_NONE;
     p->eval_dvec = (mode == SRMAP_SHARD_FRAMES || mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) ? nullptr : dir;
@@ -719,7 +723,10 @@ struct DeviceCG {
     p->eval_pub = (!reduce_scalars && p->eval_dvec != nullptr) ? hs : nullptr;
     p->eval_pub_tag_slot = hs + 15;
     p->eval_pub_tag = tag + 1.0;
+    p->eval_fold_xk = (fold_xk != nullptr && p->eval_dvec != nullptr) ? fold_xk : nullptr;
+    p->eval_fold_stp = fold_stp;
     const int rc = shard_eval(p, comm, shard, SRMAP_TERM_ALL, at ? at : x, g, st);
+    p->eval_fold_xk = nullptr;
     p->eval_dvec = nullptr;
     p->eval_pub = nullptr;
     published = p->eval_published;
@@ -912,7 +919,10 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
     // stp_in_x: cg.x already holds xk + stp_in_x * d (written by the normalisation pass); any other step is formed here
     const bool first_in_x = *nfev == 0 && stp_in_x != 0.0 && *stp == stp_in_x;
     if (*nfev == 0 && pre_launched && !first_in_x) { cg.discard_speculative(); pre_launched = false; }
-    if (!first_in_x)
+    // the trial point x = xk + stp * d: formed by the evaluation itself as it loads its window where that is possible
+    // (one n-vector pass less per trial point; x holds the point afterwards all the same), else by its own pass
+    const bool fold_here = !first_in_x && cg.foldable;
+    if (!first_in_x && !fold_here)
     {
       if ((cg.n & 3) == 0)
         hipLaunchKernelGGL(k_axpy_out4<T>, dim3((unsigned)((cg.n / 4 + 255) / 256)), dim3(256), 0, cg.st, cg.x, (const T*)cg.xk,
@@ -922,7 +932,7 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
                            (const T*)cg.d, (T)*stp, cg.n);
     }
     if (!(first_in_x && pre_launched)) {
-      rc = cg.evaluate(cg.d);
+      rc = fold_here ? cg.evaluate(cg.d, nullptr, cg.xk, *stp) : cg.evaluate(cg.d);
       if (rc) return rc;
     }
     double h[2];
@@ -990,6 +1000,10 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
   // the start point becomes the base point xk by exchanging the two buffers (no copy); x is trial scratch from here on:
   // every path below writes it before reading it (the trial points) or copies xk back into it (the early exits)
   std::swap(cg.xk, cg.x);
+  {
+    const int mode = (cg.comm && cg.shard && comm_world(cg.comm) > 1) ? cg.shard->mode : SRMAP_SHARD_NONE;
+    cg.foldable = mode == SRMAP_SHARD_NONE && cg.fold_enabled && ztile_can_fold(cg.p);
+  }
   int rc = cg.evaluate(nullptr, cg.xk);
   if (rc) return rc;
   // dk = -g (written as dn, swapped below), norms of dk; g.g = dk.dk comes with them
@@ -1202,6 +1216,7 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
   DeviceCG<T> cg;
   cg.p = p; cg.st = st; cg.n = npts; cg.comm = comm; cg.shard = shard;
   cg.chain_enabled = o.host_paced_passes == 0;
+  cg.fold_enabled = o.host_paced_passes == 0;
   cg.ow.on = 0; cg.ow.e0 = 0; cg.ow.e1 = npts; cg.ow.W = geo.W; cg.ow.H = geo.H; cg.ow.r0 = 0; cg.ow.r1 = geo.H;
   if (mode == SRMAP_SHARD_ROWS) { cg.ow.on = 1; cg.ow.r0 = shard->own_row0; cg.ow.r1 = shard->own_row1; cg.reduce_scalars = true; }
   if (mode == SRMAP_SHARD_CHANNELS || mode == SRMAP_SHARD_GRID) {

@@ -104,6 +104,11 @@ struct srmap_problem {
   const void* eval_dvec = nullptr;  // set by the solver around an evaluation: direction d (device, dtype); the tile
                                     // kernel then produces g.d with the gradient (one pass and two launches fewer)
   bool gd_valid = false;            // the last evaluation left g.d in d_cost[1]
+  // set by the solver's line search around an evaluation (with eval_dvec): the point to evaluate is
+  // eval_fold_xk + eval_fold_stp * eval_dvec, formed by the tile kernel as it loads its window and written to the x the
+  // evaluation was given (no separate n-vector pass per trial point); only where ztile_can_fold() says so
+  const void* eval_fold_xk = nullptr;
+  double eval_fold_stp = 0.0;
   // set by the solver around an evaluation: host-mapped words the evaluation's finish kernel publishes
   // {cost, g.d} to, followed by the arrival tag (saves the separate publish launch); eval_published reports it did
   double* eval_pub = nullptr;
@@ -196,7 +201,8 @@ void ztile_release(srmap_problem* p);
 void ztile_preload(const srmap_problem* p);
 void ztile_rearm(srmap_problem* p);  // re-initialise the granules of the in-kernel cost reduction (after its time-out)
 bool ztile_overlaps_halo(const srmap_problem* p);  // the next tile evaluation can run interior tiles under the halo exchange
-bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms);  // the tile kernel alone produces the regulariser part
+bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms);
+bool ztile_can_fold(const srmap_problem* p);  // a TERM_ALL evaluation with eval_dvec can form its point from xk + stp * d itself  // the tile kernel alone produces the regulariser part
 size_t ztile_partials_needed(const srmap_problem* p);
 template <typename T>
 int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms,

@@ -286,6 +286,11 @@ struct ZArgs {
   double tag;
   const double* xpart;   // plain cost partials of an EARLIER launch on the stream (sub-pixel path: the forward kernel's data
   int n_xpart;           //   cost), complete when this kernel starts: the in-kernel finish adds them, in index order
+  // ---- solver line search (WD instances): the trial point x = fold_xk + fold_stp * dvec is formed when the window goes
+  // to LDS (the expression of solver.hip's k_axpy_out, same contraction), its own pixels are written to fold_x ----
+  const T* fold_xk;      // nullptr: x is read as given
+  T* fold_x;
+  T fold_stp;
   // ---- marching kernel (kernels_zmarch.hip): workgroup -> (strip, band) ----
   int m_nstrips;         // strips of 64 LR cells per image row
   int m_band_rows;       // HR rows per band (a multiple of the step height)
@@ -793,9 +798,10 @@ __device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -
 // r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
 // S, B at compile time and the taps from the kernel arguments: the B * B loads of a residual are requested together
 // (with run-time loop bounds and a tap table in memory every tap was its own round trip: ~9 us per border block).
-template <typename T, int S, int B, typename ArgsT>
+template <typename T, int S, int B, bool FOLD = false, typename ArgsT>
 __device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int wl, const T* __restrict__ xplane,
-                                             const T* __restrict__ yk, int ox, int oy, int i, int j) {
+                                             const T* __restrict__ yk, int ox, int oy, int i, int j,
+                                             const T* __restrict__ dplane = nullptr, T stp = T(0)) {
   constexpr int hb = (B - 1) / 2;
   T xv[B * B];
   const T yv = yk[(size_t)i * wl + j];
@@ -820,7 +826,9 @@ __device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int w
 #pragma unroll
     for (int e = 0; e < B; ++e) {
       // mask as a multiply: a select on the loaded value lets the compiler sink each load under its own branch
-      xv[a * B + e] = xplane[(unsigned)(rix + cix[e])] * ((rok && cok[e]) ? T(1) : T(0));
+      T xval = xplane[(unsigned)(rix + cix[e])];
+      if (FOLD) xval = xval + stp * dplane[(unsigned)(rix + cix[e])];   // the line search's trial point, k_axpy_out's expression
+      xv[a * B + e] = xval * ((rok && cok[e]) ? T(1) : T(0));
     }
   }
   T acc = T(0);
@@ -833,7 +841,7 @@ __device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int w
 
 // One border block of NT threads; smem: scratch of at least 16 int2 + kBorderTabEntries ZEntry + 8 doubles.
 // nbb: border blocks per channel (the block's partial is stored at n_tile_partials + ch * nbb + bidx).
-template <typename T, int S, int B, int NT, bool WD, typename ArgsT>
+template <typename T, int S, int B, int NT, bool WD, bool FOLD = false, typename ArgsT>
 __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>& Bd, int bidx, int ch, void* smem, int nbb) {
   const int obs_C = Bd.obs_C;
   int2* s_hdr = reinterpret_cast<int2*>(smem);
@@ -850,7 +858,9 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
   if (t < Bd.n_ring) {
     int qr, qc;
     ring_pixel(t, A.W, A.H, A.ring, qr, qc);
-    const T* xplane = A.x + (size_t)ch * N;
+    const T* xplane = (FOLD ? A.fold_xk : A.x) + (size_t)ch * N;
+    const T* dplane = FOLD ? A.dvec + (size_t)ch * N : nullptr;
+    const T fstp = FOLD ? A.fold_stp : T(0);
     const T* ybase = A.y + (size_t)ch * nl;
     const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
     T corr = T(0);
@@ -864,8 +874,8 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
           if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
           if (S * i < A.cr0 || S * i >= A.cr1) continue;
           const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
-          const double r = (double)border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane,
-                                                            ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
+          const double r = (double)border_residual<T, S, B, FOLD>(A, A.W, A.H, A.wl, xplane,
+                                                                  ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j, dplane, fstp);
           cost += r * r;
         }
       }
@@ -887,7 +897,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
             if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
             // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
             corr += blur_tap<B>(A, b2, a) *
-                    border_residual<T, S, B>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j);
+                    border_residual<T, S, B, FOLD>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j, dplane, fstp);
           }
         }
       }
@@ -999,6 +1009,7 @@ static void fill_zargs(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>& A, srmap_problem
       for (int j = 0; j < R; ++j)
         if (i + j > 0) A.pwsum += A.powtab[i + j];
   A.m_nstrips = 0; A.m_band_rows = 0; A.m_nbt = 0;
+  A.fold_xk = nullptr; A.fold_x = nullptr; A.fold_stp = T(0);
 }
 
 // ---- marching kernel (kernels_zmarch.hip) ----
