@@ -95,7 +95,11 @@ enum {
  * workgroup-tile kernels whenever the problem geometry admits them (scale
  * 2..4, blur size 1 or 3, integer or sub-pixel shifts), else the direct
  * kernels.  TILED forces that family and fails with SRMAP_EUNSUPPORTED when it
- * does not cover the problem. */
+ * does not cover the problem.  MARCH asks for the marching evaluation kernel
+ * (one resident workgroup per CU walking a band of rows; scale 4, blur 3, one
+ * frame per pixel phase, BTV range 3, width a multiple of 256): bit-equal to
+ * the tiles, not faster on gfx950 (profiles/r05_march.txt), never chosen by
+ * AUTO, SRMAP_EUNSUPPORTED outside its geometry. */
 typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */
