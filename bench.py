@@ -240,6 +240,12 @@ def main():
     ap.add_argument("--test-single-device", action="store_true",
                     help="testing aid for 1-GPU boxes: all ranks share GPU 0 and talk over gloo through the library's "
                          "host-callback communicator (exercises the N > 1 code paths; the numbers mean nothing)")
+    ap.add_argument("--watchdog-s", type=int, default=900, help="N > 1: a rank that has not finished after this many seconds dumps its stack and exits")
+    ap.add_argument("--test-rccl-loopback", action="store_true",
+                    help="testing aid for 1-GPU boxes: all ranks share GPU 0 and talk over the REAL RCCL communicator -- "
+                         "every rank names itself a host of its own (NCCL_HOSTID), so RCCL accepts the shared device and "
+                         "runs its socket transport over the loopback interface (the N > 1 RCCL code paths execute; "
+                         "the numbers mean nothing)")
     args = ap.parse_args()
 
     # ---- N > 1 without a launcher: become one (one process per GPU, rendezvous on 127.0.0.1) ----
@@ -249,6 +255,12 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
 
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner and gloo its connection notes on fd 1
+    # when a communicator comes up, so everything but the result goes to stderr from here on
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import srmap
     import srmap_dist
@@ -256,18 +268,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
 
+    import faulthandler
+
     def watchdog(seconds, what):
-        """A rank stuck in an exchange must end the job with an error instead of holding the node."""
-        import signal
-        signal.signal(signal.SIGALRM, lambda *_: (sys.stderr.write("bench.py: rank %d timed out (%d s) in %s\n" % (rank, seconds, what)),
-                                                  os._exit(3)))
-        signal.alarm(seconds)
+        """A rank stuck in an exchange must end the job with an error instead of holding the node.  faulthandler's timer
+        is a thread of its own: it fires while the main thread sits inside a native call (a stream synchronisation, a
+        collective), where a Python signal handler -- the SIGALRM of rounds 3-4 -- is never run (seen in round 5: a rank
+        blocked in hipStreamSynchronize outlived a 900 s alarm)."""
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(seconds, exit=True)  # the dumped stack says where (`what` is for the reader)
 
     if world > 1:
-        import faulthandler
         faulthandler.enable()
-        watchdog(900, "the job")
-    local_rank = 0 if args.test_single_device else int(os.environ.get("LOCAL_RANK", "0"))
+        watchdog(args.watchdog_s, "the job")
+    one_device = args.test_single_device or args.test_rccl_loopback
+    local_rank = 0 if one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.test_rccl_loopback and world > 1:  # before anything loads librccl
+        os.environ["NCCL_HOSTID"] = "srmap-bench-host-%d" % rank
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     dist = None
     if world > 1:
         # ONE RCCL instance in the process: the library's own communicator carries every device-side exchange; the
@@ -304,7 +323,7 @@ def main():
             dist.broadcast(uid, 0)  # gloo, host memory
             watchdog(120, "ncclCommInitRank")
             comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=bytes(uid.numpy().tobytes()))
-            watchdog(900, "the job")
+            watchdog(args.watchdog_s, "the job")
             if args.overlap:
                 comm.set_overlap(True)
         comm_info = comm.info()
@@ -407,11 +426,19 @@ def main():
             watchdog(30, "the first %s-sharded step" % shard)
             step()
             stream.synchronize()
-            watchdog(900, "the job")
+            watchdog(args.watchdog_s, "the job")
         ramp_steps = 0
         if args.clock_ramp_ms > 0:  # untimed: bring the GPU to its sustained clock state
+            # a sharded step is a collective: every rank must issue the SAME number of them, so the decision to go on is
+            # taken on the maximum of the ranks' clocks (round 5: each rank consulting its own clock left one rank twenty
+            # exchanges ahead of its peers -- a 4-rank RCCL run hung here)
             t_r = time.perf_counter()
-            while (time.perf_counter() - t_r) * 1e3 < args.clock_ramp_ms:
+            while True:
+                el = time.perf_counter() - t_r
+                if sd is not None and not only_rank0:
+                    el = max_over_ranks(el)
+                if el * 1e3 >= args.clock_ramp_ms:
+                    break
                 for _ in range(20):
                     step()
                 stream.synchronize()
@@ -542,7 +569,9 @@ def main():
             "config": {"workload": cfg["label"] % (W, H), "frames": K, "scale": s, "channels": C,
                        "shard": main_shard, "collective_per_step": collective[main_shard],
                        "comm_ranks": (comm_info[1] if comm_info else (world if world > 1 else 1)),
-                       "comm_backend": (None if comm_info is None else ("rccl" if is_rccl else "host callbacks (test)")),
+                       "comm_backend": (None if comm_info is None else
+                                        (("rccl over loopback sockets, all ranks on GPU 0 (test)" if args.test_rccl_loopback else "rccl")
+                                         if is_rccl else "host callbacks (test)")),
                        "comm_library": comm_lib, "harness_group": ("gloo" if world > 1 else None),
                        "halo_overlap": bool(args.overlap) if main_shard == "rows" else None,
                        "impl": args.impl, "device_ms_per_step": res["dev_ms_per_step"],
@@ -579,7 +608,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, res["lr"], res["x0"], res["wts"])
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

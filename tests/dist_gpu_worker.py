@@ -2,7 +2,12 @@
 (through the library's host-callback communicator) and runs its shard of the joint evaluation / solve through the C
 ABI; rank 0 also evaluates the un-sharded problem and writes the comparison as JSON.
 
-    python dist_gpu_worker.py <rank> <world> <port> <mode> <out.json>
+    python dist_gpu_worker.py <rank> <world> <port> <mode> <out.json> [host|rccl]
+
+"rccl": the same shards over the RCCL communicator.  RCCL refuses two ranks on one device of one host, so every rank
+names itself a host of its own (NCCL_HOSTID) and RCCL runs its socket transport over the loopback interface: not the
+xGMI path, but ncclCommInitRank with N > 1, ncclAllReduce, the grouped ncclSend / ncclRecv halo exchange and
+ncclCommSplit execute for real.
 """
 import json
 import os
@@ -25,13 +30,23 @@ def relerr(a, ref):
 
 def main():
     rank, world, port, mode, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    backend = sys.argv[6] if len(sys.argv) > 6 else "host"
+    if backend == "rccl":  # before anything loads librccl
+        os.environ["NCCL_HOSTID"] = "srmap-test-host-%d" % rank
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     torch.cuda.init()
     torch.zeros(1, device="cuda")  # torch's HIP runtime first (see tests/conftest.py)
     import srmap
     import srmap_dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     ctx = srmap.Context(0)
-    comm = srmap.Comm(ctx, rank, world, backend="host", dist=dist)
+    if backend == "rccl":
+        box = [srmap.Comm.unique_id(ctx) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=box[0])
+    else:
+        comm = srmap.Comm(ctx, rank, world, backend="host", dist=dist)
 
     rng = np.random.default_rng(123)
     s, b, sigma = 4, 3, 1.0
@@ -47,6 +62,9 @@ def main():
     if mode == "frames2":  # a second regulariser: the direct kernels join in, the regulariser stays on reg_rank (no band split)
         regs.append((srmap.REG_TV, 0.01, 0, 0.0))
         mode = "frames"
+    if mode == "rows_overlap":  # the halo exchange posted under the interior tile rows (srmap_comm_set_overlap)
+        comm.set_overlap(True)
+        mode = "rows"
     force_direct = False
     if mode == "frames_mixed":  # ONE rank on the direct kernels (it cannot evaluate a row band): the ranks must agree on reg_rank
         force_direct = rank == 1
@@ -110,8 +128,11 @@ def main():
         p.set_observations(lr[ids][:, c0 - lo:c1 + hi])
         for r in regs:
             p.add_regularizer(*r)
-        groups = [dist.new_group([blk * FG + f for f in range(FG)]) for blk in range(nblocks)]  # collective: every rank creates all
-        fcomm = srmap.Comm(ctx, fg, FG, backend="host", dist=dist, group=groups[cb], group_ranks=[cb * FG + f for f in range(FG)])
+        if backend == "rccl":
+            fcomm = comm.split(cb, fg, fg, FG)  # ncclCommSplit: the frame groups of one channel block
+        else:
+            groups = [dist.new_group([blk * FG + f for f in range(FG)]) for blk in range(nblocks)]  # collective: every rank creates all
+            fcomm = srmap.Comm(ctx, fg, FG, backend="host", dist=dist, group=groups[cb], group_ranks=[cb * FG + f for f in range(FG)])
         sd.mode = srmap.SHARD_GRID
         sd.own_ch0, sd.own_ch1 = lo, lo + (c1 - c0)
         sd.frame_groups = FG
@@ -144,7 +165,7 @@ def main():
     f = p.eval_sharded_device(comm, sd, xd.data_ptr(), gd.data_ptr(), srmap.TERM_ALL, want_cost=True)
     torch.cuda.synchronize()
     g_loc = gd.cpu().numpy()
-    res = {"mode": mode}
+    res = {"mode": mode, "backend": comm.describe()}
     if mode == "frames":
         g_own = g_loc
     elif mode == "rows":

@@ -1,7 +1,8 @@
 """Multi-GPU paths of the C ABI on ONE GPU: the sharded evaluation and the sharded IRLS/CG solve
 (srmap_eval_sharded_device, srmap_solve_sharded) with 2 ranks sharing GPU 0 over the host-callback communicator
-(gloo), for frame, row-band and channel (+ 3-D TV halo plane) shards, against the single-process result; the RCCL
-backend with a one-rank communicator; and the CG trajectory against ALGLIB's / the oracle's mincg."""
+(gloo) AND over the RCCL communicator (loopback sockets: each rank names itself its own host), for frame, row-band and
+channel (+ 3-D TV halo plane) shards, against the single-process result; the RCCL backend with a one-rank
+communicator; and the CG trajectory against ALGLIB's / the oracle's mincg."""
 import json
 import os
 import socket
@@ -25,17 +26,23 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("mode", ["frames", "frames2", "frames_mixed", "rows", "channels", "grid"])
-def test_two_ranks_on_one_gpu(tmp_path, mode):
+@pytest.mark.parametrize("backend", ["host", "rccl"])
+@pytest.mark.parametrize("mode", ["frames", "frames2", "frames_mixed", "rows", "rows_overlap", "channels", "grid"])
+def test_two_ranks_on_one_gpu(tmp_path, mode, backend):
     """2 ranks (grid: 4 = 2 channel blocks x 2 frame groups, the frames x channels sharding of BASELINE configs[4]).
     frames: the regulariser split over the ranks by row band; frames2: two regularisers, evaluated on reg_rank;
     frames_mixed: rank 1 forced to the direct kernels -- the band split is a collective decision (all ranks fall back to
-    reg_rank), otherwise the regulariser would be counted one and a half times."""
+    reg_rank), otherwise the regulariser would be counted one and a half times; rows_overlap: the halo exchange posted
+    on the side stream under the interior tile rows.
+    backend "rccl": the same over the RCCL communicator -- ncclCommInitRank with N = 2 / 4, ncclAllReduce, the grouped
+    ncclSend / ncclRecv halo exchange and ncclCommSplit (grid) -- every rank posing as a host of its own so that RCCL
+    accepts the shared GPU and runs its socket transport over loopback (tests/dist_gpu_worker.py)."""
     world, port = (4 if mode == "grid" else 2), _free_port()
     out = str(tmp_path / "res.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(r), str(world),
-                               str(port), mode, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               str(port), mode, out, backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True)
              for r in range(world)]
     logs = []
     for p in procs:
@@ -49,6 +56,7 @@ def test_two_ranks_on_one_gpu(tmp_path, mode):
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     res = json.load(open(out))
     print(res)
+    assert res["backend"].startswith("rccl " if backend == "rccl" else "host")
     assert res["cost_err"] <= 1e-12 and res["grad_err"] <= 1e-11
     # same decisions on every rank and as the single-process solve; iterates equal up to reduction order
     assert len(set(res["cg"])) == 1 and len(set(res["irls"])) == 1 and len(set(res["evals"])) == 1
@@ -57,13 +65,16 @@ def test_two_ranks_on_one_gpu(tmp_path, mode):
         assert res["replicas_equal"]
 
 
-@pytest.mark.parametrize("shard", ["rows", "channels"])
-def test_bench_spawns_its_ranks(shard):
+@pytest.mark.parametrize("shard,how", [("rows", "--test-single-device"), ("channels", "--test-single-device"),
+                                       ("rows", "--test-rccl-loopback")])
+def test_bench_spawns_its_ranks(shard, how):
     """`python bench.py --gpus 2` as a bare subprocess (no launcher, no WORLD_SIZE): the bench re-executes itself under
-    torch.distributed.run, one rank per process; here both ranks share GPU 0 over the host-callback communicator."""
+    torch.distributed.run, one rank per process; here both ranks share GPU 0 over the host-callback communicator, or over
+    RCCL itself on loopback sockets (the path the driver's N > 1 run takes, minus xGMI)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-single-device", "--steps", "5",
+    rccl = how == "--test-rccl-loopback"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", how, "--steps", "5",
                         "--warmup", "2", "--clock-ramp-ms", "0", "--min-timed-ms", "0", "--hr", "512", "--shard", shard],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -74,10 +85,15 @@ def test_bench_spawns_its_ranks(shard):
     assert out["config"]["shard"] == shard
     if shard == "rows":
         assert out["scaling"] == "strong" and out["config"]["comm_ranks"] == 2
-        # the labels say what ran: the host-callback test backend, not RCCL
-        assert out["config"]["comm_backend"].startswith("host") and out["config"]["comm_library"] == "host callbacks"
-        assert out["frames_variant"]["value"] > 0 and "host-callback all-reduce" in out["frames_variant"]["collective_per_step"]
-        assert "host-callback send/recv" in out["config"]["collective_per_step"]
+        # the labels say what ran
+        if rccl:
+            assert out["config"]["comm_backend"].startswith("rccl over loopback") and out["config"]["comm_library"].startswith("rccl ")
+            assert out["frames_variant"]["value"] > 0 and "ncclAllReduce" in out["frames_variant"]["collective_per_step"]
+            assert "ncclSend/ncclRecv" in out["config"]["collective_per_step"]
+        else:
+            assert out["config"]["comm_backend"].startswith("host") and out["config"]["comm_library"] == "host callbacks"
+            assert out["frames_variant"]["value"] > 0 and "host-callback all-reduce" in out["frames_variant"]["collective_per_step"]
+            assert "host-callback send/recv" in out["config"]["collective_per_step"]
         # the configs[2] block: rows strong scaling with its own N = 1 time from the same run
         c3 = out["cfg3"]
         assert c3["shard"] == "rows" and c3["scaling"] == "strong" and c3["value"] > 0
