@@ -61,6 +61,14 @@
 //   SRMAP_EXP_NOLOAD    TIMING ONLY (results wrong by construction): every global load of a tile workgroup replaced by a
 //                       value formed in registers -- the time no prefetch scheme can beat (profiles/r05_ceiling.txt)
 //   SRMAP_EXP_NOHALO    TIMING ONLY: no halo-row / halo-column passes (what a marching band saves at best)
+//   SRMAP_ZT_ONLY_T     with SRMAP_ZT_ONLY_CFG2: the arithmetic type of that one instance (default double)
+//   SRMAP_EXP_F32_WPE   f32 instances: waves per SIMD the register budget is set for (product: 6 = 80 VGPRs)
+#ifndef SRMAP_ZT_ONLY_T
+#define SRMAP_ZT_ONLY_T double
+#endif
+#ifndef SRMAP_EXP_F32_WPE
+#define SRMAP_EXP_F32_WPE 6
+#endif
 #ifndef SRMAP_EXP_NOLOAD
 #define SRMAP_EXP_NOLOAD 0
 #endif
@@ -73,7 +81,7 @@ namespace srmap {
 namespace {
 
 template <typename T, int S, int B, int REGK, int R, bool WD, bool SP>
-__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? 6 : (S == 2 ? 6 : 4))) void k_eval_z(
+__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRMAP_EXP_F32_WPE : (S == 2 ? 6 : 4))) void k_eval_z(
     ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
   using C = ZCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
@@ -883,7 +891,7 @@ static void preload_reg(int regk, int regr) {
 template <typename T>
 static void preload_sb(int S, int B, int regk, int regr) {
 #ifdef SRMAP_ZT_ONLY_CFG2
-  if (sizeof(T) == 8 && S == 4 && B == 3 && regk == 2 && regr == 3) preload_z<double, 4, 3, 2, 3>();
+  if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == 3 && regk == 2 && regr == 3) preload_z<SRMAP_ZT_ONLY_T, 4, 3, 2, 3>();
   return;
 #else
   if (S == 2 && B == 1) preload_reg<T, 2, 1>(regk, regr);
@@ -977,9 +985,10 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (p->impl == SRMAP_IMPL_MARCH && !march) return set_error(p->ctx, SRMAP_EUNSUPPORTED, "the marching kernel does not cover this evaluation");
   auto tiles = [&](int border_only) {
 #ifdef SRMAP_ZT_ONLY_CFG2
-    if (sizeof(T) == 8 && S == 4 && B == 3 && regk == 2 && regr == 3)
-      return launch_z<double, 4, 3, 2, 3>(p, geo, obs_c0, zterms, (const double*)x, (double*)g, (const double*)wts, z, partials, &nb, st,
-                                          (const double*)dv, pgd, mfin, border_only);
+    if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == 3 && regk == 2 && regr == 3)
+      return launch_z<SRMAP_ZT_ONLY_T, 4, 3, 2, 3>(p, geo, obs_c0, zterms, (const SRMAP_ZT_ONLY_T*)x, (SRMAP_ZT_ONLY_T*)g,
+                                                   (const SRMAP_ZT_ONLY_T*)wts, z, partials, &nb, st, (const SRMAP_ZT_ONLY_T*)dv, pgd,
+                                                   mfin, border_only);
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "measurement build: cfg2 instance only");
 #else
     if (S == 2 && B == 1) return dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
