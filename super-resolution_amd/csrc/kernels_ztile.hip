@@ -268,19 +268,21 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
     if (hgr >= 0 && hgr < A.H && hgc >= 0) wcolv = wplane[(size_t)hgr * A.W + hgc];
   }
 
+  // WD: how elements of the direction are read (as given, or normalised on the fly from the unnormalised direction)
+  const DirScale dsc = dir_scale(WD ? A.fold_norms : nullptr);
   if (WD && fold) {  // trial point: x = xk + stp * d, element by element the expression of solver.hip's k_axpy_out
     T* xout = A.fold_x + (size_t)ch * N;
 #pragma unroll
     for (int it = 0; it < ARI; ++it) {
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) va[it][pc] = va[it][pc] + A.fold_stp * vda[it][pc];
+      for (int pc = 0; pc < S; ++pc) va[it][pc] = va[it][pc] + A.fold_stp * dir_elem<T>(vda[it][pc], dsc);
       if (owna[it]) {
 #pragma unroll
         for (int pc = 0; pc < S; ++pc) xout[xoa[it] + pc] = va[it][pc];
       }
       if (!XT) {
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) vb[it][pc] = vb[it][pc] + A.fold_stp * vdb[it][pc];
+        for (int pc = 0; pc < S; ++pc) vb[it][pc] = vb[it][pc] + A.fold_stp * dir_elem<T>(vdb[it][pc], dsc);
         if (ownb[it]) {
 #pragma unroll
           for (int pc = 0; pc < S; ++pc) xout[xob[it] + pc] = vb[it][pc];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
   if (WD && gr < A.H && gc0 < A.W && gr >= A.cr0 && gr < A.cr1) {
     const T* dp = A.dvec + (size_t)ch * N + (size_t)gr * A.W + gc0;
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) dreg[pc] = dp[pc];
+    for (int pc = 0; pc < S; ++pc) dreg[pc] = dir_elem<T>(dp[pc], dsc);
   }
   if (want_data && A.g != nullptr) {
     const T sc = (T)(2 * S * S);  // g += 2 * (s*s block sum) (objective_data_term.cpp:55-71)
@@ -807,6 +809,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   fill_zargs<T, S, B, REGK, R>(A, p, geo, obs_c0, terms, x, g, wts, z, partials, dvec, partials_gd);
   if (dvec != nullptr && p->eval_fold_xk != nullptr) {  // line search: the point is xk + stp * d; its own pixels go to x
     A.fold_xk = (const T*)p->eval_fold_xk; A.fold_x = const_cast<T*>(x); A.fold_stp = (T)p->eval_fold_stp;
+    A.fold_norms = p->eval_fold_norms;
   }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }

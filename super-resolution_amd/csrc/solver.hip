@@ -9,16 +9,19 @@
 // selection, stopping rules) runs on the host, in double, in ALGLIB's order of
 // operations, so that the trajectory follows the reference's up to reduction
 // order.  Per CG iteration the host waits for the device 2 + nfev times: once
-// for (g.d, d.d, direction norms), once per trial point for (f, g.d), once for
-// the beta dot products; the n-vector work is three fused passes:
-//   k_direction      dn = -g + beta dk, max|dn| and dn.dn
-//   k_normalize_dots d = (dn / max|dn|) / ||dn / max|dn|||, g.d, d.d
-//                    (the two scale factors are computed on the device from
-//                    the reduced norms: no host round trip in between)
+// for the direction's sums, once per trial point for (f, g.d), once for the beta
+// dot products; the n-vector work is two fused passes:
+//   k_direction      dn = -g + beta dk, max|dn|, dn.dn and g.dn -- from which the
+//                    host derives linminnormalized's two scale factors, g.d and
+//                    d.d (cg_norm.hpp): the normalised direction d = dn s1 s2 is
+//                    not re-summed, and on the tile path not even stored
 //   k_beta_dots      y = g - g_prev on the fly (the gradient buffers ping-pong,
 //                    mincg's yk vector is never stored), y.dk, g.g, g.y
-// plus x = xk + stp d and g.d per trial point.  Each pass reduces its sums in
-// the SAME launch: every block publishes its partials as write-through
+// plus the trial points x = xk + stp d: formed by the evaluation itself as it
+// loads its window, from dk and the device-resident norms (tile kernel, un-sharded
+// solves: no n-vector pass per trial point); elsewhere k_normalize stores d (and
+// the first trial point) and k_axpy_out the later ones.  Each pass reduces its sums
+// in the SAME launch: every block publishes its partials as write-through
 // granules, the last block of the grid adds them in index order and hands the
 // results (and the arrival tag) to the host -- no one-block second kernel.
 //
@@ -34,6 +37,7 @@
 #include <utility>
 #include <vector>
 
+#include "cg_norm.hpp"
 #include "comm.hpp"
 
 namespace srmap {
@@ -198,15 +202,21 @@ __device__ __forceinline__ void stv(T* __restrict__ p, const T (&in)[V]) {
 // summed in a different order (tests/test_gpu_parity.py: the PSNR bar of the ill-conditioned small cases follows the CPU
 // reference path's own sensitivity to a last-bit perturbation).
 
-// dn = -g + beta * dk ; sums: [0] max |dn| (owned), [1] dn.dn (owned).  When the finishing thread publishes to the
-// host (fin.pub_dst), the two sums follow the pub_n copied scalars: pub_dst[pub_n], pub_dst[pub_n + 1].
+// dn = -g + beta * dk ; sums: [0] max |dn| (owned), [1] dn.dn (owned), [2] g.dn (owned).  From these the host (and the
+// kernels that need the normalised direction d = dn s1 s2) derive s1, s2, g.d = (g.dn s1) s2 and d.d = dn.dn s1^2 s2^2:
+// the normalisation pass of rounds 1-4 (k_normalize_dots: five n-vector streams and a reduction per CG iteration, only
+// to re-sum g.d and d.d over the stored d) is gone from every path; where d is needed as a vector a plain scaling pass
+// (k_normalize) stores it.  norms_pub (host-mapped), when given, receives the three sums from the finishing thread
+// ahead of the tag.  keep_dn: dn is read again by the evaluations (trial points formed from dn): stored with the
+// default cache policy instead of non-temporal.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, const T* __restrict__ g,
                                                   const T* __restrict__ dk, T beta, size_t n, Owned ow,
-                                                  double* __restrict__ part, Fin fin, const double* __restrict__ beta_dev) {
+                                                  double* __restrict__ part, Fin fin, const double* __restrict__ beta_dev,
+                                                  double* norms_pub, int keep_dn) {
   // beta_dev: the beta the preceding k_beta_dots left on the device (the host queues this pass without waiting for it)
   if (beta_dev != nullptr) beta = (T)beta_dev[0];
-  double mx = 0, ss = 0;
+  double mx = 0, ss = 0, gd = 0;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
     T gi[V], di[V], v[V];
     ldv<T, V, false>(g + i, gi);
@@ -216,13 +226,15 @@ __global__ __launch_bounds__(256) void k_direction(T* __restrict__ dn, const T* 
       v[q] = -gi[q];
       if (dk != nullptr) v[q] += beta * di[q];
     }
-    stv<T, V, true>(dn + i, v);
+    if (keep_dn) stv<T, V, false>(dn + i, v); else stv<T, V, true>(dn + i, v);
 #pragma unroll
     for (int q = 0; q < V; ++q)
-      if (ow.has(i + q)) { mx = fmax(mx, fabs((double)v[q])); ss += (double)v[q] * (double)v[q]; }
+      if (ow.has(i + q)) {
+        mx = fmax(mx, fabs((double)v[q])); ss += (double)v[q] * (double)v[q]; gd += (double)gi[q] * (double)v[q];
+      }
   }
-  if (block_partials3(mx, ss, 0.0, part, true, 2, fin)) {
-    if (fin.pub_dst != nullptr) { fin.pub_dst[fin.pub_n] = fin.out[0]; fin.pub_dst[fin.pub_n + 1] = fin.out[1]; }
+  if (block_partials3(mx, ss, gd, part, true, 3, fin)) {
+    if (norms_pub != nullptr) { norms_pub[0] = fin.out[0]; norms_pub[1] = fin.out[1]; norms_pub[2] = fin.out[2]; }
     fin_tag(fin);
   }
 }
@@ -284,29 +296,23 @@ __global__ void k_publish(double* __restrict__ dst, const double* __restrict__ s
   }
 }
 
-// linminnormalized (alglibinternal.cpp:12165-12196): d = (dn * s1) * s2 with s1 = 1 / max|dn| and
-// s2 = 1 / sqrt(sum (dn s1)^2); the sum is taken as (dn.dn) * s1^2 from the pass that produced dn.  norms = device
-// {max|dn|, dn.dn} (already all-reduced); every thread derives the same two factors.  Partials: [0] g.d, [1] d.d.
-// Block 0 publishes s1, s2 in scal_out[0..1] for the host's step scaling.  When the first step of the line search is
-// known before this pass (ALGLIB's lastgoodstep), its trial point x1 = xk + stp1 * d is written here as well: one pass
-// over xk / x less per CG iteration than a separate k_axpy_out (same expression, same rounding).
+// d = (dn * s1) * s2 stored as a vector, for the paths whose evaluations read the normalised direction from memory
+// (sharded solves, the direct kernels, host-paced passes).  norms = device {max|dn|, dn.dn} (already all-reduced); every
+// thread derives the same two factors.  When the first step of the line search is known before this pass (ALGLIB's
+// lastgoodstep), its trial point x1 = xk + stp1 * d is written here as well: one pass over xk / x less per CG iteration
+// than a separate k_axpy_out (same expression, same rounding).
 template <typename T, int V>
-__global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const T* __restrict__ dn, const T* __restrict__ g,
-                                                       const double* __restrict__ norms, size_t n, Owned ow,
-                                                       double* __restrict__ part, double* __restrict__ scal_out, Fin fin,
-                                                       const T* __restrict__ xk, T* __restrict__ x1, T stp1) {
+__global__ __launch_bounds__(256) void k_normalize(T* __restrict__ d, const T* __restrict__ dn, const double* __restrict__ norms,
+                                                  size_t n, const T* __restrict__ xk, T* __restrict__ x1, T stp1) {
   const double mx = norms[0], ss = norms[1];
-  double s1 = 1.0, s2 = 1.0;
-  if (mx != 0.0) { s1 = 1.0 / mx; s2 = 1.0 / sqrt(ss * s1 * s1); }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { scal_out[0] = s1; scal_out[1] = s2; }
-  double gd = 0, dd = 0;
+  double s1, s2;
+  norm_factors(mx, ss, s1, s2);
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
-    T dv[V], gv[V], xv[V], v[V];
+    T dv[V], xv[V], v[V];
     ldv<T, V, true>(dn + i, dv);
-    ldv<T, V, false>(g + i, gv);
     if (x1 != nullptr) ldv<T, V, false>(xk + i, xv);
 #pragma unroll
-    for (int q = 0; q < V; ++q) v[q] = mx != 0.0 ? (T)(((double)dv[q] * s1) * s2) : dv[q];
+    for (int q = 0; q < V; ++q) v[q] = norm_elem<T>(dv[q], mx, s1, s2);
     stv<T, V, false>(d + i, v);
     if (x1 != nullptr) {  // the line search's first trial point (k_axpy_out's expression)
       T xn[V];
@@ -314,14 +320,6 @@ __global__ __launch_bounds__(256) void k_normalize_dots(T* __restrict__ d, const
       for (int q = 0; q < V; ++q) xn[q] = xv[q] + stp1 * v[q];
       stv<T, V, false>(x1 + i, xn);
     }
-#pragma unroll
-    for (int q = 0; q < V; ++q)
-      if (ow.has(i + q)) { gd += (double)gv[q] * (double)v[q]; dd += (double)v[q] * (double)v[q]; }
-  }
-  if (block_partials3(gd, dd, 0.0, part, false, 2, fin)) {
-    // {max|dn|, dn.dn, s1, s2} for the host's step scaling (block 0 may not have stored scal_out yet: derived here)
-    if (fin.pub_dst != nullptr) { fin.pub_dst[0] = mx; fin.pub_dst[1] = ss; fin.pub_dst[2] = s1; fin.pub_dst[3] = s2; }
-    fin_tag(fin);
   }
 }
 
@@ -595,13 +593,14 @@ struct DeviceCG {
   bool chain_enabled = true;
   bool chained() const { return fused() && chain_enabled && (shard == nullptr || comm == nullptr); }
   // x, g: current point and gradient; xk/dk: accepted point and direction; dn: next direction;
-  // d: normalised direction; gp: the gradient at xk while the line search writes its trial gradients to g (the two
+  // d: normalised direction (stored only where evaluations read it from memory: !foldable); gp: the gradient at xk
+  // while the line search writes its trial gradients to g (the two
   // buffers swap; mincg's yk = g_{k+1} - g_k is formed on the fly).  The line-search base is xk itself.
   T *x = nullptr, *g = nullptr, *xk = nullptr, *dk = nullptr, *dn = nullptr, *d = nullptr, *gp = nullptr;
   double* part = nullptr;   // [3][kRedBlocks] block partials (two-launch reductions: sharded solves)
   unsigned long long* gran = nullptr;  // [3][kRedBlocks] granules of the one-launch reductions (armed)
-  double* dscal = nullptr;  // device scalars: [0..3] reduction results, [4..5] direction norms, [6..7] s1 s2, [8] beta
-  double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal): results [0..13], arrival tag [15]
+  double* dscal = nullptr;  // device scalars: [0..3] reduction results, [4..6] the direction's sums {max|dn|, dn.dn, g.dn}, [8] beta, [15] time-out flag
+  double* hs = nullptr;     // host-mapped pinned scalars (ctx->h_scal): pass results [0..3], the direction's sums [8..10], arrival tag [15]
   double tag = 0;           // last tag handed to a publishing kernel
   int evaluations = 0;
   double wait_seconds = 0;  // host time spent in wait_tag
@@ -723,10 +722,14 @@ struct DeviceCG {
     p->eval_pub = (!reduce_scalars && p->eval_dvec != nullptr) ? hs : nullptr;
     p->eval_pub_tag_slot = hs + 15;
     p->eval_pub_tag = tag + 1.0;
+    // fold: `dir` is the UNNORMALISED direction dk; the kernel scales it by the factors it derives from the norms the
+    // direction pass left at dscal[4..5] (norm_factors / norm_elem: the bits of the stored d)
     p->eval_fold_xk = (fold_xk != nullptr && p->eval_dvec != nullptr) ? fold_xk : nullptr;
     p->eval_fold_stp = fold_stp;
+    p->eval_fold_norms = p->eval_fold_xk != nullptr ? (const double*)(dscal + 4) : nullptr;
     const int rc = shard_eval(p, comm, shard, SRMAP_TERM_ALL, at ? at : x, g, st);
     p->eval_fold_xk = nullptr;
+    p->eval_fold_norms = nullptr;
     p->eval_dvec = nullptr;
     p->eval_pub = nullptr;
     published = p->eval_published;
@@ -771,29 +774,56 @@ struct DeviceCG {
     out[1] = hs[0];
     return SRMAP_OK;
   }
-  // dn = -g + beta dk (dk may be null); direction norms -> dscal[4..5] (device, all-reduced).  publish_cost: the
-  // first pass of a CG run also hands {f -> hs[0], norms -> hs[8..9]} to the host (fetched by finish(0, ..., 2)).
+  // dn = -g + beta dk (dk may be null); {max|dn|, dn.dn, g.dn} -> dscal[4..6] (device, all-reduced) and, under a tag of
+  // the pass's own (dir_tag: wait_dir), hs[8..10].  publish_cost: the first pass of a CG run also hands f to the host
+  // (one-launch scheme: hs[0] with the same tag; two-launch scheme: the caller's finish(0, ..., 3) publishes all four).
   // beta_dev: beta comes from the device scalar the k_beta_dots queued just before left there (one-launch scheme only)
+  double dir_tag = 0;
   int direction(const T* dk_or_null, double beta, bool publish_cost = false, const double* beta_dev = nullptr) {
     Fin f{};
     if (fused()) {
+      tag += 1.0;
+      dir_tag = tag;
       f.gran = gran; f.out = dscal + 4; f.timeout_flag = dscal + 15;
-      if (publish_cost) {
-        tag += 1.0;
-        f.pub_src = (const double*)p->d_cost; f.pub_dst = hs; f.pub_n = 1;  // hs[0] = f, then hs[1..2] = the norms
-        f.tag_slot = hs + 15; f.tag = tag;
-      }
+      if (publish_cost) { f.pub_src = (const double*)p->d_cost; f.pub_dst = hs; f.pub_n = 1; }  // hs[0] = f
+      f.tag_slot = hs + 15; f.tag = tag;
     }
-    if (vec()) hipLaunchKernelGGL((k_direction<T, kVec>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f, beta_dev);
-    else hipLaunchKernelGGL((k_direction<T, 1>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f, beta_dev);
+    double* npub = fused() ? hs + 8 : (double*)nullptr;
+    const int keep = foldable ? 1 : 0;
+    if (vec()) hipLaunchKernelGGL((k_direction<T, kVec>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f, beta_dev, npub, keep);
+    else hipLaunchKernelGGL((k_direction<T, 1>), dim3(nb()), dim3(256), 0, st, dn, (const T*)g, dk_or_null, (T)beta, n, ow, part, f, beta_dev, npub, keep);
     if (!fused()) {
-      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 2, 1, dscal + 4, (const double*)nullptr,
+      hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, st, part, nb(), 3, 1, dscal + 4, (const double*)nullptr,
                          (double*)nullptr, 0.0);
       int rc = comm_allreduce(comm, dscal + 4, 1, SRMAP_F64, 1, st);
       if (rc) return rc;
-      rc = comm_allreduce(comm, dscal + 5, 1, SRMAP_F64, 0, st);
+      rc = comm_allreduce(comm, dscal + 5, 2, SRMAP_F64, 0, st);
       if (rc) return rc;
+      if (!publish_cost) {
+        tag += 1.0;
+        dir_tag = tag;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, hs + 8, (const double*)(dscal + 4), 3, hs + 15, tag);
+      }
     }
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    return SRMAP_OK;
+  }
+  // the sums of the last direction pass on the host: {max|dn|, dn.dn, g.dn}
+  int wait_dir(double* mx, double* ss, double* gdn) {
+    const int rc = wait_tag(dir_tag);
+    if (rc) return rc;
+    *mx = hs[8]; *ss = hs[9]; *gdn = hs[10];
+    return SRMAP_OK;
+  }
+  // d = dk s1 s2 stored as a vector (+ the first trial point x = xk + stp1 d when stp1 != 0): the paths whose evaluations
+  // read the normalised direction from memory
+  int normalize(double stp1) {
+    if (vec())
+      hipLaunchKernelGGL((k_normalize<T, kVec>), dim3(nb()), dim3(256), 0, st, d, (const T*)dk, (const double*)(dscal + 4), n,
+                         (const T*)xk, stp1 != 0.0 ? x : (T*)nullptr, (T)stp1);
+    else
+      hipLaunchKernelGGL((k_normalize<T, 1>), dim3(nb()), dim3(256), 0, st, d, (const T*)dk, (const double*)(dscal + 4), n,
+                         (const T*)xk, stp1 != 0.0 ? x : (T*)nullptr, (T)stp1);
     SRMAP_HIP(p->ctx, hipGetLastError());
     return SRMAP_OK;
   }
@@ -916,7 +946,8 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
     if ((brackt && (*stp <= stmin || *stp >= stmax)) || *nfev >= maxfev - 1 || infoc == 0 ||
         (brackt && stmax - stmin <= xtol * stmax))
       *stp = b.stx;
-    // stp_in_x: cg.x already holds xk + stp_in_x * d (written by the normalisation pass); any other step is formed here
+    // stp_in_x: cg.x already holds xk + stp_in_x * d (written by the scaling pass) or the evaluation that forms it is
+    // already queued (pre_launched); any other step is formed here
     const bool first_in_x = *nfev == 0 && stp_in_x != 0.0 && *stp == stp_in_x;
     if (*nfev == 0 && pre_launched && !first_in_x) { cg.discard_speculative(); pre_launched = false; }
     // the trial point x = xk + stp * d: formed by the evaluation itself as it loads its window where that is possible
@@ -932,7 +963,7 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
                            (const T*)cg.d, (T)*stp, cg.n);
     }
     if (!(first_in_x && pre_launched)) {
-      rc = fold_here ? cg.evaluate(cg.d, nullptr, cg.xk, *stp) : cg.evaluate(cg.d);
+      rc = fold_here ? cg.evaluate(cg.dk, nullptr, cg.xk, *stp) : cg.evaluate(cg.d);
       if (rc) return rc;
     }
     double h[2];
@@ -1009,19 +1040,19 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
   // dk = -g (written as dn, swapped below), norms of dk; g.g = dk.dk comes with them
   rc = cg.direction(nullptr, 0.0, true);
   if (rc) return rc;
-  if (cg.fused()) {  // the direction pass published {f, max|dk|, dk.dk} itself
+  if (cg.fused()) {  // the direction pass published {f -> hs[0]; max|dk|, dk.dk, g.dk -> hs[8..10]} itself
     rc = cg.wait_tag();
     if (rc) return rc;
     f = cg.hs[0];
-    gg = cg.hs[2];
   } else {
-    // fetch f and g.g (= dn.dn, already reduced on the device) with one wait
+    // fetch f and the direction's sums (already reduced on the device) with one wait
     double h[1];
-    rc = cg.finish(0, false, true, h, 2);
+    rc = cg.finish(0, false, true, h, 3);
     if (rc) return rc;
+    cg.dir_tag = cg.tag;
     f = h[0];
-    gg = cg.hs[9];
   }
+  gg = cg.hs[9];  // g.g = dk.dk
   if (trace) trace->push_back(f);
   std::swap(cg.dk, cg.dn);
   const double trim = 10 * (std::fabs(f) + 1);
@@ -1030,54 +1061,44 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
   double fold = f, lastgoodstep = 1.0;
   int rstimer = rscountdownlen;
   for (;;) {
-    // d = normalised dk (linminnormalized), g.d, d.d; x = xk is not materialised: the line search writes every
-    // trial point x = xk + stp * d itself
+    // d = dk s1 s2 (linminnormalized); g.d and d.d follow from the sums of the pass that produced dk.  x = xk is not
+    // materialised: every trial point x = xk + stp * d is written by the line search -- by the evaluation itself, from dk
+    // and the norms on the device, where the tile kernel can (foldable), else from the d a scaling pass stores.
     double stp = 1.0, dginit = 0, dd = 0;
     bool pre_launched = false, g_swapped = false;
-    // the first step is lastgoodstep unless that is 0 (then it comes from the norms this pass reduces)
+    // the first step is lastgoodstep unless that is 0 (then it comes from the direction's norms)
     const double stp_pre = (lastgoodstep != 0 && lastgoodstep >= 1.0e-50 && lastgoodstep <= 1.0e+50) ? lastgoodstep : 0.0;
+    double stp_ready = 0.0;  // the step whose trial point is already in cg.x and / or whose evaluation is already queued
     {
-      if (cg.vec())
-        hipLaunchKernelGGL((k_normalize_dots<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
-                           (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
-                           cg.fin_host(false, nullptr, cg.hs + 8, 0, cg.hs + 12), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
-                           (T)stp_pre);
-      else
-        hipLaunchKernelGGL((k_normalize_dots<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, cg.d, (const T*)cg.dk, (const T*)cg.g,
-                           (const double*)(cg.dscal + 4), n, cg.ow, cg.part, cg.dscal + 6,
-                           cg.fin_host(false, nullptr, cg.hs + 8, 0, cg.hs + 12), (const T*)cg.xk, stp_pre != 0.0 ? cg.x : (T*)nullptr,
-                           (T)stp_pre);
-      double h[2];
-      if (cg.fused()) {
-        // One-launch scheme: {g.d, d.d} arrive in hs[12..13] (+ {max|dk|, dk.dk, s1, s2} in hs[8..11]) under the pass's
-        // own tag.  The line search's first trial point is already in cg.x, so its evaluation is queued NOW, behind the
-        // pass, and runs while the host waits for these sums and decides (mcsrch tries stp first whenever g.d < 0;
-        // otherwise line_search discards the evaluation): no host round trip between the two launches.
-        const double tag_norm = cg.tag;
-        if (stp_pre != 0.0 && cg.chained()) {
-          std::swap(cg.g, cg.gp);  // gp = gradient at xk (the pass above was launched with the old pointers)
-          g_swapped = true;
-          rc = cg.evaluate(cg.d);
-          if (rc) return rc;
-          pre_launched = true;
-        }
-        rc = cg.wait_tag(tag_norm);
+      if (!cg.foldable) {
+        rc = cg.normalize(stp_pre);
         if (rc) return rc;
-        h[0] = cg.hs[12];
-        h[1] = cg.hs[13];
-      } else {
-        rc = cg.finish(2, false, false, h, 4);  // + {max|dk|, dk.dk, s1, s2} -> hs[8..11]
-        if (rc) return rc;
+        stp_ready = stp_pre;
       }
-      dginit = h[0];
-      dd = h[1];
-      const double mx = cg.hs[8], s1 = cg.hs[10], s2 = cg.hs[11];
+      // The line search's first trial evaluation is queued NOW, behind the passes above, and runs while the host waits
+      // for the direction's sums and decides (mcsrch tries stp first whenever g.d < 0; otherwise line_search discards the
+      // evaluation): no host round trip in front of it.
+      if (stp_pre != 0.0 && cg.chained()) {
+        std::swap(cg.g, cg.gp);  // gp = gradient at xk
+        g_swapped = true;
+        rc = cg.foldable ? cg.evaluate(cg.dk, nullptr, cg.xk, stp_pre) : cg.evaluate(cg.d);
+        if (rc) return rc;
+        pre_launched = true;
+        stp_ready = stp_pre;
+      }
+      double mx = 0, ss = 0, gdn = 0;
+      rc = cg.wait_dir(&mx, &ss, &gdn);
+      if (rc) return rc;
+      double s1, s2;
+      norm_factors(mx, ss, s1, s2);
+      dginit = (gdn * s1) * s2;
+      dd = ((ss * s1) * s1) * (s2 * s2);
       if (mx != 0) { stp = stp / s1; stp = stp / s2; }
     }
     if (lastgoodstep != 0) stp = lastgoodstep;
     int mcinfo = 0, nfev = 0;
     if (!g_swapped) std::swap(cg.g, cg.gp);  // gp = gradient at xk; the trial evaluations write g
-    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace, stp_pre, pre_launched);
+    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace, stp_ready, pre_launched);
     if (rc) return rc;
     if (nfev == 0) std::swap(cg.g, cg.gp);  // nothing was evaluated: g stays the gradient at xk, as in mcsrch
     double betak = 0;

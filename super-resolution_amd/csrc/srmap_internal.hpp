@@ -109,6 +109,7 @@ struct srmap_problem {
   // evaluation was given (no separate n-vector pass per trial point); only where ztile_can_fold() says so
   const void* eval_fold_xk = nullptr;
   double eval_fold_stp = 0.0;
+  const double* eval_fold_norms = nullptr;  // device {max|dk|, dk.dk}: eval_dvec is the unnormalised direction (solver.hip norm_elem)
   // set by the solver around an evaluation: host-mapped words the evaluation's finish kernel publishes
   // {cost, g.d} to, followed by the arrival tag (saves the separate publish launch); eval_published reports it did
   double* eval_pub = nullptr;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "cg_norm.hpp"
 #include "srmap_internal.hpp"
 
 namespace srmap {
@@ -291,6 +292,8 @@ struct ZArgs {
   const T* fold_xk;      // nullptr: x is read as given
   T* fold_x;
   T fold_stp;
+  const double* fold_norms;  // device {max|dk|, dk.dk}: dvec is the UNNORMALISED direction, every element read from it is
+                             // scaled to the normalised one (cg_norm.hpp) -- the solver stores no normalised vector
   // ---- marching kernel (kernels_zmarch.hip): workgroup -> (strip, band) ----
   int m_nstrips;         // strips of 64 LR cells per image row
   int m_band_rows;       // HR rows per band (a multiple of the step height)
@@ -795,13 +798,37 @@ struct BorderArgs {      // device-resident (one per problem): only the border b
 
 __device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
+// How an evaluation reads the search direction: the vector as given, or -- norms given -- the normalised direction formed
+// from the unnormalised one (uniform values, kept in scalar registers).
+struct DirScale {
+  double mx, s1, s2;
+  bool on;
+};
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ DirScale dir_scale(const double* __restrict__ norms) {
+  DirScale ds{0.0, 1.0, 1.0, false};
+  if (norms != nullptr) {  // uniform
+    double s1, s2;
+    const double mx = norms[0];
+    norm_factors(mx, norms[1], s1, s2);
+    ds.mx = uniform_d(mx); ds.s1 = uniform_d(s1); ds.s2 = uniform_d(s2); ds.on = true;
+  }
+  return ds;
+}
+template <typename T>
+__device__ __forceinline__ T dir_elem(T v, const DirScale& ds) { return ds.on ? norm_elem<T>(v, ds.mx, ds.s1, ds.s2) : v; }
+
 // r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
 // S, B at compile time and the taps from the kernel arguments: the B * B loads of a residual are requested together
 // (with run-time loop bounds and a tap table in memory every tap was its own round trip: ~9 us per border block).
 template <typename T, int S, int B, bool FOLD = false, typename ArgsT>
 __device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int wl, const T* __restrict__ xplane,
                                              const T* __restrict__ yk, int ox, int oy, int i, int j,
-                                             const T* __restrict__ dplane = nullptr, T stp = T(0)) {
+                                             const T* __restrict__ dplane = nullptr, T stp = T(0),
+                                             const DirScale& ds = DirScale{0.0, 1.0, 1.0, false}) {
   constexpr int hb = (B - 1) / 2;
   T xv[B * B];
   const T yv = yk[(size_t)i * wl + j];
@@ -827,7 +854,7 @@ __device__ __forceinline__ T border_residual(const ArgsT& A, int W, int H, int w
     for (int e = 0; e < B; ++e) {
       // mask as a multiply: a select on the loaded value lets the compiler sink each load under its own branch
       T xval = xplane[(unsigned)(rix + cix[e])];
-      if (FOLD) xval = xval + stp * dplane[(unsigned)(rix + cix[e])];   // the line search's trial point, k_axpy_out's expression
+      if (FOLD) xval = xval + stp * dir_elem<T>(dplane[(unsigned)(rix + cix[e])], ds);   // the line search's trial point, k_axpy_out's expression
       xv[a * B + e] = xval * ((rok && cok[e]) ? T(1) : T(0));
     }
   }
@@ -861,6 +888,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
     const T* xplane = (FOLD ? A.fold_xk : A.x) + (size_t)ch * N;
     const T* dplane = FOLD ? A.dvec + (size_t)ch * N : nullptr;
     const T fstp = FOLD ? A.fold_stp : T(0);
+    const DirScale ds = dir_scale(WD ? A.fold_norms : nullptr);
     const T* ybase = A.y + (size_t)ch * nl;
     const bool inside = qr >= 0 && qr < A.H && qc >= 0 && qc < A.W;
     T corr = T(0);
@@ -875,7 +903,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
           if (S * i < A.cr0 || S * i >= A.cr1) continue;
           const int oy = e.oyx >> 16, ox = (int)(short)(e.oyx & 0xffff);
           const double r = (double)border_residual<T, S, B, FOLD>(A, A.W, A.H, A.wl, xplane,
-                                                                  ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j, dplane, fstp);
+                                                                  ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j, dplane, fstp, ds);
           cost += r * r;
         }
       }
@@ -897,13 +925,13 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
             if (i < 0 || i >= A.hl || j < 0 || j >= A.wl) continue;
             // B^T = correlation with kernel.t() (blur_module.cpp:30-36)
             corr += blur_tap<B>(A, b2, a) *
-                    border_residual<T, S, B, FOLD>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j, dplane, fstp);
+                    border_residual<T, S, B, FOLD>(A, A.W, A.H, A.wl, xplane, ybase + (size_t)e.k * obs_C * nl, ox, oy, i, j, dplane, fstp, ds);
           }
         }
       }
       corr *= (T)(2 * S * S);
       // g.d of the corrected gradient: the correction's share, over the rows whose terms this problem counts
-      if (WD && qr >= A.cr0 && qr < A.cr1) gdc = -(double)corr * (double)A.dvec[(size_t)ch * N + (size_t)qr * A.W + qc];
+      if (WD && qr >= A.cr0 && qr < A.cr1) gdc = -(double)corr * (double)dir_elem<T>(A.dvec[(size_t)ch * N + (size_t)qr * A.W + qc], ds);
     }
     if (A.g != nullptr) Bd.corr[(size_t)ch * Bd.n_ring + t] = corr;
   }
@@ -1009,7 +1037,7 @@ static void fill_zargs(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>& A, srmap_problem
       for (int j = 0; j < R; ++j)
         if (i + j > 0) A.pwsum += A.powtab[i + j];
   A.m_nstrips = 0; A.m_band_rows = 0; A.m_nbt = 0;
-  A.fold_xk = nullptr; A.fold_x = nullptr; A.fold_stp = T(0);
+  A.fold_xk = nullptr; A.fold_x = nullptr; A.fold_stp = T(0); A.fold_norms = nullptr;
 }
 
 // ---- marching kernel (kernels_zmarch.hip) ----
