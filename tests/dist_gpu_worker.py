@@ -45,6 +45,7 @@ def main():
         box = [srmap.Comm.unique_id(ctx) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=box[0])
+        print("RCCL_COMM_OK rank %d" % rank, flush=True)  # past this line a failure is the library's, not the environment's
     else:
         comm = srmap.Comm(ctx, rank, world, backend="host", dist=dist)
 

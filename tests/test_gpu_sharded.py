@@ -53,6 +53,10 @@ def test_two_ranks_on_one_gpu(tmp_path, mode, backend):
                 q.kill()
             raise
         logs.append(o)
+    if backend == "rccl" and any(p.returncode != 0 for p in procs) and not all("RCCL_COMM_OK" in o for o in logs):
+        # the communicator itself did not come up (no loopback interface, sockets forbidden ...): the environment cannot
+        # host this test; a failure AFTER the communicator exists is the library's and fails below
+        pytest.skip("RCCL could not create a %d-rank communicator over loopback here:\n%s" % (world, "\n".join(o[-600:] for o in logs)))
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     res = json.load(open(out))
     print(res)
