@@ -323,6 +323,7 @@ def main():
             dist.broadcast(uid, 0)  # gloo, host memory
             watchdog(120, "ncclCommInitRank")
             comm = srmap.Comm(ctx, rank, world, backend="rccl", unique_id=bytes(uid.numpy().tobytes()))
+            sys.stderr.write("bench.py: rank %d RCCL communicator up\n" % rank)
             watchdog(args.watchdog_s, "the job")
             if args.overlap:
                 comm.set_overlap(True)
