@@ -16,7 +16,8 @@
 //                    d.d (cg_norm.hpp): the normalised direction d = dn s1 s2 is
 //                    not re-summed, and on the tile path not even stored
 //   k_beta_dots      y = g - g_prev on the fly (the gradient buffers ping-pong,
-//                    mincg's yk vector is never stored), y.dk, g.g, g.y
+//                    mincg's yk vector is never stored), g.g, g.y; their
+//                    denominator y.dk = g.dk - g_prev.dk from sums already known
 // plus the trial points x = xk + stp d: formed by the evaluation itself as it
 // loads its window, from dk and the device-resident norms (tile kernel, un-sharded
 // solves: no n-vector pass per trial point); elsewhere k_normalize stores d (and
@@ -323,31 +324,33 @@ __global__ __launch_bounds__(256) void k_normalize(T* __restrict__ d, const T* _
   }
 }
 
-// y = g - gp (mincg: yk = -g_k, then yk += g_{k+1}: the same rounding) ; sums: [0] y.dk, [1] g.g, [2] g.y   (the DY / HS
-// betas, optimization.cpp:17700-17760)
+// y = g - gp (mincg: yk = -g_k, then yk += g_{k+1}: the same rounding) ; sums: [0] g.g, [1] g.y   (the DY / HS betas,
+// optimization.cpp:17700-17760).  Their denominator vv = y.dk is not summed here: y.dk = g.dk - gp.dk, and both terms are
+// already known -- gp.dk is the g.dn the direction pass reduced, g.dk = (g.d) / (s1 s2) from the accepted trial
+// evaluation's g.d (the line search bounds |g.d| by 0.3 |gp.d|: no cancellation) -- so the pass reads two vectors
+// instead of three (dk is not touched).  vv comes as an argument.
 template <typename T, int V>
-__global__ __launch_bounds__(256) void k_beta_dots(const T* __restrict__ gp, const T* __restrict__ g, const T* __restrict__ dk,
+__global__ __launch_bounds__(256) void k_beta_dots(const T* __restrict__ gp, const T* __restrict__ g,
                                                   size_t n, Owned ow, double* __restrict__ part, Fin fin,
-                                                  double* __restrict__ beta_dst, int restart) {
-  double a = 0, b = 0, c = 0;
+                                                  double* __restrict__ beta_dst, int restart, double vv) {
+  double b = 0, c = 0;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
-    T gv[V], pv[V], kv[V];
+    T gv[V], pv[V];
     ldv<T, V, false>(g + i, gv);
     ldv<T, V, true>(gp + i, pv);
-    ldv<T, V, true>(dk + i, kv);
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       if (!ow.has(i + q)) continue;
       const T y = -pv[q] + gv[q];
-      a += (double)y * (double)kv[q]; b += (double)gv[q] * (double)gv[q]; c += (double)gv[q] * (double)y;
+      b += (double)gv[q] * (double)gv[q]; c += (double)gv[q] * (double)y;
     }
   }
   double tot[3];
-  if (block_partials3(a, b, c, part, false, 3, fin, tot)) {
+  if (block_partials3(b, c, 0.0, part, false, 2, fin, tot)) {
     if (beta_dst != nullptr) {
       // betak = max(0, min(betady, betahs)) exactly as run_cg forms it on the host (same IEEE divisions and compares):
       // the direction pass queued behind this one reads it, the host never has to answer in between
-      const double vv = tot[0], bdy = tot[1] / vv, bhs = tot[2] / vv;
+      const double bdy = tot[0] / vv, bhs = tot[1] / vv;
       const double bm = bdy < bhs ? bdy : bhs;
       double bk = 0.0 > bm ? 0.0 : bm;
       if (restart) bk = 0.0;
@@ -916,7 +919,7 @@ static void mt_step(Bracket* b, double* stp, double fp, double dp, bool* brackt,
 template <typename T>
 static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, double gtol,
                        int* info, int* nfev, double trim, std::vector<double>* trace, double stp_in_x = 0.0,
-                       bool pre_launched = false) {
+                       bool pre_launched = false, double* dg_last = nullptr) {
   const double ftol = 0.001, xtol = 100 * 5E-16, stpmin = 1.0e-50, stpmax = 1.0e+50, p5 = 0.5,
                p66 = 0.66, xtrapf = 4.0;
   const int maxfev = 20;
@@ -979,6 +982,7 @@ static int line_search(DeviceCG<T>& cg, double* f, double dginit, double* stp, d
     }
     *info = 0;
     *nfev += 1;
+    if (dg_last) *dg_last = dg;
     const double ftest1 = finit + *stp * dgtest;
     if ((brackt && (*stp <= stmin || *stp >= stmax)) || infoc == 0) *info = 6;
     if (*stp == stpmax && *f < finit && *f <= ftest1 && dg <= dgtest) *info = 5;
@@ -1065,6 +1069,7 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     // materialised: every trial point x = xk + stp * d is written by the line search -- by the evaluation itself, from dk
     // and the norms on the device, where the tile kernel can (foldable), else from the d a scaling pass stores.
     double stp = 1.0, dginit = 0, dd = 0;
+    double gdk = 0, ns1 = 1, ns2 = 1;  // g.dk at xk and the two scale factors, for the beta denominator below
     bool pre_launched = false, g_swapped = false;
     // the first step is lastgoodstep unless that is 0 (then it comes from the direction's norms)
     const double stp_pre = (lastgoodstep != 0 && lastgoodstep >= 1.0e-50 && lastgoodstep <= 1.0e+50) ? lastgoodstep : 0.0;
@@ -1093,12 +1098,14 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
       norm_factors(mx, ss, s1, s2);
       dginit = (gdn * s1) * s2;
       dd = ((ss * s1) * s1) * (s2 * s2);
+      gdk = gdn; ns1 = s1; ns2 = s2;
       if (mx != 0) { stp = stp / s1; stp = stp / s2; }
     }
     if (lastgoodstep != 0) stp = lastgoodstep;
     int mcinfo = 0, nfev = 0;
     if (!g_swapped) std::swap(cg.g, cg.gp);  // gp = gradient at xk; the trial evaluations write g
-    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace, stp_ready, pre_launched);
+    double dg_acc = 0;  // g.d at the last trial point
+    rc = line_search(cg, &f, dginit, &stp, gtol, &mcinfo, &nfev, trim, trace, stp_ready, pre_launched, &dg_acc);
     if (rc) return rc;
     if (nfev == 0) std::swap(cg.g, cg.gp);  // nothing was evaluated: g stays the gradient at xk, as in mcsrch
     double betak = 0;
@@ -1109,28 +1116,29 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
     const bool chain = cg.chained();
     const int restart = (res.its > 0 && res.its % (3 + (long long)n) == 0) ? 1 : 0;
     if (mcinfo == 1) {
-      // yk = g - gp ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv
+      // yk = g - gp ; vv = yk.dk ; betady = g.g/vv ; betahs = g.yk/vv.  vv = g.dk - gp.dk from sums already on the
+      // host: gp.dk is the direction pass's g.dn, g.dk = (g.d) / (s2 s1) with the accepted evaluation's g.d (k_beta_dots)
+      const double vv = (dg_acc / ns2) / ns1 - gdk;
       double* beta_dst = chain ? cg.dscal + 8 : (double*)nullptr;
       if (cg.vec())
         hipLaunchKernelGGL((k_beta_dots<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
-                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart);
+                           n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart, vv);
       else
         hipLaunchKernelGGL((k_beta_dots<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
-                           (const T*)cg.dk, n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart);
+                           n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart, vv);
       if (chain) {
         const double tag_beta = cg.tag;
-        rc = cg.direction(cg.dk, 0.0, false, cg.dscal + 8);  // dn, norms of dn (device)
+        rc = cg.direction(cg.dk, 0.0, false, cg.dscal + 8);  // dn, sums of dn (device)
         if (rc) return rc;
         rc = cg.wait_tag(tag_beta);
         if (rc) return rc;
-        gg = cg.hs[1];
+        gg = cg.hs[0];
       } else {
-        double h[3];
-        rc = cg.finish(3, false, false, h);
+        double h[2];
+        rc = cg.finish(2, false, false, h);
         if (rc) return rc;
-        const double vv = h[0];
-        betak = dmax(0.0, dmin(h[1] / vv, h[2] / vv));
-        gg = h[1];
+        betak = dmax(0.0, dmin(h[0] / vv, h[1] / vv));
+        gg = h[0];
       }
     } else {
       if (cg.vec())
