@@ -96,10 +96,14 @@ def test_cfg2_class_solve_matches_oracle(sr, ctx, impl):
     assert psnr_ref < psnr0  # the reference objective's minimiser fits the noise: the drop is the reference's behaviour
 
 
-def test_chained_passes_equal_host_paced_passes(sr, ctx):
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_chained_passes_equal_host_paced_passes(sr, ctx, dtype):
     """The solver queues passes whose inputs are already on the device without waiting for the host (the first trial
-    evaluation behind the normalisation pass, the direction pass behind the beta sums: csrc/solver.hip run_cg).  With
-    srmap_irls_options.host_paced_passes = 1 every pass waits for the host as before: the two must agree bit for bit."""
+    evaluation behind the direction pass, the direction pass behind the beta sums: csrc/solver.hip run_cg) and lets the
+    evaluation form every trial point x = xk + stp * d itself, from the UNNORMALISED direction and the norms on the device
+    (csrc/cg_norm.hpp).  With srmap_irls_options.host_paced_passes = 1 every pass waits for the host, a scaling pass
+    stores the normalised direction and separate passes form the trial points: the two must agree bit for bit, in both
+    arithmetic types (the element d_i is one expression wherever it is formed)."""
     import bench
     s, K, W, H = 4, 16, 256, 256
     shifts = [[k % s, (k // s) % s] for k in range(K)]
@@ -110,7 +114,7 @@ def test_chained_passes_equal_host_paced_passes(sr, ctx):
     x0 = bench.bilinear_upsample(lr[0], s)
     out = {}
     for mode in ("1", "0"):
-        p = sr.Problem(ctx, W, H, 1, K, s, shifts, 3, 1.0, sr.F64)
+        p = sr.Problem(ctx, W, H, 1, K, s, shifts, 3, 1.0, dtype)
         p.set_observations(lr)
         p.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5)
         opts = sr.default_irls_options()
