@@ -125,3 +125,46 @@ def test_chained_passes_equal_host_paced_passes(sr, ctx, dtype):
         out[mode] = (x, rep.irls_rounds, rep.cg_iterations, rep.evaluations, rep.final_cost)
     assert out["1"][1:] == out["0"][1:]
     assert np.array_equal(out["1"][0], out["0"][0])
+
+
+# (scale, blur, HR width, HR height, channels, frames, regulariser, dtype): partial tiles on the right / bottom edge, every
+# scale and blur size of the tile path, TV and BTV, more than one channel, offsets of both signs
+FOLD_GEOMS = [
+    (4, 3, 200, 136, 1, 16, (2, 0.01, 3, 0.5), 0),
+    (4, 3, 328, 72, 2, 8, (2, 0.02, 2, 0.7), 0),
+    (4, 1, 264, 96, 1, 16, (0, 0.01, 0, 0.0), 0),
+    (3, 3, 201, 99, 1, 9, (2, 0.01, 3, 0.5), 0),
+    (3, 1, 150, 150, 1, 5, (0, 0.02, 0, 0.0), 0),
+    (2, 3, 130, 70, 1, 4, (2, 0.01, 1, 0.5), 0),
+    (2, 1, 96, 160, 3, 4, (0, 0.01, 0, 0.0), 0),
+    (4, 3, 200, 136, 1, 16, (2, 0.01, 3, 0.5), 1),
+    (2, 3, 130, 70, 1, 4, (0, 0.01, 0, 0.0), 1),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FOLD_GEOMS)))
+def test_fold_equals_separate_passes_over_geometries(sr, ctx, case):
+    """The evaluation that forms its own trial point (window = xk + stp * d_i, d_i from the unnormalised direction and the
+    norms on the device; border blocks and edge tiles included) against the separate passes (host_paced_passes = 1), over
+    the geometries of the tile path: same iterates bit for bit, same counts."""
+    s, b, W, H, C, K, reg, dtype = FOLD_GEOMS[case]
+    rng = np.random.default_rng(900 + case)
+    shifts = [[int(rng.integers(-(s - 1), s)), int(rng.integers(-(s - 1), s))] for _ in range(K)]
+    shifts[0] = [0, 0]
+    w, h = W // s, H // s
+    W, H = w * s, h * s
+    lr = rng.random((K, C, h, w))
+    x0 = rng.random((C, H, W))
+    out = {}
+    for paced in (0, 1):
+        p = sr.Problem(ctx, W, H, C, K, s, shifts, b, 1.0 if b > 1 else 0.0, dtype)
+        p.set_observations(lr)
+        p.add_regularizer(*reg)
+        opts = sr.default_irls_options()
+        opts.max_num_irls_iterations = 2
+        opts.max_num_solver_iterations = 6
+        opts.host_paced_passes = paced
+        x, rep = p.solve(x0, opts)
+        out[paced] = (x, rep.irls_rounds, rep.cg_iterations, rep.evaluations, rep.final_cost)
+    assert out[0][1:] == out[1][1:]
+    assert np.array_equal(out[0][0], out[1][0])
