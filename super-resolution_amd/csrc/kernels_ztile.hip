@@ -69,6 +69,11 @@
 #ifndef SRMAP_EXP_F32_WPE
 #define SRMAP_EXP_F32_WPE 6
 #endif
+//   SRMAP_EXP_SPOLD     sub-pixel instances: the entry-major tap table of rounds 2-4 (one request per pixel and tap)
+//                       instead of the source-major one (z_row_sp2)
+#ifndef SRMAP_EXP_SPOLD
+#define SRMAP_EXP_SPOLD 0
+#endif
 #ifndef SRMAP_EXP_NOLOAD
 #define SRMAP_EXP_NOLOAD 0
 #endif
@@ -337,16 +342,22 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
     // table columns reach Dr / S + 1 LR cells around a pixel's own (+ 1 for the neighbour pixels of the cell)
     const int mj = A.Dr / S + 3;
     const bool col_inner = (CJ0 - mj >= 0) && (CJ0 + C::CW + mj <= A.wl);
+#if SRMAP_EXP_SPOLD
+#define SRMAP_ZROW_SP z_row_sp
+#else
+#define SRMAP_ZROW_SP z_row_sp2
+#endif
     if (row_edge) {
-      z_row_sp<T, S, B, C, true, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
-      if (has_z_halo) z_row_sp<T, S, B, C, true, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+      SRMAP_ZROW_SP<T, S, B, C, true, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) SRMAP_ZROW_SP<T, S, B, C, true, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
     } else if (!col_inner) {
-      z_row_sp<T, S, B, C, false, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
-      if (has_z_halo) z_row_sp<T, S, B, C, false, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+      SRMAP_ZROW_SP<T, S, B, C, false, true>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) SRMAP_ZROW_SP<T, S, B, C, false, true>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
     } else {
-      z_row_sp<T, S, B, C, false, false>(A, zs, wv, R0, CJ0, lane, ch, zown);
-      if (has_z_halo) z_row_sp<T, S, B, C, false, false>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
+      SRMAP_ZROW_SP<T, S, B, C, false, false>(A, zs, wv, R0, CJ0, lane, ch, zown);
+      if (has_z_halo) SRMAP_ZROW_SP<T, S, B, C, false, false>(A, zs, hrowz, R0, CJ0, lane, ch, dummy);
     }
+#undef SRMAP_ZROW_SP
   }
   if (!SP && want_data) {
     T dummy[S];
@@ -537,6 +548,7 @@ void ztile_release(srmap_problem* p) {
   if (z->d_off) (void)hipFree(z->d_off);
   if (z->d_aux) (void)hipFree(z->d_aux);
   if (z->d_spw) (void)hipFree(z->d_spw);
+  if (z->d_spsrc) (void)hipFree(z->d_spsrc);
   spfwd_release(&z->spf);
   if (z->d_corr) (void)hipFree(z->d_corr);
   if (z->d_bd) (void)hipFree(z->d_bd);
@@ -611,6 +623,30 @@ bool ztile_plan(srmap_problem* p) {
             lists[(size_t)pr * S + pc].push_back(q);
           }
         }
+    // the same taps source-major (z_row_sp2): per row phase one record per (frame, vertical tap) on the LR grid
+    std::vector<std::vector<ZSrc>> srcs((size_t)S);
+    for (int pr = 0; pr < S; ++pr)
+      for (int k = 0; k < K; ++k) {
+        const WarpTaps<double>& b = p->bwd_warps[k];
+        for (int dy = 0; dy < 2; ++dy) {
+          double w0 = 0.0, w1 = 0.0;
+          for (int t = 0; t < b.ntaps; ++t)
+            if ((t >> 1) == dy) { if (t & 1) w1 = b.w[t]; else w0 = b.w[t]; }
+          if (w0 == 0.0 && w1 == 0.0) continue;
+          const int rr = pr + b.oy + dy;
+          if (pmod(rr, S) != 0) continue;
+          ZSrc q; q.k = k; q.io = fdiv(rr, S); q.ox = b.ox; q.pad = 0; q.w0 = w0; q.w1 = w1;
+          srcs[(size_t)pr].push_back(q);
+        }
+      }
+    int spmax = 1;
+    for (const auto& l : srcs) spmax = std::max(spmax, (int)l.size());
+    z->spmax = spmax;
+    std::vector<ZSrc> srctab((size_t)S * spmax, ZSrc{0, 0, 0, 0, 0.0, 0.0});
+    for (int pr = 0; pr < S; ++pr) {
+      z->spn[pr] = (int)srcs[(size_t)pr].size();
+      for (size_t n = 0; n < srcs[(size_t)pr].size(); ++n) srctab[(size_t)pr * spmax + n] = srcs[(size_t)pr][n];
+    }
     int MS = 1;
     for (const auto& l : lists) MS = std::max(MS, (int)l.size());
     z->MS = MS;
@@ -638,6 +674,8 @@ bool ztile_plan(srmap_problem* p) {
               hipMemcpy(z->d_aux, aux.data(), sizeof(ZEntry) * aux.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&z->d_spw, sizeof(double) * spw.size()) == hipSuccess &&
               hipMemcpy(z->d_spw, spw.data(), sizeof(double) * spw.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void**)&z->d_spsrc, sizeof(ZSrc) * srctab.size()) == hipSuccess &&
+              hipMemcpy(z->d_spsrc, srctab.data(), sizeof(ZSrc) * srctab.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&z->d_off, 64) == hipSuccess;
     p->zplan = z;
     if (ok) {  // granules of the in-kernel cost reduction (as below)

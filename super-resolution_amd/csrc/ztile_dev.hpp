@@ -82,6 +82,11 @@ struct ZCfg {
   static constexpr int NP = REGK == 2 ? 2 * R + 1 : 1;
 };
 
+// Sub-pixel instances, source-major table: one record per (frame, vertical tap of the transpose warp) that lands on a
+// row phase -- LR row offset io, the frame's integer column offset ox, the two horizontal tap weights (already multiplied
+// by the vertical one).  The residual column q + e a pixel reads and which of the S + 2 HB pixels of a cell it serves
+// follow from ox alone (z_row_sp2).
+struct ZSrc { int k, io, ox, pad; double w0, w1; };
 struct ZEntry { int k, io, jo, oyx; };  // frame, LR row / column offset of the residual a pixel of this phase owns,
                                          // forward offset packed (oy << 16) | (ox & 0xffff)
 
@@ -273,6 +278,9 @@ struct ZArgs {
   const ZEntry* aux;     // [MS][S][S] the same residuals as (frame, LR row offset, LR column offset) for edge tiles
   const T* rbuf;         // SP instances (sub-pixel shifts): residuals r_k = A_k x - y_k, [K][C][h][w], from k_forward_direct
   const double* spw;     //   bilinear tap weight of every table entry, [MS][S][S]
+  const ZSrc* spsrc;     //   the same taps source-major: [S][spmax] records, spn[pr] of them in use (z_row_sp2)
+  int spn[4];
+  int spmax;
   int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
   RingRects ring;        // border frame rectangles (border blocks / tasks, corrections)
   // ---- in-kernel finish (no second launch): partials leave as write-through granules, the last block of the grid
@@ -597,6 +605,90 @@ __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int
     sp_load_round<T, S, C, EDGE, COLCLAMP>(A, pr, rc, t, cell0, lane, ch, cn, rv, wm);
 #pragma unroll
     for (int v = 0; v < NV; ++v) z[v] += wm[v] * rv[v];
+  }
+  if (B == 1) {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) zout[pc] = z[pc];
+  } else {
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      T zh = T(0);
+#pragma unroll
+      for (int e = 0; e < B; ++e) zh += k1_tap<B>(A, e) * z[pc + e];
+      zs[(rowrel + HB) * C::ZROW + pc * C::CW + lane] = zh;
+    }
+  }
+}
+
+// The same sum with the taps grouped by SOURCE (frame, vertical tap): the residual r_k(i, m) a horizontal tap pair lands
+// on serves two neighbouring pixels -- (m S - ox) with the dx = 0 weight and the pixel left of it with the dx = 1 weight --
+// so a cell's S + 2 HB pixels need 1 - 2 residuals per source instead of one request per (pixel, tap): 14 requests per
+// row instead of 24 - 30 at cfg2's 16 frames (entry-major rounds are padded to the longest phase).  With
+// a = (-ox) mod S the pixels are pcv = a + S e (dx = 0) and a - 1 + S e (dx = 1), the residual column (ox + a) / S + e,
+// e in {-1, 0, 1}: compile-time pixel indices per value of a (uniform switch).
+template <typename T, int S, typename C, int A, bool EDGE, bool COLCLAMP, typename ArgsT>
+__device__ __forceinline__ void sp_source(const ArgsT& A_, const T* __restrict__ rowp, int jbase, int lane, T w0, T w1,
+                                          T (&z)[C::NV]) {
+  constexpr int HB = C::HB, NV = C::NV;
+#pragma unroll
+  for (int e = -1; e <= 1; ++e) {
+    const int p0 = A + S * e, p1 = A - 1 + S * e;                 // pixel (relative to the cell) of the dx = 0 / dx = 1 tap
+    const bool in0 = p0 >= -HB && p0 < S + HB, in1 = p1 >= -HB && p1 < S + HB;
+    if (!in0 && !in1) continue;
+    T r;
+    T m0 = w0, m1 = w1;
+    if (!COLCLAMP) {
+      r = rowp[(unsigned)(lane + e + 1)];   // rowp points one cell left of the source's base column (e = -1 -> + 0)
+    } else {
+      const int j = jbase + lane + e;
+      const int jc = j < 0 ? 0 : (j >= A_.wl ? A_.wl - 1 : j);
+      r = rowp[jc];
+      const bool ok = (unsigned)j < (unsigned)A_.wl;  // the WEIGHT is masked: nothing is done to the loaded value
+      m0 = ok ? w0 : T(0);
+      m1 = ok ? w1 : T(0);
+    }
+    if (in0) z[(in0 ? p0 : 0) + HB] += m0 * r;
+    if (in1) z[(in1 ? p1 : 0) + HB] += m1 * r;
+  }
+}
+
+template <typename T, int S, int B, typename C, bool EDGE, bool COLCLAMP, typename ArgsT>
+__device__ __forceinline__ void z_row_sp2(const ArgsT& A, T* __restrict__ zs, int rowrel, int R0, int cell0, int lane, int ch,
+                                          T (&zout)[S]) {
+  constexpr int HB = C::HB, NV = C::NV;
+  int rc, pr;
+  row_phase<S>(R0 + rowrel, rc, pr);
+  const size_t nl = (size_t)A.wl * A.hl;
+  const int ns = A.spn[pr];
+  T z[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) z[v] = T(0);
+  typedef const ZSrc __attribute__((address_space(4))) * SrcPtr;
+  SrcPtr tab = (SrcPtr)(unsigned long long)(A.spsrc + (size_t)pr * A.spmax);
+  for (int n = 0; n < ns; ++n) {
+    const int k = tab[n].k, io = tab[n].io, ox = tab[n].ox;
+    const T w0 = (T)tab[n].w0, w1 = (T)tab[n].w1;
+    const int i = rc + io;
+    if (EDGE && (unsigned)i >= (unsigned)A.hl) continue;  // uniform: no such LR row
+    const int a = posmod(-ox, S);
+    const int q = (ox + a) / S;                           // exact: ox + a is a multiple of S
+    const T* plane = A.rbuf + (size_t)(k * A.obs_C + ch) * nl + (size_t)i * A.wl;
+    // COLCLAMP: per-lane clamped column (jbase = column of e = 0 for lane 0); else uniform row base one cell to the left
+    const int jbase = cell0 + q;
+    const T* rowp = COLCLAMP ? plane : plane + (jbase - 1);
+    if (S == 4) {
+      if (a == 0) sp_source<T, S, C, 0, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+      else if (a == 1) sp_source<T, S, C, 1, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+      else if (a == 2) sp_source<T, S, C, 2, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+      else sp_source<T, S, C, (S > 3 ? 3 : 0), EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+    } else if (S == 3) {
+      if (a == 0) sp_source<T, S, C, 0, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+      else if (a == 1) sp_source<T, S, C, 1, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+      else sp_source<T, S, C, (S > 2 ? 2 : 0), EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+    } else {
+      if (a == 0) sp_source<T, S, C, 0, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+      else sp_source<T, S, C, 1, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+    }
   }
   if (B == 1) {
 #pragma unroll
@@ -974,6 +1066,9 @@ struct ZPlan {
   bool subpix = false;  // sub-pixel shifts: residuals from k_forward_direct, z by 4-tap tables, exact ring by k_gather_direct
   int Dr = 0;           //   ring width
   double* d_spw = nullptr;
+  ZSrc* d_spsrc = nullptr;     //   source-major tap table [S][spmax] (z_row_sp2)
+  int spn[4] = {0, 0, 0, 0};
+  int spmax = 0;
   SpForwardPlan spf;    //   forward tile kernel (kernels_spfwd.hip); the direct forward kernel when it does not apply
   int E = 0;   // max |shift|
   int MS = 1;  // table slots per (row phase, column phase)
@@ -1007,6 +1102,8 @@ static void fill_zargs(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>& A, srmap_problem
   A.x = x; A.y = (const T*)p->d_obs + (size_t)obs_c0 * geo.w * geo.h; A.w = wts; A.g = g; A.partials = partials;
   A.dvec = dvec; A.partials_gd = partials_gd;
   A.cnt = z.d_cnt; A.off = z.d_off; A.aux = z.d_aux; A.MS = z.MS;
+  A.spsrc = z.d_spsrc; A.spmax = z.spmax;
+  for (int pr = 0; pr < 4; ++pr) A.spn[pr] = z.spn[pr];
   for (int pr = 0; pr < 4; ++pr) {
     for (int i = 0; i < 8; ++i) A.cntk[pr][i] = z.h_cnt[pr * 8 + i];
     for (int pc = 0; pc < 4; ++pc) { A.off0[pr][pc] = z.h_off0[pr * 4 + pc]; A.aux0[pr][pc] = z.h_aux0[pr * 4 + pc]; }
