@@ -626,29 +626,27 @@ __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int
 // row instead of 24 - 30 at cfg2's 16 frames (entry-major rounds are padded to the longest phase).  With
 // a = (-ox) mod S the pixels are pcv = a + S e (dx = 0) and a - 1 + S e (dx = 1), the residual column (ox + a) / S + e,
 // e in {-1, 0, 1}: compile-time pixel indices per value of a (uniform switch).
-template <typename T, int S, typename C, int A, bool EDGE, bool COLCLAMP, typename ArgsT>
-__device__ __forceinline__ void sp_source(const ArgsT& A_, const T* __restrict__ rowp, int jbase, int lane, T w0, T w1,
-                                          T (&z)[C::NV]) {
-  constexpr int HB = C::HB, NV = C::NV;
+// Requests and arithmetic are separated per chunk of kSpChunk sources: all residual requests of the chunk are issued
+// first (which of the three columns e a source needs follows from a with scalar arithmetic), then the multiply-adds run
+// per source with compile-time pixel indices.  (One source at a time left every request's latency exposed: table
+// record -> request -> multiply-add, 8 - 10 times per row.)
+constexpr int kSpChunk = 4;
+template <typename T, int S, typename C, int A, bool COLCLAMP, typename ArgsT>
+__device__ __forceinline__ void sp_apply(const ArgsT& A_, const T (&rv)[3], int jbase, int lane, T w0, T w1, T (&z)[C::NV]) {
+  constexpr int HB = C::HB;
 #pragma unroll
   for (int e = -1; e <= 1; ++e) {
     const int p0 = A + S * e, p1 = A - 1 + S * e;                 // pixel (relative to the cell) of the dx = 0 / dx = 1 tap
     const bool in0 = p0 >= -HB && p0 < S + HB, in1 = p1 >= -HB && p1 < S + HB;
     if (!in0 && !in1) continue;
-    T r;
     T m0 = w0, m1 = w1;
-    if (!COLCLAMP) {
-      r = rowp[(unsigned)(lane + e + 1)];   // rowp points one cell left of the source's base column (e = -1 -> + 0)
-    } else {
-      const int j = jbase + lane + e;
-      const int jc = j < 0 ? 0 : (j >= A_.wl ? A_.wl - 1 : j);
-      r = rowp[jc];
-      const bool ok = (unsigned)j < (unsigned)A_.wl;  // the WEIGHT is masked: nothing is done to the loaded value
+    if (COLCLAMP) {  // the WEIGHT is masked per lane: nothing was done to the loaded value
+      const bool ok = (unsigned)(jbase + lane + e) < (unsigned)A_.wl;
       m0 = ok ? w0 : T(0);
       m1 = ok ? w1 : T(0);
     }
-    if (in0) z[(in0 ? p0 : 0) + HB] += m0 * r;
-    if (in1) z[(in1 ? p1 : 0) + HB] += m1 * r;
+    if (in0) z[(in0 ? p0 : 0) + HB] += m0 * rv[e + 1];
+    if (in1) z[(in1 ? p1 : 0) + HB] += m1 * rv[e + 1];
   }
 }
 
@@ -665,29 +663,52 @@ __device__ __forceinline__ void z_row_sp2(const ArgsT& A, T* __restrict__ zs, in
   for (int v = 0; v < NV; ++v) z[v] = T(0);
   typedef const ZSrc __attribute__((address_space(4))) * SrcPtr;
   SrcPtr tab = (SrcPtr)(unsigned long long)(A.spsrc + (size_t)pr * A.spmax);
-  for (int n = 0; n < ns; ++n) {
-    const int k = tab[n].k, io = tab[n].io, ox = tab[n].ox;
-    const T w0 = (T)tab[n].w0, w1 = (T)tab[n].w1;
-    const int i = rc + io;
-    if (EDGE && (unsigned)i >= (unsigned)A.hl) continue;  // uniform: no such LR row
-    const int a = posmod(-ox, S);
-    const int q = (ox + a) / S;                           // exact: ox + a is a multiple of S
-    const T* plane = A.rbuf + (size_t)(k * A.obs_C + ch) * nl + (size_t)i * A.wl;
-    // COLCLAMP: per-lane clamped column (jbase = column of e = 0 for lane 0); else uniform row base one cell to the left
-    const int jbase = cell0 + q;
-    const T* rowp = COLCLAMP ? plane : plane + (jbase - 1);
-    if (S == 4) {
-      if (a == 0) sp_source<T, S, C, 0, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-      else if (a == 1) sp_source<T, S, C, 1, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-      else if (a == 2) sp_source<T, S, C, 2, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-      else sp_source<T, S, C, (S > 3 ? 3 : 0), EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-    } else if (S == 3) {
-      if (a == 0) sp_source<T, S, C, 0, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-      else if (a == 1) sp_source<T, S, C, 1, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-      else sp_source<T, S, C, (S > 2 ? 2 : 0), EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-    } else {
-      if (a == 0) sp_source<T, S, C, 0, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
-      else sp_source<T, S, C, 1, EDGE, COLCLAMP>(A, rowp, jbase, lane, w0, w1, z);
+  for (int n0 = 0; n0 < ns; n0 += kSpChunk) {
+    T rv[kSpChunk][3];
+    T w0s[kSpChunk], w1s[kSpChunk];
+    int as[kSpChunk], jb[kSpChunk];
+    // ---- requests of the chunk ----
+#pragma unroll
+    for (int c = 0; c < kSpChunk; ++c) {
+      const int n = n0 + c;
+      as[c] = -1; jb[c] = 0; w0s[c] = T(0); w1s[c] = T(0);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) rv[c][e] = T(0);
+      if (n >= ns) continue;                                 // uniform
+      const int k = tab[n].k, io = tab[n].io, ox = tab[n].ox;
+      const int i = rc + io;
+      if (EDGE && (unsigned)i >= (unsigned)A.hl) continue;   // uniform: no such LR row
+      const int a = posmod(-ox, S);
+      const int q = (ox + a) / S;                            // exact: ox + a is a multiple of S
+      as[c] = a; jb[c] = cell0 + q;
+      w0s[c] = (T)tab[n].w0; w1s[c] = (T)tab[n].w1;
+      const T* plane = A.rbuf + (size_t)(k * A.obs_C + ch) * nl + (size_t)i * A.wl;
+#pragma unroll
+      for (int e = -1; e <= 1; ++e) {
+        const int p0 = a + S * e, p1 = p0 - 1;
+        const bool need = (p0 >= -HB && p0 < S + HB) || (p1 >= -HB && p1 < S + HB);   // uniform
+        if (!need) continue;
+#ifdef SRMAP_EXP_SPNOLOAD
+        rv[c][e + 1] = (T)(lane + e) * w0s[c];               // TIMING ONLY: no residual request
+#else
+        if (!COLCLAMP) {
+          rv[c][e + 1] = (plane + (jb[c] + e))[(unsigned)lane];   // uniform base + lane
+        } else {
+          const int j = jb[c] + lane + e;
+          rv[c][e + 1] = plane[j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j)];
+        }
+#endif
+      }
+    }
+    // ---- multiply-adds, per source with compile-time pixel indices ----
+#pragma unroll
+    for (int c = 0; c < kSpChunk; ++c) {
+      const int a = as[c];
+      if (a < 0) continue;                                   // uniform
+      if (a == 0) sp_apply<T, S, C, 0, COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
+      else if (a == 1) sp_apply<T, S, C, 1, COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
+      else if (a == 2) sp_apply<T, S, C, (S > 2 ? 2 : 0), COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
+      else sp_apply<T, S, C, (S > 3 ? 3 : 0), COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
     }
   }
   if (B == 1) {
