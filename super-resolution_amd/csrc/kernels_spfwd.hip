@@ -34,7 +34,10 @@ constexpr int kMaxRowsPerWave = 4;
 template <typename T>
 struct SpFrame {  // one frame's forward warp folded with the blur
   int oy, ox;     // integer part of the bilinear gather (source = pixel + (oy, ox) + {0,1}^2)
-  int pad0, pad1;
+  int rowb;       // window row of stencil row 0 for LR row 0 of the workgroup: -HB + oy - RLO
+  int pad0;
+  int coloff[4];  // per stencil column e1: window offset (column phase) * XC + (cell offset - CLO), worked out on the
+                  // host (the divisions and the 64-bit address arithmetic per frame and column ran on the scalar unit)
   T comb[4][16];  // (b+1) x (b+1) stencils, row major with stride b+1: [0] interior, [1] without blur column 0
                   // (LR column 0), [2] without blur row 0 (LR row 0), [3] without both
 };
@@ -135,15 +138,13 @@ __global__ __launch_bounds__(64 * kNW) void k_forward_sp(SpfArgs<T> A) {
       typedef const SpFrame<T> __attribute__((address_space(4))) * FramePtr;
       FramePtr fp = (FramePtr)(unsigned long long)(A.frames + k);
       const auto& f = *fp;
-      const int roff = S * li - HB + f.oy - A.RLO;  // window row of stencil row 0
+      const int roff = S * li + f.rowb;  // window row of stencil row 0
       T acc = T(0);
       const auto* cm = f.comb[vrow];
       const auto* cmc = f.comb[vrow | 1];
 #pragma unroll
       for (int e1 = 0; e1 < NB1; ++e1) {
-        const int co = f.ox - HB + e1;
-        const int cq = fdiv_rt(co, S), ph = co - cq * S;
-        const T* col = xs + roff * XROW + ph * A.XC + (cq - A.CLO) + lane;
+        const T* col = xs + roff * XROW + f.coloff[e1] + lane;
 #pragma unroll
         for (int a1 = 0; a1 < NB1; ++a1) acc += cm[a1 * NB1 + e1] * col[a1 * XROW];
       }
@@ -151,9 +152,7 @@ __global__ __launch_bounds__(64 * kNW) void k_forward_sp(SpfArgs<T> A) {
         acc = T(0);
 #pragma unroll
         for (int e1 = 0; e1 < NB1; ++e1) {
-          const int co = f.ox - HB + e1;
-          const int cq = fdiv_rt(co, S), ph = co - cq * S;
-          const T* col = xs + roff * XROW + ph * A.XC + (cq - A.CLO);
+          const T* col = xs + roff * XROW + f.coloff[e1];
 #pragma unroll
           for (int a1 = 0; a1 < NB1; ++a1) acc += cmc[a1 * NB1 + e1] * col[a1 * XROW];
         }
@@ -184,7 +183,13 @@ bool upload_frames(const srmap_problem* p, SpForwardPlan* sp) {
   for (int k = 0; k < g.K; ++k) {
     const WarpTaps<double>& f = p->fwd_warps[k];
     SpFrame<T>& o = fr[k];
-    o.oy = f.oy; o.ox = f.ox; o.pad0 = o.pad1 = 0;
+    o.oy = f.oy; o.ox = f.ox; o.pad0 = 0;
+    o.rowb = -g.hb + f.oy - sp->RLO;
+    for (int e1 = 0; e1 < 4; ++e1) {
+      const int co = f.ox - g.hb + e1;
+      const int cq = co >= 0 ? co / g.s : -((-co + g.s - 1) / g.s), ph = co - cq * g.s;
+      o.coloff[e1] = ph * sp->XC + (cq - sp->CLO);
+    }
     T w[4];
     for (int t = 0; t < 4; ++t) w[t] = (T)(t < f.ntaps ? f.w[t] : 0.0);
     for (int v = 0; v < 4; ++v) {

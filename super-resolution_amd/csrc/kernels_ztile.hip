@@ -635,7 +635,15 @@ bool ztile_plan(srmap_problem* p) {
           if (w0 == 0.0 && w1 == 0.0) continue;
           const int rr = pr + b.oy + dy;
           if (pmod(rr, S) != 0) continue;
-          ZSrc q; q.k = k; q.io = fdiv(rr, S); q.ox = b.ox; q.pad = 0; q.w0 = w0; q.w1 = w1;
+          ZSrc q; q.k = k; q.io = fdiv(rr, S); q.w0 = w0; q.w1 = w1;
+          const int a = pmod(-b.ox, S);
+          q.q = (b.ox + a) / S;  // exact
+          int em = 0;            // residual columns e = -1, 0, 1 that a cell's S + 2 HB pixels use (z_row_sp2 / sp_apply)
+          for (int e = -1; e <= 1; ++e) {
+            const int p0 = a + S * e, p1 = p0 - 1;
+            if ((p0 >= -g.hb && p0 < S + g.hb) || (p1 >= -g.hb && p1 < S + g.hb)) em |= 0x100 << (e + 1);
+          }
+          q.am = a | em;
           srcs[(size_t)pr].push_back(q);
         }
       }

@@ -83,10 +83,12 @@ struct ZCfg {
 };
 
 // Sub-pixel instances, source-major table: one record per (frame, vertical tap of the transpose warp) that lands on a
-// row phase -- LR row offset io, the frame's integer column offset ox, the two horizontal tap weights (already multiplied
-// by the vertical one).  The residual column q + e a pixel reads and which of the S + 2 HB pixels of a cell it serves
-// follow from ox alone (z_row_sp2).
-struct ZSrc { int k, io, ox, pad; double w0, w1; };
+// row phase -- LR row offset io, the two horizontal tap weights (already multiplied by the vertical one) and what follows
+// from the frame's integer column offset ox alone, worked out on the host (the scalar unit of a CU is shared by its
+// sixteen waves: per-source divisions and range tests there were a fifth of the kernel): a = (-ox) mod S, the residual
+// column offset q = (ox + a) / S of e = 0, the set of columns e in {-1, 0, 1} a cell's S + 2 HB pixels use (bits 8..10
+// of am) (z_row_sp2).
+struct ZSrc { int k, io, q, am; double w0, w1; };
 struct ZEntry { int k, io, jo, oyx; };  // frame, LR row / column offset of the residual a pixel of this phase owns,
                                          // forward offset packed (oy << 16) | (ox & 0xffff)
 
@@ -671,23 +673,18 @@ __device__ __forceinline__ void z_row_sp2(const ArgsT& A, T* __restrict__ zs, in
 #pragma unroll
     for (int c = 0; c < kSpChunk; ++c) {
       const int n = n0 + c;
-      as[c] = -1; jb[c] = 0; w0s[c] = T(0); w1s[c] = T(0);
-#pragma unroll
-      for (int e = 0; e < 3; ++e) rv[c][e] = T(0);
+      // (rv / w0s / w1s of a slot are read only where the same source's am says they were written)
+      as[c] = -1; jb[c] = 0;
       if (n >= ns) continue;                                 // uniform
-      const int k = tab[n].k, io = tab[n].io, ox = tab[n].ox;
+      const int io = tab[n].io, q = tab[n].q, am = tab[n].am;
       const int i = rc + io;
       if (EDGE && (unsigned)i >= (unsigned)A.hl) continue;   // uniform: no such LR row
-      const int a = posmod(-ox, S);
-      const int q = (ox + a) / S;                            // exact: ox + a is a multiple of S
-      as[c] = a; jb[c] = cell0 + q;
+      as[c] = am & 0xff; jb[c] = cell0 + q;
       w0s[c] = (T)tab[n].w0; w1s[c] = (T)tab[n].w1;
-      const T* plane = A.rbuf + (size_t)(k * A.obs_C + ch) * nl + (size_t)i * A.wl;
+      const T* plane = A.rbuf + ((size_t)(tab[n].k * A.obs_C + ch) * nl + (size_t)i * A.wl);
 #pragma unroll
       for (int e = -1; e <= 1; ++e) {
-        const int p0 = a + S * e, p1 = p0 - 1;
-        const bool need = (p0 >= -HB && p0 < S + HB) || (p1 >= -HB && p1 < S + HB);   // uniform
-        if (!need) continue;
+        if (!(am & (0x100 << (e + 1)))) continue;            // uniform: no pixel of the cell uses this column
 #ifdef SRMAP_EXP_SPNOLOAD
         rv[c][e + 1] = (T)(lane + e) * w0s[c];               // TIMING ONLY: no residual request
 #else
