@@ -239,6 +239,93 @@ __global__ __launch_bounds__(256) void k_gather_direct(
   gout[o] = base + out_scale * acc;
 }
 
+// The ring mode of the sub-pixel tile path as its own kernel: the pixels within `ring` of the image edge, the exact
+// per-stage-clipped transpose (the expression of k_gather_direct), for blur sizes <= scale (at most one blur tap per
+// dimension lands on the LR grid) and frames without per-row tables.  64 pixels x 4 frame groups per block: a WAVE is one
+// frame group, so a frame's warp record comes through scalar loads; a thread owns up to FP frames and issues the requests
+// of ALL of them (residual + blur coefficient per warp tap, at clamped addresses, the coefficient masked) before the first
+// multiply-add -- in k_gather_direct every frame was two dependent round trips inside a branchy loop (12.8 us for 57 K
+// pixels at cfg2 geometry).
+template <typename T, int SC, int FP>
+__global__ __launch_bounds__(256) void k_gather_ring(const T* __restrict__ resid, T* __restrict__ gout, Geometry g,
+                                                    const WarpTaps<T>* __restrict__ warps, const T* __restrict__ blur_t,
+                                                    int nk, T out_scale, int ring) {
+  constexpr int gs = SC;
+  __shared__ T part[256];
+  const int lane = threadIdx.x & 63;
+  const int fg = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int c = blockIdx.y;
+  const int N = g.W * g.H, n = g.w * g.h;
+  // thread index -> pixel of the border ring of width `ring`: top band, bottom band, then the left / right strips
+  const int band = ring * g.W, mid = g.H - 2 * ring, t = blockIdx.x * 64 + lane;
+  const bool live = t < 2 * band + 2 * ring * mid;
+  int rr = 0, cc = 0;
+  if (t < band) { rr = t / g.W; cc = t % g.W; }
+  else if (t < 2 * band) { rr = g.H - ring + (t - band) / g.W; cc = (t - band) % g.W; }
+  else if (live) { const int u = t - 2 * band, m = u % (2 * ring); rr = ring + u / (2 * ring); cc = m < ring ? m : g.W - 2 * ring + m; }
+  const int hp = rr * g.W + cc;
+  typedef const WarpTaps<T> __attribute__((address_space(4))) * WP;
+  const size_t o = (size_t)c * N + hp;
+  const T gold = (fg == 0 && live) ? gout[o] : T(0);  // requested with everything else (the launch adds to g)
+  T rv[FP][4], cf[FP][4], wq[FP][4];
+  // ---- every request of this thread's frames ----
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    const int kk = fg + 4 * f;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) { rv[f][tp] = T(0); cf[f][tp] = T(0); wq[f][tp] = T(0); }
+    if (kk >= nk) continue;  // uniform
+    WP wt = (WP)(unsigned long long)(warps + kk);
+    const int oy = wt->oy, ox = wt->ox, nt = wt->ntaps;
+    const T* rk = resid + ((size_t)kk * g.C + c) * n;
+    // row / column part of a tap's index, once per tap row / column: the warped pixel, the blur tap that lands on the LR
+    // grid ((p + a - hb) a multiple of the scale; at most one since b <= scale), the LR index, and whether all of it exists
+    int ia[2], ie[2], li[2], lj[2];
+    bool okr[2], okc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int pr = rr + oy + d, pc = cc + ox + d;
+      int a = (g.hb - pr) % gs, e = (g.hb - pc) % gs;
+      if (a < 0) a += gs;
+      if (e < 0) e += gs;
+      const int R = pr + a - g.hb, Cc = pc + e - g.hb;
+      ia[d] = a; ie[d] = e; li[d] = R / gs; lj[d] = Cc / gs;
+      okr[d] = pr >= 0 && pr < g.H && a < g.b && R >= 0 && R < g.H && li[d] < g.h;
+      okc[d] = pc >= 0 && pc < g.W && e < g.b && Cc >= 0 && Cc < g.W && lj[d] < g.w;
+    }
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+      if (tp >= nt) continue;  // uniform
+      wq[f][tp] = wt->w[tp];
+      const int dy = tp >> 1, dx = tp & 1;
+      const bool ok = live && okr[dy] && okc[dx];
+      const T bt = blur_t[ok ? ia[dy] * g.b + ie[dx] : 0];
+      rv[f][tp] = rk[ok ? li[dy] * g.w + lj[dx] : 0];
+      cf[f][tp] = ok ? bt : T(0);
+    }
+  }
+  // ---- the sums, frame by frame, tap by tap (k_gather_direct's order within a frame) ----
+  T acc = T(0);
+#pragma unroll
+  for (int f = 0; f < FP; ++f) {
+    T tk = T(0);
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+      T v = T(0);
+      v += cf[f][tp] * rv[f][tp];
+      tk += wq[f][tp] * v;
+    }
+    acc += tk;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (fg != 0 || !live) return;
+  acc = part[lane];
+#pragma unroll
+  for (int q = 1; q < 4; ++q) acc += part[lane + q * 64];
+  gout[o] = gold + out_scale * acc;
+}
+
 template <typename T>
 int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, T* g,
                          int k0, int nk, double out_scale, bool accumulate,
@@ -248,6 +335,19 @@ int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, 
   if (ring > 0) {
     if (2 * ring >= geo.H || 2 * ring >= geo.W) ring = 0;
     else npix = 2 * (size_t)ring * geo.W + 2 * (size_t)ring * (geo.H - 2 * ring);
+  }
+  const WarpTaps<T>* wp0 = p->has_motion ? (const WarpTaps<T>*)p->d_bwd_warps : nullptr;
+  if (ring > 0 && accumulate && k0 == 0 && wp0 != nullptr && geo.b <= geo.s && geo.s >= 2 && geo.s <= 4 && nk <= 16 &&
+      p->d_ytabs.empty()) {
+    dim3 grid((unsigned)((npix + 63) / 64), geo.C);
+    const T* bt0 = (const T*)p->d_blur_t;
+#define SRMAP_RING(SS, FF) hipLaunchKernelGGL((k_gather_ring<T, SS, FF>), grid, dim3(256), 0, st, resid, g, geo, wp0, bt0, nk, (T)out_scale, ring)
+#define SRMAP_RING_S(SS) do { if (nk <= 4) SRMAP_RING(SS, 1); else if (nk <= 8) SRMAP_RING(SS, 2); else SRMAP_RING(SS, 4); } while (0)
+    if (geo.s == 2) SRMAP_RING_S(2); else if (geo.s == 3) SRMAP_RING_S(3); else SRMAP_RING_S(4);
+#undef SRMAP_RING_S
+#undef SRMAP_RING
+    SRMAP_HIP(p->ctx, hipGetLastError());
+    return SRMAP_OK;
   }
   int groups = 1;
   while (groups < 16 && groups < nk) groups *= 2;  // thread groups of the ring mode: a power of two, at most 16
