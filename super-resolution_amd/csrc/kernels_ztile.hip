@@ -638,21 +638,18 @@ bool ztile_plan(srmap_problem* p) {
           ZSrc q; q.k = k; q.io = fdiv(rr, S); q.w0 = w0; q.w1 = w1;
           const int a = pmod(-b.ox, S);
           q.q = (b.ox + a) / S;  // exact
-          int em = 0;            // residual columns e = -1, 0, 1 that a cell's S + 2 HB pixels use (z_row_sp2 / sp_apply)
-          for (int e = -1; e <= 1; ++e) {
-            const int p0 = a + S * e, p1 = p0 - 1;
-            if ((p0 >= -g.hb && p0 < S + g.hb) || (p1 >= -g.hb && p1 < S + g.hb)) em |= 0x100 << (e + 1);
-          }
-          q.am = a | em;
+          // the first residual column e in {-1, 0, 1} that a cell's S + 2 HB pixels use (sp_apply derives the same from a)
+          const bool lo = (a - S >= -g.hb) || (a - 1 - S >= -g.hb);
+          q.am = a | ((lo ? 0 : 1) << 8);  // (e_lo + 1) << 8
           srcs[(size_t)pr].push_back(q);
         }
       }
-    int spmax = 1;
-    for (const auto& l : srcs) spmax = std::max(spmax, (int)l.size());
+    int spmax = kSpChunk;
+    for (const auto& l : srcs) spmax = std::max(spmax, (int)((l.size() + kSpChunk - 1) / kSpChunk) * kSpChunk);
     z->spmax = spmax;
-    std::vector<ZSrc> srctab((size_t)S * spmax, ZSrc{0, 0, 0, 0, 0.0, 0.0});
+    std::vector<ZSrc> srctab((size_t)S * spmax, ZSrc{0, 0, 0, kSpNull, 0.0, 0.0});   // null records behind the sources
     for (int pr = 0; pr < S; ++pr) {
-      z->spn[pr] = (int)srcs[(size_t)pr].size();
+      z->spn[pr] = (int)((srcs[(size_t)pr].size() + kSpChunk - 1) / kSpChunk) * kSpChunk;
       for (size_t n = 0; n < srcs[(size_t)pr].size(); ++n) srctab[(size_t)pr * spmax + n] = srcs[(size_t)pr][n];
     }
     int MS = 1;

@@ -86,9 +86,13 @@ struct ZCfg {
 // row phase -- LR row offset io, the two horizontal tap weights (already multiplied by the vertical one) and what follows
 // from the frame's integer column offset ox alone, worked out on the host (the scalar unit of a CU is shared by its
 // sixteen waves: per-source divisions and range tests there were a fifth of the kernel): a = (-ox) mod S, the residual
-// column offset q = (ox + a) / S of e = 0, the set of columns e in {-1, 0, 1} a cell's S + 2 HB pixels use (bits 8..10
-// of am) (z_row_sp2).
+// column offset q = (ox + a) / S of e = 0, and the first of the residual columns e in {-1, 0, 1} a cell's S + 2 HB pixels
+// use (am = a | (e_lo + 1) << 8; the kSpSlots(S, HB) columns from e_lo on are requested unconditionally -- no per-column
+// test on the scalar unit).  Rows of the table are padded to a multiple of kSpChunk with null records (am = kSpNull,
+// weights 0): a chunk's records are loaded back to back without control flow in between (z_row_sp2).
 struct ZSrc { int k, io, q, am; double w0, w1; };
+constexpr int kSpNull = 0xff;
+__host__ __device__ constexpr int kSpSlots(int S, int HB) { return (S == 2 && HB == 1) ? 3 : 2; }
 struct ZEntry { int k, io, jo, oyx; };  // frame, LR row / column offset of the residual a pixel of this phase owns,
                                          // forward offset packed (oy << 16) | (ox & 0xffff)
 
@@ -628,16 +632,23 @@ __device__ __forceinline__ void z_row_sp(const ArgsT& A, T* __restrict__ zs, int
 // row instead of 24 - 30 at cfg2's 16 frames (entry-major rounds are padded to the longest phase).  With
 // a = (-ox) mod S the pixels are pcv = a + S e (dx = 0) and a - 1 + S e (dx = 1), the residual column (ox + a) / S + e,
 // e in {-1, 0, 1}: compile-time pixel indices per value of a (uniform switch).
-// Requests and arithmetic are separated per chunk of kSpChunk sources: all residual requests of the chunk are issued
-// first (which of the three columns e a source needs follows from a with scalar arithmetic), then the multiply-adds run
-// per source with compile-time pixel indices.  (One source at a time left every request's latency exposed: table
-// record -> request -> multiply-add, 8 - 10 times per row.)
+// Requests and arithmetic are separated per chunk of kSpChunk sources: the chunk's table records are loaded back to back,
+// then all its residual requests are issued (uniform frame base + a 32-bit row / column / lane offset), then the
+// multiply-adds run per source with compile-time pixel indices (uniform switch on a).  The scalar unit of a CU is shared
+// by its sixteen waves: the phase clock showed this gather at 8 - 12 K cycles per row while it held one table round trip,
+// a 64-bit address chain and three column tests per source there (profiles/r05_subpixel.txt).
 constexpr int kSpChunk = 4;
 template <typename T, int S, typename C, int A, bool COLCLAMP, typename ArgsT>
-__device__ __forceinline__ void sp_apply(const ArgsT& A_, const T (&rv)[3], int jbase, int lane, T w0, T w1, T (&z)[C::NV]) {
-  constexpr int HB = C::HB;
+__device__ __forceinline__ void sp_apply(const ArgsT& A_, const T (&rv)[kSpSlots(S, C::HB)], int elo, int jbase, int lane,
+                                         T w0, T w1, T (&z)[C::NV]) {
+  constexpr int HB = C::HB, NSL = kSpSlots(S, C::HB);
+  // e_lo as the host derived it for this a (compile-time here): the first column any pixel of the cell uses
+  constexpr int ELO = ((A - S >= -HB) || (A - 1 - S >= -HB)) ? -1 : 0;
+  (void)elo;
 #pragma unroll
-  for (int e = -1; e <= 1; ++e) {
+  for (int sl = 0; sl < NSL; ++sl) {
+    const int e = ELO + sl;
+    if (e > 1) continue;
     const int p0 = A + S * e, p1 = A - 1 + S * e;                 // pixel (relative to the cell) of the dx = 0 / dx = 1 tap
     const bool in0 = p0 >= -HB && p0 < S + HB, in1 = p1 >= -HB && p1 < S + HB;
     if (!in0 && !in1) continue;
@@ -647,52 +658,57 @@ __device__ __forceinline__ void sp_apply(const ArgsT& A_, const T (&rv)[3], int 
       m0 = ok ? w0 : T(0);
       m1 = ok ? w1 : T(0);
     }
-    if (in0) z[(in0 ? p0 : 0) + HB] += m0 * rv[e + 1];
-    if (in1) z[(in1 ? p1 : 0) + HB] += m1 * rv[e + 1];
+    if (in0) z[(in0 ? p0 : 0) + HB] += m0 * rv[sl];
+    if (in1) z[(in1 ? p1 : 0) + HB] += m1 * rv[sl];
   }
 }
 
 template <typename T, int S, int B, typename C, bool EDGE, bool COLCLAMP, typename ArgsT>
 __device__ __forceinline__ void z_row_sp2(const ArgsT& A, T* __restrict__ zs, int rowrel, int R0, int cell0, int lane, int ch,
                                           T (&zout)[S]) {
-  constexpr int HB = C::HB, NV = C::NV;
+  constexpr int HB = C::HB, NV = C::NV, NSL = kSpSlots(S, C::HB);
   int rc, pr;
   row_phase<S>(R0 + rowrel, rc, pr);
   const size_t nl = (size_t)A.wl * A.hl;
-  const int ns = A.spn[pr];
+  const int ns = A.spn[pr];   // a multiple of kSpChunk (null records behind the last source)
   T z[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) z[v] = T(0);
   typedef const ZSrc __attribute__((address_space(4))) * SrcPtr;
   SrcPtr tab = (SrcPtr)(unsigned long long)(A.spsrc + (size_t)pr * A.spmax);
   for (int n0 = 0; n0 < ns; n0 += kSpChunk) {
-    T rv[kSpChunk][3];
-    T w0s[kSpChunk], w1s[kSpChunk];
-    int as[kSpChunk], jb[kSpChunk];
-    // ---- requests of the chunk ----
+    // ---- the chunk's records (scalar loads, no control flow in between) ----
+    int rk[kSpChunk], rio[kSpChunk], rq[kSpChunk], ram[kSpChunk];
+    double rw0[kSpChunk], rw1[kSpChunk];
 #pragma unroll
     for (int c = 0; c < kSpChunk; ++c) {
-      const int n = n0 + c;
-      // (rv / w0s / w1s of a slot are read only where the same source's am says they were written)
-      as[c] = -1; jb[c] = 0;
-      if (n >= ns) continue;                                 // uniform
-      const int io = tab[n].io, q = tab[n].q, am = tab[n].am;
-      const int i = rc + io;
-      if (EDGE && (unsigned)i >= (unsigned)A.hl) continue;   // uniform: no such LR row
-      as[c] = am & 0xff; jb[c] = cell0 + q;
-      w0s[c] = (T)tab[n].w0; w1s[c] = (T)tab[n].w1;
-      const T* plane = A.rbuf + ((size_t)(tab[n].k * A.obs_C + ch) * nl + (size_t)i * A.wl);
+      rk[c] = tab[n0 + c].k; rio[c] = tab[n0 + c].io; rq[c] = tab[n0 + c].q; ram[c] = tab[n0 + c].am;
+      rw0[c] = tab[n0 + c].w0; rw1[c] = tab[n0 + c].w1;
+    }
+    // ---- requests of the chunk ----
+    T rv[kSpChunk][NSL];
+    int as[kSpChunk], jb[kSpChunk];
 #pragma unroll
-      for (int e = -1; e <= 1; ++e) {
-        if (!(am & (0x100 << (e + 1)))) continue;            // uniform: no pixel of the cell uses this column
+    for (int c = 0; c < kSpChunk; ++c) {
+      const int i = rc + rio[c];
+      as[c] = ram[c] & 0xff;
+      if (EDGE && (unsigned)i >= (unsigned)A.hl) as[c] = kSpNull;   // uniform: no such LR row
+      jb[c] = cell0 + rq[c];
+      const int elo = (ram[c] >> 8) - 1;
+      // null records (and rows outside the image) request the frame's element 0: harmless, never used
+      const bool live = as[c] != kSpNull;
+      const T* base = A.rbuf + (size_t)((live ? rk[c] : 0) * A.obs_C + ch) * nl;   // uniform
+      const unsigned rowoff = live ? (unsigned)i * (unsigned)A.wl : 0u;
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) {
 #ifdef SRMAP_EXP_SPNOLOAD
-        rv[c][e + 1] = (T)(lane + e) * w0s[c];               // TIMING ONLY: no residual request
+        rv[c][sl] = (T)(lane + sl) * (T)rw0[c];                 // TIMING ONLY: no residual request
 #else
         if (!COLCLAMP) {
-          rv[c][e + 1] = (plane + (jb[c] + e))[(unsigned)lane];   // uniform base + lane
+          rv[c][sl] = base[rowoff + (unsigned)(live ? jb[c] + elo + sl + lane : 0)];
         } else {
-          const int j = jb[c] + lane + e;
-          rv[c][e + 1] = plane[j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j)];
+          const int j = jb[c] + lane + elo + sl;
+          rv[c][sl] = base[rowoff + (unsigned)(live ? (j < 0 ? 0 : (j >= A.wl ? A.wl - 1 : j)) : 0)];
         }
 #endif
       }
@@ -701,11 +717,12 @@ __device__ __forceinline__ void z_row_sp2(const ArgsT& A, T* __restrict__ zs, in
 #pragma unroll
     for (int c = 0; c < kSpChunk; ++c) {
       const int a = as[c];
-      if (a < 0) continue;                                   // uniform
-      if (a == 0) sp_apply<T, S, C, 0, COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
-      else if (a == 1) sp_apply<T, S, C, 1, COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
-      else if (a == 2) sp_apply<T, S, C, (S > 2 ? 2 : 0), COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
-      else sp_apply<T, S, C, (S > 3 ? 3 : 0), COLCLAMP>(A, rv[c], jb[c], lane, w0s[c], w1s[c], z);
+      const int elo = (ram[c] >> 8) - 1;
+      const T w0 = (T)rw0[c], w1 = (T)rw1[c];
+      if (a == 0) sp_apply<T, S, C, 0, COLCLAMP>(A, rv[c], elo, jb[c], lane, w0, w1, z);
+      else if (a == 1) sp_apply<T, S, C, 1, COLCLAMP>(A, rv[c], elo, jb[c], lane, w0, w1, z);
+      else if (a == 2) sp_apply<T, S, C, (S > 2 ? 2 : 0), COLCLAMP>(A, rv[c], elo, jb[c], lane, w0, w1, z);
+      else if (a == 3) sp_apply<T, S, C, (S > 3 ? 3 : 0), COLCLAMP>(A, rv[c], elo, jb[c], lane, w0, w1, z);
     }
   }
   if (B == 1) {

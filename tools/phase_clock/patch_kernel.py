@@ -42,8 +42,11 @@ rep('''  __syncthreads();
 rep('''  // ---------------- cost partial of this workgroup ----------------''','''  ZT_STAMP(9);
   if (dbg && lane == 0) { for (int q = 0; q < 10; ++q) dbg[q] = zts[q]; dbg[10] = rt0; dbg[11] = wall_clock64(); dbg[12] = ((unsigned long long)xccid << 32) | hwid; }
   // ---------------- cost partial of this workgroup ----------------''')
-rep('''    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);''','''    const unsigned long long brt0 = wall_clock64();
-    if (bidx * C::NT < Bd.n_ring) border_block<T, S, B, C::NT, WD>(A, Bd, bidx, blockIdx.z, xs, A.nby * gridDim.x);
-    if (g_ztdbg && threadIdx.x == 0) { unsigned long long* d = g_ztdbg + ((size_t)(2048 + bidx) * 8) * 16; d[10] = brt0; d[11] = wall_clock64(); d[12] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); d[13] = (bidx * C::NT < Bd.n_ring); }''')
+rep('''    if (bidx * C::NT < Bd.n_ring) {''','''    const unsigned long long brt0 = wall_clock64();
+    if (bidx * C::NT < Bd.n_ring) {''')
+rep('''    else if (threadIdx.x == 0) {
+      const int nbb = A.nby * gridDim.x;''','''    if (g_ztdbg && threadIdx.x == 0) { unsigned long long* d = g_ztdbg + ((size_t)(2048 + bidx) * 8) * 16; d[10] = brt0; d[11] = wall_clock64(); d[12] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); d[13] = (bidx * C::NT < Bd.n_ring); }
+    if (!(bidx * C::NT < Bd.n_ring) && threadIdx.x == 0) {
+      const int nbb = A.nby * gridDim.x;''')
 rep('// ---------------------------------------------------------------------------------------------------------\n// host side: plan','extern "C" int srmap_dbg_set_timing(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ztdbg), &buf, sizeof(buf)); }\n// ---------------------------------------------------------------------------------------------------------\n// host side: plan')
 open('/tmp/spx/kz_time.hip','w').write(s)

@@ -8,7 +8,11 @@ sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd", "python"))
 import srmap
 srmap.LIB_PATH = os.path.join(ROOT, "tools", "phase_clock", "libsrmap_time.so")
 W = 2048; s, K = 4, 16
+SUBPIX = "--subpixel" in sys.argv   # the sub-pixel instance k_eval_z<...,SP> (tools/subpixel_timing.py's shifts)
 shifts = [[k % s, (k // s) % s] for k in range(K)]
+if SUBPIX:
+    rng = np.random.default_rng(5)
+    shifts = [[k % s + float(np.round(rng.uniform(-.5, .5) * 32) / 32), (k // s) % s + float(np.round(rng.uniform(-.5, .5) * 32) / 32)] for k in range(K)]
 ctx = srmap.Context(0)
 p = srmap.Problem(ctx, W, W, 1, K, s, shifts, 3, 1.0, srmap.F64)
 y = torch.rand((K, 1, W // s, W // s), dtype=torch.float64, device="cuda")
