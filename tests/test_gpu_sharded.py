@@ -47,7 +47,7 @@ def test_two_ranks_on_one_gpu(tmp_path, mode, backend):
     logs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=600)
+            o, _ = p.communicate(timeout=300)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -78,7 +78,7 @@ def test_bench_spawns_its_ranks(shard, how):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     rccl = how == "--test-rccl-loopback"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", how, "--steps", "5",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", how, "--watchdog-s", "240", "--steps", "5",
                         "--warmup", "2", "--clock-ramp-ms", "0", "--min-timed-ms", "0", "--hr", "512", "--shard", shard],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     if rccl and r.returncode != 0 and r.stderr.count("RCCL communicator up") < 2:
