@@ -223,6 +223,10 @@ SUBPIX_CASES = [
     (90, 72, 2, 3, [[0.75, -0.5], [1, 1], [-2.25, 0.125]], 0, 0.0),
     (70, 66, 1, 2, [[0.5, 0.5], [-0.5, 1.5], [1.25, -1.75], [0, 0]], 3, 0.7),
     (84, 64, 1, 4, [[0.4, -0.6], [1.9, 0.2]], 3, 1.2),
+    # 7 and 13 frames: two / four frames per thread of the ring kernel (k_gather_ring), chunks of the source-major tap
+    # table with null records behind the last source
+    (96, 72, 1, 4, [[0.25 * k - 0.8, 1.1 - 0.35 * k] for k in range(7)], 3, 1.0),
+    (81, 75, 1, 3, [[0.3 * k - 1.9, 0.21 * k - 1.3] for k in range(13)], 0, 0.0),
 ]
 
 
