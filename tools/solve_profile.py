@@ -14,10 +14,14 @@ def main():
     ap.add_argument("--dtype", default="f64"); ap.add_argument("--hr", type=int, default=2048)
     ap.add_argument("--irls", type=int, default=2); ap.add_argument("--cg", type=int, default=20)
     ap.add_argument("--host-paced", action="store_true", help="srmap_irls_options.host_paced_passes = 1 (every CG pass waits for the host)")
+    ap.add_argument("--subpixel", action="store_true", help="random 1/32-px sub-pixel shifts (the registered-data case) instead of integer ones")
     a = ap.parse_args()
     S, K, W = 4, 16, a.hr
     gt = bench.synth_ground_truth(W, W, 1)
     shifts = [(k % S, (k // S) % S) for k in range(K)]
+    if a.subpixel:
+        r5 = np.random.default_rng(5)
+        shifts = [(k % S + float(np.round(r5.uniform(-.5, .5) * 32) / 32), (k // S) % S + float(np.round(r5.uniform(-.5, .5) * 32) / 32)) for k in range(K)]
     ctx = srmap.Context(0)
     prob = srmap.Problem(ctx, W, W, 1, K, S, shifts, 3, 1.0, srmap.F64 if a.dtype == "f64" else srmap.F32)
     rng = np.random.default_rng(777)
