@@ -74,6 +74,30 @@
 #ifndef SRMAP_EXP_SPOLD
 #define SRMAP_EXP_SPOLD 0
 #endif
+//   SRMAP_EXP_F64_WPE   f64 S > 2 instances: waves per SIMD of __launch_bounds__ (product: 4)
+//   SRMAP_EXP_ALIAS_ZC  TIMING ONLY: zh and 2*lambda*w*r share one LDS array (what a three-phase tile would allocate)
+#ifndef SRMAP_EXP_F64_WPE
+#define SRMAP_EXP_F64_WPE 4
+#endif
+#ifndef SRMAP_EXP_ALIAS_ZC
+#define SRMAP_EXP_ALIAS_ZC 0
+#endif
+//   SRMAP_EXP_LDS_PAD   TIMING ONLY: extra bytes of (dynamic) LDS per workgroup (fewer resident workgroups, same instruction stream)
+#ifndef SRMAP_EXP_LDS_PAD
+#define SRMAP_EXP_LDS_PAD 0
+#endif
+//   SRMAP_EXP_REGFIRST  phase 1: regulariser pass before the data term (the observations get a pass longer to arrive)
+//   SRMAP_EXP_NTLOAD    observations and IRLS weights requested with non-temporal loads (streamed once)
+//   SRMAP_EXP_HEADPRIO  s_setprio 3 from the start of a tile workgroup until its requests are issued
+#ifndef SRMAP_EXP_REGFIRST
+#define SRMAP_EXP_REGFIRST 0
+#endif
+#ifndef SRMAP_EXP_NTLOAD
+#define SRMAP_EXP_NTLOAD 0
+#endif
+#ifndef SRMAP_EXP_HEADPRIO
+#define SRMAP_EXP_HEADPRIO 0
+#endif
 #ifndef SRMAP_EXP_NOLOAD
 #define SRMAP_EXP_NOLOAD 0
 #endif
@@ -86,15 +110,21 @@ namespace srmap {
 namespace {
 
 template <typename T, int S, int B, int REGK, int R, bool WD, bool SP>
-__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRMAP_EXP_F32_WPE : (S == 2 ? 6 : 4))) void k_eval_z(
+__global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRMAP_EXP_F32_WPE : (S == 2 ? 6 : SRMAP_EXP_F64_WPE))) void k_eval_z(
     ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP> A) {
   using C = ZCfg<T, S, B, REGK, R>;
   constexpr int HB = C::HB, NV = C::NV, RU = C::RU;
   // border blocks borrow the x tile's LDS for the frame table
   constexpr int kBorderLds = (int)((16 * sizeof(int2) + kBorderTabEntries * sizeof(ZEntry) + 16 * sizeof(double) + sizeof(T) - 1) / sizeof(T));
   __shared__ T xs[C::XS_ELEMS > kBorderLds ? C::XS_ELEMS : kBorderLds];
+#if SRMAP_EXP_ALIAS_ZC
+  __shared__ T zcs[C::ZS_ELEMS > C::CS_ELEMS ? C::ZS_ELEMS : (C::CS_ELEMS > 0 ? C::CS_ELEMS : 1)];
+  T* const zs = zcs;
+  T* const cs = zcs;
+#else
   __shared__ T zs[C::ZS_ELEMS > 0 ? C::ZS_ELEMS : 1];
   __shared__ T cs[C::CS_ELEMS > 0 ? C::CS_ELEMS : 1];
+#endif
   __shared__ double red[2][C::NW];
   __shared__ T wcs[32];  // IRLS weights of the left-halo-column pixels (two columns x up to 16 rows)
   __shared__ T whs[(C::RU > 0 ? C::RU : 1) * S * C::CW];  // IRLS weights of the halo rows of 2*lambda*w*r
@@ -152,6 +182,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
     tbx = (by == 0) ? 0 : (by == 1 ? nby_t - 1 : by - 1);
   }
   if (A.sel_mode != 0 && ((A.sel_mode == 1) != (tby >= A.sel0 && tby < A.sel1))) return;  // uniform; before any barrier
+  if (SRMAP_EXP_HEADPRIO) __builtin_amdgcn_s_setprio(3);
   const int R0 = tby * C::TH, CJ0 = tbx * C::CW, C0 = CJ0 * S;
   const int ch = blockIdx.z;
   const size_t N = (size_t)A.W * A.H;
@@ -249,7 +280,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
     for (int pc = 0; pc < S; ++pc) wreg[pc] = (T)(lane + 2 * pc + 1) * A.lambda;
   } else if (wplane != nullptr && gr < A.H && gc0 < A.W) {
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) wreg[pc] = wplane[(size_t)gr * A.W + gc0 + pc];
+    for (int pc = 0; pc < S; ++pc) wreg[pc] = SRMAP_EXP_NTLOAD ? __builtin_nontemporal_load(&wplane[(size_t)gr * A.W + gc0 + pc]) : wplane[(size_t)gr * A.W + gc0 + pc];
   }
   // halo row of 2*lambda*w*r this wave evaluates (waves 2 .. 2+RU-1: tile rows -1 .. -RU) and its weights
   const bool reg_halo_on = !SRMAP_EXP_NOHALO && want_reg && A.g != nullptr && RU > 0;
@@ -295,6 +326,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
       }
     }
   }
+  if (SRMAP_EXP_HEADPRIO) __builtin_amdgcn_s_setprio(0);
   // ---------------- x tile -> LDS, polyphase ----------------
 #pragma unroll
   for (int it = 0; it < ARI; ++it) {
@@ -335,6 +367,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
   double cost_data = 0.0, cost_reg = 0.0;
 
   // ---------------- phase 1: data term ----------------
+  auto phase1_data = [&]() __attribute__((always_inline)) {
   if (SP && want_data) {
     T dummy[S];
     // table rows reach (Dr + S) / S LR rows around the tile's own: only the top / bottom tile rows can leave the image
@@ -370,6 +403,8 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
       if (has_z_halo) z_row<T, S, B, C, false>(A, xs, zs, hrowz, R0, CJ0, lane, ybase, true, ypre2, false, mk, dummy, dcost);
     }
   }
+  };
+  if (!SRMAP_EXP_REGFIRST) phase1_data();
   // ---------------- phase 1: regulariser ----------------
   if (want_reg) {
     const bool reg_border = (R0 + C::TH + C::WIN > A.H) || (C0 + C::TW + C::WIN > A.W);
@@ -406,6 +441,7 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
       }
     }
   }
+  if (SRMAP_EXP_REGFIRST) phase1_data();
   __syncthreads();
 
   // ---------------- phase 2 ----------------
@@ -883,18 +919,18 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   if (border_only >= 0) {
     *nblocks = nbb * (int)grid.z;
     if (nbb == 0) return SRMAP_OK;
-    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
+    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
     SRMAP_HIP(p->ctx, hipGetLastError());
     return SRMAP_OK;
   }
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
     A.rbuf = (const T*)p->d_resid;
     A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
-    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), 0, st, A);
+    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
   } else {
     auto launch = [&]() {
-      if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), 0, st, A);
-      else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), 0, st, A);
+      if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
+      else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
     };
     if (p->ov_hook != nullptr) {
       // Row shard: a tile row [8 t, 8 t + 8) reads x rows within the halo width of itself, so the tile rows t with

@@ -52,7 +52,10 @@ __device__ __forceinline__ double absv<double>(double d) { return __builtin_fabs
 constexpr int zmax(int a, int b) { return a > b ? a : b; }
 constexpr int zceil(int a, int b) { return (a + b - 1) / b; }
 
-template <typename T, int S, int B, int REGK, int R, int NW_ = 8>
+#ifndef SRMAP_ZT_NW
+#define SRMAP_ZT_NW 8   // measurement builds: waves (= HR rows) per tile workgroup
+#endif
+template <typename T, int S, int B, int REGK, int R, int NW_ = SRMAP_ZT_NW>
 struct ZCfg {
   static constexpr int NW = NW_;               // waves = HR rows per tile
   static constexpr int NT = 64 * NW;
@@ -422,7 +425,11 @@ __device__ __forceinline__ void load_obs_row(const ArgsT& A, int pr, int rc, int
     for (int v = 0; v < NV; ++v) {
       const int pcv = v - HB, pc = posmod(pcv, S), dc = floordiv(pcv, S);
       const T* yp = yrow + (offs[pc] + dc);  // uniform pointer; the lane adds its (non-negative) cell index
+#if defined(SRMAP_EXP_NTLOAD) && SRMAP_EXP_NTLOAD
+      yv[v] = __builtin_nontemporal_load(&yp[(unsigned)lane]);
+#else
       yv[v] = yp[(unsigned)lane];
+#endif
     }
     return;
   }

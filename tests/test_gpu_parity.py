@@ -19,9 +19,7 @@ pytestmark = pytest.mark.gpu
 TOL = {0: 1e-12, 1: 2e-5}
 
 
-def relerr(a, ref):
-    a, ref = np.asarray(a, dtype=float).ravel(), np.asarray(ref, dtype=float).ravel()
-    return float(np.max(np.abs(a - ref) / np.maximum(1.0, np.abs(ref)))) if a.size else 0.0
+from parity_log import relerr  # noqa: E402  (max |a - ref| / max(1, |ref|), logged when SRMAP_PARITY_LOG is set)
 
 
 @pytest.fixture(scope="module")
