@@ -222,9 +222,8 @@ def main():
                     help="N > 1: rows = HR row bands + halo exchange of x (default, strong scaling; the frame variant is timed "
                          "in the same run); frames = only the frame variant; channels = N independent channels, no "
                          "collective (weak scaling, the reference's split_channels semantics)")
-    ap.add_argument("--impl", choices=["auto", "direct", "tiled", "march"], default="auto",
-                    help="auto = the library's choice (the 8-row tile kernel where it covers the problem); march = the marching kernel "
-                         "(kernels_zmarch.hip; opt-in, profiles/r05_march.txt)")
+    ap.add_argument("--impl", choices=["auto", "direct", "tiled"], default="auto",
+                    help="auto = the library's choice (the 8-row tile kernel where it covers the problem)")
     ap.add_argument("--hr", type=int, default=0, help="override the HR size of the configuration (testing)")
     ap.add_argument("--terms", choices=["all", "data", "reg"], default="all",
                     help="ablation only: evaluate a subset of the objective terms")
@@ -304,7 +303,7 @@ def main():
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     E = 8 if args.dtype == "f64" else 4
     terms = {"all": srmap.TERM_ALL, "data": srmap.TERM_DATA, "reg": srmap.TERM_REG}[args.terms]
-    impl = {"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED, "march": srmap.IMPL_MARCH}[args.impl]
+    impl = {"auto": srmap.IMPL_AUTO, "direct": srmap.IMPL_DIRECT, "tiled": srmap.IMPL_TILED}[args.impl]
     ctx = srmap.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
     sh = stream.cuda_stream

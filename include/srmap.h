@@ -95,12 +95,11 @@ enum {
  * workgroup-tile kernels whenever the problem geometry admits them (scale
  * 2..4, blur size 1 or 3, integer or sub-pixel shifts), else the direct
  * kernels.  TILED forces that family and fails with SRMAP_EUNSUPPORTED when it
- * does not cover the problem.  MARCH asks for the marching evaluation kernel
- * (one resident workgroup per CU walking a band of rows; scale 4, blur 3, one
- * frame per pixel phase, BTV range 3, width a multiple of 256): bit-equal to
- * the tiles, not faster on gfx950 (profiles/r05_march.txt), never chosen by
- * AUTO, SRMAP_EUNSUPPORTED outside its geometry. */
-typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2, SRMAP_IMPL_MARCH = 3 } srmap_impl;
+ * does not cover the problem.  (Value 3 was round 5's marching evaluation
+ * kernel: bit-equal to the tiles, not faster on gfx950 -- profiles/r05_march.txt
+ * -- and removed from the library in round 6; srmap_problem_set_impl answers
+ * SRMAP_EINVAL for it.) */
+typedef enum { SRMAP_IMPL_AUTO = 0, SRMAP_IMPL_DIRECT = 1, SRMAP_IMPL_TILED = 2 } srmap_impl;
 
 /* ---------------------------------------------------------------- context */
 /* Binds HIP device `device_id`.  Replaces nothing in the reference (it has no
@@ -280,6 +279,10 @@ int srmap_register_translational_ex(srmap_ctx* ctx, int num_images, int width, i
  * (alglib_objective.cpp:47-75); L-BFGS / numeric differentiation are test-only
  * alternatives in the reference and are out of scope. */
 typedef struct {
+  int struct_size;                       /* sizeof(srmap_irls_options) of the header the caller was built with: filled by
+                                            srmap_irls_options_default(); srmap_solve answers SRMAP_EINVAL when it is
+                                            not this library's (a caller built against another version of this header
+                                            would otherwise have its fields read at the wrong offsets) */
   int max_num_solver_iterations;         /* 50 */
   double gradient_norm_threshold;        /* 1e-6 */
   double cost_decrease_threshold;        /* 1e-6 */

@@ -104,6 +104,11 @@
 #ifndef SRMAP_EXP_NOHALO
 #define SRMAP_EXP_NOHALO 0
 #endif
+// The TIMING-ONLY switches produce wrong results by construction: a build that sets one has to say that it is a
+// measurement build (tools/exp_build.sh, tools/full_build.sh and tools/phase_clock/build.sh define it; the product build does not).
+#if (SRMAP_EXP_NOLOAD || SRMAP_EXP_NOHALO || SRMAP_EXP_ALIAS_ZC || SRMAP_EXP_LDS_PAD || defined(SRMAP_EXP_SPNOLOAD)) && !defined(SRMAP_MEASUREMENT_BUILD)
+#error "SRMAP_EXP_NOLOAD / NOHALO / ALIAS_ZC / LDS_PAD / SPNOLOAD are timing-only switches: define SRMAP_MEASUREMENT_BUILD (tools/exp_build.sh)"
+#endif
 
 namespace srmap {
 
@@ -856,33 +861,42 @@ bool ztile_reg_band_ok(const srmap_problem* p, unsigned terms) {
   return active == 1;
 }
 
+// Upper bound of the cost partials one tile launch over C channels produces (tiles + border blocks, which fill whole
+// grid rows) -- ONE definition for the granule allocation, the launch and the solver's decisions.
+static size_t ztile_est_partials(const ZPlan* z, int w, int H, int C) {
+  const size_t tiles = (size_t)((w + 63) / 64) * ((H + 7) / 8) * C;
+  const size_t ring = (z && z->n_ring > 0) ? (size_t)((z->n_ring + 511) / 512 + (H + 7) / 8) * C : (size_t)0;
+  return tiles + ring;
+}
+
+// Whether the tile launch of an evaluation with `terms` over C channels is the g.d instance (k_eval_z<..., WD>): it must
+// produce the WHOLE gradient (no further regulariser kernel behind it) and few enough partials for its in-kernel
+// reduction.  launch_eval_ztile asks it for the launch, ztile_can_fold for the solver (a folded trial point exists only
+// inside that instance): the two cannot drift apart.
+static bool ztile_gd_instance_ok(const srmap_problem* p, const ZPlan& z, int w, int H, int C, unsigned terms) {
+  if (z.subpix) return false;
+  if (terms & SRMAP_TERM_REG)
+    for (int r = 0; r < p->nreg; ++r)
+      if (!(z.regk != 0 && r == z.reg_index) && p->reg[r].lambda > 0.0) return false;
+  return ztile_est_partials(&z, w, H, C) <= kMaxFusedPartials;
+}
+
 bool ztile_can_fold(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
-  if (!z || z->subpix || p->impl == SRMAP_IMPL_DIRECT || p->impl == SRMAP_IMPL_MARCH || p->ov_hook != nullptr) return false;
-  for (int r = 0; r < p->nreg; ++r)   // as launch_eval_ztile's `more_regs`: the tile launch must produce the whole gradient
-    if (!(z->regk != 0 && r == z->reg_index) && p->reg[r].lambda > 0.0) return false;
+  if (!z || p->impl == SRMAP_IMPL_DIRECT || p->ov_hook != nullptr) return false;
   const Geometry& g = p->geo;
-  const int C = p->view_C > 0 ? p->view_C : g.C;
-  const size_t est_parts = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * C +
-                           (z->n_ring > 0 ? (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * C : (size_t)0);
-  return est_parts <= kMaxFusedPartials;
+  return ztile_gd_instance_ok(p, *z, g.w, g.H, p->view_C > 0 ? p->view_C : g.C, SRMAP_TERM_ALL);
 }
 
 size_t ztile_partials_needed(const srmap_problem* p) {
   const Geometry& g = p->geo;
-  const size_t tiles = (size_t)((g.w + 63) / 64) * ((g.H + 7) / 8) * g.C;
-  const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
-  size_t ring = 0;
-  if (z && z->n_ring > 0) ring = (size_t)((z->n_ring + 511) / 512 + (g.H + 7) / 8) * g.C;  // border blocks fill whole grid rows
-  return tiles + ring;
+  return ztile_est_partials(static_cast<const ZPlan*>(p->zplan), g.w, g.H, g.C);
 }
 
 template <typename T, int S, int B, int REGK, int R>
 static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                     const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st, const T* dvec,
-                    double* partials_gd, MFin mfin, int border_only = -1) {
-  // border_only >= 0: launch the border blocks alone (the marching kernel evaluates the image; its workgroups hold the
-  // first `border_only` partials)
+                    double* partials_gd, MFin mfin) {
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
   fill_zargs<T, S, B, REGK, R>(A, p, geo, obs_c0, terms, x, g, wts, z, partials, dvec, partials_gd);
@@ -892,8 +906,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
-  const int n_tile_partials = border_only >= 0 ? border_only : (int)(grid.x * grid.y * grid.z);
-  if (border_only >= 0) grid.y = 0;
+  const int n_tile_partials = (int)(grid.x * grid.y * grid.z);
   // border blocks: whole rows of the grid in front of the tiles
   A.bd = (const BorderArgs<T>*)z.d_bd;
   A.nby = 0; A.n_tile_partials = n_tile_partials;
@@ -916,13 +929,6 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.xpart = mfin.xpart; A.n_xpart = mfin.n_xpart;
   if (mfin.on && (size_t)A.n_partials > z.mpart_cap) return set_error(p->ctx, SRMAP_EHIP, "granule capacity");
   A.sel_mode = 0; A.sel0 = 0; A.sel1 = 0;
-  if (border_only >= 0) {
-    *nblocks = nbb * (int)grid.z;
-    if (nbb == 0) return SRMAP_OK;
-    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, false>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
-    SRMAP_HIP(p->ctx, hipGetLastError());
-    return SRMAP_OK;
-  }
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
     A.rbuf = (const T*)p->d_resid;
     A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
@@ -996,12 +1002,12 @@ void ztile_preload(const srmap_problem* p) {
 template <typename T, int S, int B>
 static int dispatch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                       const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, hipStream_t st,
-                      const T* dv, double* pgd, MFin mfin, int border_only = -1) {
-  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
-  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
-  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
-  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
-  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, border_only);
+                      const T* dv, double* pgd, MFin mfin) {
+  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
 }
 
 template <typename T>
@@ -1029,10 +1035,9 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (want_reg)
     for (int r = 0; r < p->nreg; ++r)
       if (!(regk && r == z.reg_index) && p->reg[r].lambda > 0.0) more_regs = true;
-  const size_t est_parts = (size_t)((geo.w + 63) / 64) * ((geo.H + 7) / 8) * geo.C +
-                           (z.n_ring > 0 ? (size_t)((z.n_ring + 511) / 512 + (geo.H + 7) / 8) * geo.C : (size_t)0);  // as ztile_partials_needed
+  const size_t est_parts = ztile_est_partials(&z, geo.w, geo.H, geo.C);
   const bool sp_data = z.subpix && (terms & SRMAP_TERM_DATA);
-  const bool with_d = p->eval_dvec != nullptr && g != nullptr && !more_regs && est_parts <= kMaxFusedPartials && !z.subpix;
+  const bool with_d = p->eval_dvec != nullptr && g != nullptr && ztile_gd_instance_ok(p, z, geo.w, geo.H, geo.C, terms);
   int nfwd = 0;
   if (sp_data) {
     // sub-pixel shifts: exact residuals (and the data cost) from the direct forward kernel, then the tile kernel
@@ -1045,7 +1050,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     if (rc) return rc;
     partials += nfwd;
   }
-  if (p->eval_fold_xk != nullptr && !(with_d && p->impl != SRMAP_IMPL_MARCH && p->ov_hook == nullptr))
+  if (p->eval_fold_xk != nullptr && !(with_d && p->ov_hook == nullptr))
     return set_error(p->ctx, SRMAP_EINVAL, "internal: a folded trial point needs the tile kernel's g.d instance (ztile_can_fold)");
   const T* dv = with_d ? (const T*)p->eval_dvec : nullptr;
   double* pgd = with_d ? p->d_partials + p->partials_cap / 2 : nullptr;
@@ -1061,32 +1066,24 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   mfin.publish = mfin.on && with_d && p->eval_pub != nullptr;
   mfin.xpart = (mfin.on && sp_data) ? partials - nfwd : nullptr;
   mfin.n_xpart = (mfin.on && sp_data) ? nfwd : 0;
-  // the marching kernel (kernels_zmarch.hip) where it covers the evaluation; SRMAP_IMPL_TILED keeps the 8-row tiles
-  int m_ns = 0, m_rows = 0;
-  const bool march = p->impl == SRMAP_IMPL_MARCH && zmarch_covers<T>(p, geo, z, z.regk, z.regr, zterms, g, dv, &m_ns, &m_rows);  // one instance per plan: the terms are run-time switches
-  if (p->impl == SRMAP_IMPL_MARCH && !march) return set_error(p->ctx, SRMAP_EUNSUPPORTED, "the marching kernel does not cover this evaluation");
-  auto tiles = [&](int border_only) {
+  auto tiles = [&]() {
 #ifdef SRMAP_ZT_ONLY_CFG2
     if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == 3 && regk == 2 && regr == 3)
       return launch_z<SRMAP_ZT_ONLY_T, 4, 3, 2, 3>(p, geo, obs_c0, zterms, (const SRMAP_ZT_ONLY_T*)x, (SRMAP_ZT_ONLY_T*)g,
                                                    (const SRMAP_ZT_ONLY_T*)wts, z, partials, &nb, st, (const SRMAP_ZT_ONLY_T*)dv, pgd,
-                                                   mfin, border_only);
+                                                   mfin);
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "measurement build: cfg2 instance only");
 #else
-    if (S == 2 && B == 1) return dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
-    if (S == 2 && B == 3) return dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
-    if (S == 3 && B == 1) return dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
-    if (S == 3 && B == 3) return dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
-    if (S == 4 && B == 1) return dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
-    if (S == 4 && B == 3) return dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, border_only);
+    if (S == 2 && B == 1) return dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+    if (S == 2 && B == 3) return dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+    if (S == 3 && B == 1) return dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+    if (S == 3 && B == 3) return dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+    if (S == 4 && B == 1) return dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+    if (S == 4 && B == 3) return dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
 #endif
   };
-  if (march) {  // border tasks (ownerless residuals) ride inside the marching workgroups' prologue
-    rc = launch_zmarch<T>(p, geo, obs_c0, zterms, x, g, wts, z, z.regk, z.regr, partials, &nb, st, mfin, m_ns, m_rows, 0);
-  } else {
-    rc = tiles(-1);
-  }
+  rc = tiles();
   if (rc) return rc;
   if (sp_data) {
     partials -= nfwd;

@@ -255,7 +255,7 @@ static int eval_typed(srmap_problem* p, unsigned terms, const T* x, T* g, hipStr
     if (rc) return rc;
     SRMAP_HIP(p->ctx, hipStreamWaitEvent(st, p->ov_event, 0));
   }
-  if ((p->impl == SRMAP_IMPL_TILED || p->impl == SRMAP_IMPL_MARCH) && !ztile)
+  if (p->impl == SRMAP_IMPL_TILED && !ztile)
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "tiled kernels do not cover this geometry");
   int nparts = 0;
   if (ztile) {
@@ -525,7 +525,7 @@ void srmap_problem_destroy(srmap_problem* p) {
 
 int srmap_problem_set_impl(srmap_problem* p, int impl) {
   if (!p) return SRMAP_EINVAL;
-  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_MARCH) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
+  if (impl < SRMAP_IMPL_AUTO || impl > SRMAP_IMPL_TILED) return set_error(p->ctx, SRMAP_EINVAL, "bad impl");
   p->impl = impl;
   p->plan_gen++;
   return SRMAP_OK;
@@ -831,6 +831,7 @@ int srmap_synchronize(srmap_ctx* ctx) {
 
 void srmap_irls_options_default(srmap_irls_options* o) {
   if (!o) return;
+  o->struct_size = (int)sizeof(srmap_irls_options);
   o->max_num_solver_iterations = 50;
   o->gradient_norm_threshold = 1.0e-6;
   o->cost_decrease_threshold = 1.0e-6;
@@ -846,7 +847,15 @@ int srmap_solve_sharded(srmap_problem* p, srmap_comm* comm, const srmap_shard_de
                         srmap_solve_report* report) {
   if (!p || !x0 || !x_out) return SRMAP_EINVAL;
   srmap_irls_options o;
-  if (options) o = *options; else srmap_irls_options_default(&o);
+  if (options) {
+    // the first member is the size of the struct the caller was compiled with: another layout is refused, not guessed at
+    if (options->struct_size != (int)sizeof(srmap_irls_options))
+      return set_error(p->ctx, SRMAP_EINVAL, "srmap_irls_options: struct_size %d, this library expects %d (fill the struct with "
+                       "srmap_irls_options_default() of the matching include/srmap.h)", options->struct_size, (int)sizeof(srmap_irls_options));
+    o = *options;
+  } else {
+    srmap_irls_options_default(&o);
+  }
   SRMAP_HIP(p->ctx, hipSetDevice(p->ctx->device));
   return solve_impl(p, comm, shard, &o, x0, x_out, report);
 }

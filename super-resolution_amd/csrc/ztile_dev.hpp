@@ -311,10 +311,6 @@ struct ZArgs {
   T fold_stp;
   const double* fold_norms;  // device {max|dk|, dk.dk}: dvec is the UNNORMALISED direction, every element read from it is
                              // scaled to the normalised one (cg_norm.hpp) -- the solver stores no normalised vector
-  // ---- marching kernel (kernels_zmarch.hip): workgroup -> (strip, band) ----
-  int m_nstrips;         // strips of 64 LR cells per image row
-  int m_band_rows;       // HR rows per band (a multiple of the step height)
-  int m_nbt;             // border tasks: pixels of the border frame (0 = none), dealt to the workgroups
 };
 
 // The x tile is staged PRE-SCALED by 2^Q (exact: a power of two).  Every difference of two staged values is the
@@ -1135,7 +1131,7 @@ struct ZPlan {
 // in-kernel finish of this launch; publish {cost, g.d} to the solver's host words; plain partials of an earlier launch to add
 struct MFin { bool on, publish; const double* xpart; int n_xpart; };
 
-// Kernel arguments shared by the tile kernel and the marching kernel (everything but the grid-dependent fields).
+// Kernel arguments of the tile kernel (everything but the grid-dependent fields).
 template <typename T, int S, int B, int REGK, int R>
 static void fill_zargs(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>& A, srmap_problem* p, const Geometry& geo, int obs_c0,
                        unsigned terms, const T* x, T* g, const T* wts, const ZPlan& z, double* partials, const T* dvec,
@@ -1175,19 +1171,7 @@ static void fill_zargs(ZArgs<T, B, ZCfg<T, S, B, REGK, R>::NP>& A, srmap_problem
     for (int i = 0; i < R; ++i)
       for (int j = 0; j < R; ++j)
         if (i + j > 0) A.pwsum += A.powtab[i + j];
-  A.m_nstrips = 0; A.m_band_rows = 0; A.m_nbt = 0;
   A.fold_xk = nullptr; A.fold_x = nullptr; A.fold_stp = T(0); A.fold_norms = nullptr;
 }
-
-// ---- marching kernel (kernels_zmarch.hip) ----
-// Whether k_eval_m covers this evaluation; *nstrips / *band_rows: its decomposition.
-template <typename T>
-bool zmarch_covers(const srmap_problem* p, const Geometry& geo, const ZPlan& z, int regk, int regr, unsigned terms,
-                   const T* g, const T* dvec, int* nstrips, int* band_rows);
-template <typename T>
-int launch_zmarch(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g, const T* wts,
-                  const ZPlan& z, int regk, int regr, double* partials, int* nblocks, hipStream_t st, MFin mfin,
-                  int nstrips, int band_rows, int n_border_partials);
-void zmarch_preload();
 
 }  // namespace srmap

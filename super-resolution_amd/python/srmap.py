@@ -16,7 +16,7 @@ OK, EINVAL, ENOMEM, EHIP, EUNSUPPORTED = 0, 1, 2, 3, 4
 F64, F32 = 0, 1
 REG_TV, REG_TV3D, REG_BTV = 0, 1, 2
 TERM_DATA, TERM_REG, TERM_ALL = 1, 2, 3
-IMPL_AUTO, IMPL_DIRECT, IMPL_TILED, IMPL_MARCH = 0, 1, 2, 3
+IMPL_AUTO, IMPL_DIRECT, IMPL_TILED = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
 
@@ -34,7 +34,8 @@ class ProblemDesc(C.Structure):
 
 
 class IrlsOptions(C.Structure):
-    _fields_ = [("max_num_solver_iterations", C.c_int),
+    _fields_ = [("struct_size", C.c_int),
+                ("max_num_solver_iterations", C.c_int),
                 ("gradient_norm_threshold", C.c_double),
                 ("cost_decrease_threshold", C.c_double),
                 ("parameter_variation_threshold", C.c_double),

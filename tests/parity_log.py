@@ -9,6 +9,15 @@ import os
 import numpy as np
 
 
+def note(e, what=""):
+    """Log an error figure measured elsewhere (torch on the GPU, scalar costs); returns it."""
+    path = os.environ.get("SRMAP_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write("%s%s\t%.3e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], (" " + what) if what else "", float(e)))
+    return float(e)
+
+
 def relerr(a, ref):
     a, ref = np.asarray(a, dtype=float).ravel(), np.asarray(ref, dtype=float).ravel()
     e = float(np.max(np.abs(a - ref) / np.maximum(1.0, np.abs(ref)))) if a.size else 0.0

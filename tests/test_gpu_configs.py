@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 TOL = {0: 1e-12, 1: 2e-5}
 
 
-from parity_log import relerr  # noqa: E402  (max |a - ref| / max(1, |ref|), logged when SRMAP_PARITY_LOG is set)
+from parity_log import note, relerr  # noqa: E402  (max |a - ref| / max(1, |ref|), logged when SRMAP_PARITY_LOG is set)
 
 
 def cfg_shifts(K, s):
@@ -96,12 +96,12 @@ def test_reduced_replica_matches_oracle(sr, ctx, case, blurred, dtype):
         p.set_impl(impl)
         f, g = p.eval(x)
         assert abs(f - f_ref) <= (tol if dtype == 0 else 1e-5) * max(1.0, abs(f_ref)), (name, impl)
-        assert relerr(g, g_ref) <= 4 * tol, (name, impl)
+        assert relerr(g, g_ref) <= tol, (name, impl)
     p.set_impl(sr.IMPL_AUTO)
     fd, gd = p.eval(x, sr.TERM_DATA)
     fd_ref, gd_ref = ref.data_term(x)
     assert abs(fd - fd_ref) <= (tol if dtype == 0 else 1e-5) * max(1.0, abs(fd_ref))
-    assert relerr(gd, gd_ref) <= 4 * tol
+    assert relerr(gd, gd_ref) <= tol
 
 
 def test_cfg2_full_size_matches_oracle(sr, ctx):
@@ -124,7 +124,7 @@ def test_cfg2_full_size_matches_oracle(sr, ctx):
     p.set_irls_weights(p.add_regularizer(sr.REG_BTV, 0.01, 3, 0.5), wts)
     f, g = p.eval(x)
     assert abs(f - f_ref) <= 1e-12 * abs(f_ref)
-    assert relerr(g, g_ref) <= 4e-12
+    assert relerr(g, g_ref) <= 1e-12
 
 
 # ------------------------------------------------------------------ torch restatement (whole-array, on the GPU)
@@ -249,9 +249,9 @@ def _full_size_case(sr, ctx, name, W, H, C, check_channels, blurred=False):
     p.set_impl(sr.IMPL_DIRECT)
     f_d = p.eval_device(x.data_ptr(), g_d.data_ptr(), sr.TERM_ALL, want_cost=True)
     torch.cuda.synchronize()
-    assert abs(f_t - f_d) <= 1e-11 * abs(f_d), (f_t, f_d)
+    assert note(abs(f_t - f_d) / abs(f_d), "cost tiled-vs-direct") <= 1e-12, (f_t, f_d)
     den = torch.clamp(g_d.abs(), min=1.0)
-    assert float(((g_t - g_d).abs() / den).max()) <= 1e-11
+    assert note(float(((g_t - g_d).abs() / den).max()), "grad tiled-vs-direct") <= 1e-12
     # torch restatement on the selected channels
     k1, k2 = (orc.gaussian_kernel(b, sigma) if b else (None, [[1.0]]))
     k2 = [[float(v) for v in row] for row in np.asarray(k2)]
@@ -282,10 +282,10 @@ def _full_size_case(sr, ctx, name, W, H, C, check_channels, blurred=False):
             gc = gc + gr
         total += fc
         den = torch.clamp(gc.abs(), min=1.0)
-        err = float(((g_t[c:c + 1] - gc).abs() / den).max())
+        err = note(float(((g_t[c:c + 1] - gc).abs() / den).max()), "grad vs torch")
         assert err <= 1e-10, (name, c, err)   # weights up to 1e5 amplify rounding of the regulariser values
     if len(check_channels) == C:
-        assert abs(total - f_t) <= 1e-10 * abs(f_t), (total, f_t)
+        assert note(abs(total - f_t) / abs(f_t), "cost vs torch") <= 1e-10, (total, f_t)
     del p
     torch.cuda.empty_cache()
 

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 out=$ROOT/gpurun_ab/$name; mkdir -p $out
 CS=$ROOT/super-resolution_amd/csrc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -mllvm -simplifycfg-sink-common=false -Wno-invalid-offsetof -I$ROOT/include -I$CS"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -mllvm -simplifycfg-sink-common=false -Wno-invalid-offsetof -I$ROOT/include -I$CS -DSRMAP_MEASUREMENT_BUILD"
 pids=""
 for src in $CS/*.hip; do
   b=$(basename $src)
