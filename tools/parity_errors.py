@@ -15,7 +15,7 @@ for line in open(sys.argv[1]):
     k = (base.replace("tests/", ""), what, "f32" if (f32 or e > 5e-10) else "f64")
     rows[k][0] += 1; rows[k][1] = max(rows[k][1], e)
 print("measured parity errors of one `pytest tests -m gpu` run on one MI355X (max |a - ref| / max(1, |ref|) per element over")
-print("every comparison the tests make; bars asserted: f64 1e-12, f32 2e-5 unless the line says otherwise)")
+print("every comparison the tests make; bars asserted: f64 1e-12, f32 2e-5 -- test_gpu_sharded: 1e-11 (two ranks, reduction order))")
 print("%-78s %-22s %-4s %6s %10s" % ("test", "quantity", "type", "n", "max error"))
 for (b, w, c), (n, mx) in sorted(rows.items()):
     print("%-78s %-22s %-4s %6d %10.2e" % (b, w or "gradient / operator", c, n, mx))
