@@ -23,4 +23,29 @@ __host__ __device__ __forceinline__ T norm_elem(T v, double mx, double s1, doubl
   return mx != 0.0 ? (T)(((double)v * s1) * s2) : v;
 }
 
+#if defined(__HIPCC__)
+// How an evaluation reads the search direction: the vector as given, or -- norms given -- the normalised direction formed
+// from the unnormalised one (uniform values, kept in scalar registers).
+struct DirScale {
+  double mx, s1, s2;
+  bool on;
+};
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ DirScale dir_scale(const double* __restrict__ norms) {
+  DirScale ds{0.0, 1.0, 1.0, false};
+  if (norms != nullptr) {  // uniform
+    double s1, s2;
+    const double mx = norms[0];
+    norm_factors(mx, norms[1], s1, s2);
+    ds.mx = uniform_d(mx); ds.s1 = uniform_d(s1); ds.s2 = uniform_d(s2); ds.on = true;
+  }
+  return ds;
+}
+template <typename T>
+__device__ __forceinline__ T dir_elem(T v, const DirScale& ds) { return ds.on ? norm_elem<T>(v, ds.mx, ds.s1, ds.s2) : v; }
+#endif
+
 }  // namespace srmap

@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void k_gather_direct(
 template <typename T, int SC, int FP>
 __global__ __launch_bounds__(256) void k_gather_ring(const T* __restrict__ resid, T* __restrict__ gout, Geometry g,
                                                     const WarpTaps<T>* __restrict__ warps, const T* __restrict__ blur_t,
-                                                    int nk, T out_scale, int ring) {
+                                                    int nk, T out_scale, int ring, T* __restrict__ ringbuf) {
+  // ringbuf != nullptr: the ring's data gradient goes to ringbuf[c][t] (t = the ring pixel's number below) instead of
+  // being added to gout -- the pass then runs AHEAD of the tile kernel, which adds the value as it stores g (and can
+  // produce g.d with the gradient: kernels_ztile.hip, sub-pixel WD instances)
   constexpr int gs = SC;
   __shared__ T part[256];
   const int lane = threadIdx.x & 63;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void k_gather_ring(const T* __restrict__ resid
   const int hp = rr * g.W + cc;
   typedef const WarpTaps<T> __attribute__((address_space(4))) * WP;
   const size_t o = (size_t)c * N + hp;
-  const T gold = (fg == 0 && live) ? gout[o] : T(0);  // requested with everything else (the launch adds to g)
+  const T gold = (fg == 0 && live && ringbuf == nullptr) ? gout[o] : T(0);  // requested with everything else (the launch adds to g)
   T rv[FP][4], cf[FP][4], wq[FP][4];
   // ---- every request of this thread's frames ----
 #pragma unroll
@@ -323,13 +326,19 @@ __global__ __launch_bounds__(256) void k_gather_ring(const T* __restrict__ resid
   acc = part[lane];
 #pragma unroll
   for (int q = 1; q < 4; ++q) acc += part[lane + q * 64];
-  gout[o] = gold + out_scale * acc;
+  if (ringbuf != nullptr) ringbuf[(size_t)c * (size_t)(2 * band + 2 * ring * mid) + t] = out_scale * acc;
+  else gout[o] = gold + out_scale * acc;
+}
+
+bool gather_ring_kernel_ok(const srmap_problem* p, const Geometry& geo, int nk, int ring) {
+  return ring > 0 && 2 * ring < geo.H && 2 * ring < geo.W && p->has_motion && p->d_bwd_warps != nullptr && geo.b <= geo.s &&
+         geo.s >= 2 && geo.s <= 4 && nk <= 16 && p->d_ytabs.empty();
 }
 
 template <typename T>
 int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, T* g,
                          int k0, int nk, double out_scale, bool accumulate,
-                         hipStream_t st, int ring) {
+                         hipStream_t st, int ring, T* ringbuf) {
   // ring > 0: only the pixels within `ring` of the image edge (the exact border of the sub-pixel tile path)
   size_t npix = (size_t)geo.W * geo.H;
   if (ring > 0) {
@@ -337,11 +346,12 @@ int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, 
     else npix = 2 * (size_t)ring * geo.W + 2 * (size_t)ring * (geo.H - 2 * ring);
   }
   const WarpTaps<T>* wp0 = p->has_motion ? (const WarpTaps<T>*)p->d_bwd_warps : nullptr;
-  if (ring > 0 && accumulate && k0 == 0 && wp0 != nullptr && geo.b <= geo.s && geo.s >= 2 && geo.s <= 4 && nk <= 16 &&
-      p->d_ytabs.empty()) {
+  if (ringbuf != nullptr && !(accumulate && k0 == 0 && gather_ring_kernel_ok(p, geo, nk, ring)))
+    return set_error(p->ctx, SRMAP_EINVAL, "internal: the ring buffer needs the ring kernel");
+  if (ring > 0 && accumulate && k0 == 0 && gather_ring_kernel_ok(p, geo, nk, ring)) {
     dim3 grid((unsigned)((npix + 63) / 64), geo.C);
     const T* bt0 = (const T*)p->d_blur_t;
-#define SRMAP_RING(SS, FF) hipLaunchKernelGGL((k_gather_ring<T, SS, FF>), grid, dim3(256), 0, st, resid, g, geo, wp0, bt0, nk, (T)out_scale, ring)
+#define SRMAP_RING(SS, FF) hipLaunchKernelGGL((k_gather_ring<T, SS, FF>), grid, dim3(256), 0, st, resid, g, geo, wp0, bt0, nk, (T)out_scale, ring, ringbuf)
 #define SRMAP_RING_S(SS) do { if (nk <= 4) SRMAP_RING(SS, 1); else if (nk <= 8) SRMAP_RING(SS, 2); else SRMAP_RING(SS, 4); } while (0)
     if (geo.s == 2) SRMAP_RING_S(2); else if (geo.s == 3) SRMAP_RING_S(3); else SRMAP_RING_S(4);
 #undef SRMAP_RING_S
@@ -1055,7 +1065,7 @@ int launch_reduce_partials(srmap_problem* p, const double* partials, int n, doub
                                         const T*, int, int, T*, int, int, double*, int*,   \
                                         hipStream_t);                                       \
   template int launch_gather_direct<T>(srmap_problem*, const Geometry&, const T*, T*, int, \
-                                       int, double, bool, hipStream_t, int);                \
+                                       int, double, bool, hipStream_t, int, T*);            \
   template int launch_reg_values<T>(srmap_problem*, const Geometry&, const RegSpec&,       \
                                     const T*, T*, hipStream_t);                             \
   template int launch_reg_gradient_direct<T>(srmap_problem*, const Geometry&,              \

@@ -19,6 +19,7 @@
 #include <climits>
 #include <vector>
 
+#include "cg_norm.hpp"
 #include "srmap_internal.hpp"
 
 namespace srmap {
@@ -52,6 +53,19 @@ struct SpfArgs {
   int K, W, H, wl, hl, C, obs_C, obs_c0, cr0, cr1;
   int RLO, CLO, XR, XC;  // window: rows S*i0 + RLO .. + XR-1, cells j0 + CLO .. + XC-1
   double cost_scale;
+  // FOLD instances (solver line search): the point is fold_xk + fold_stp * d, formed as the window is loaded -- the
+  // expression of solver.hip's k_axpy_out, the same contraction -- and the workgroup's OWN pixels (the S kLRH x S kCW
+  // block of its LR cells) are written to `xout`: the tile kernel behind this launch, and the solver, find the trial
+  // point there.  The window holds what the frames read, which need not include every own pixel (frames that all read
+  // up-left of their LR pixel leave the block's last row out): FOLD instances walk the union of window and own block,
+  // rows S*i0 + RF0 .. + NRF-1, cells j0 + CF0 .. + NCF-1, and stage only the window's part in LDS.
+  // dvec / fold_norms as in ZArgs (cg_norm.hpp).
+  int RF0, NRF, CF0, NCF;
+  const T* fold_xk;
+  const T* dvec;
+  T* xout;
+  T fold_stp;
+  const double* fold_norms;
 };
 
 __device__ __forceinline__ int fdiv_rt(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -62,7 +76,7 @@ __device__ __forceinline__ double wave_sum64(double v) {
   return v;
 }
 
-template <typename T, int S, int B>
+template <typename T, int S, int B, bool FOLD>
 __global__ __launch_bounds__(64 * kNW) void k_forward_sp(SpfArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* xs = reinterpret_cast<T*>(smem_raw);
@@ -73,18 +87,21 @@ __global__ __launch_bounds__(64 * kNW) void k_forward_sp(SpfArgs<T> A) {
   const int li = wv % kLRH, par = wv / kLRH;
   const int i0 = blockIdx.y * kLRH, j0 = blockIdx.x * kCW, ch = blockIdx.z;
   const size_t N = (size_t)A.W * A.H, nl = (size_t)A.wl * A.hl;
-  const T* xplane = A.x + (size_t)ch * N;
+  const T* xplane = (FOLD ? A.fold_xk : A.x) + (size_t)ch * N;
   const int XROW = S * A.XC;
+  const DirScale dsc = dir_scale(FOLD ? A.fold_norms : nullptr);
 
   // ---- window -> LDS (all loads first) ----
   T va[kMaxRowsPerWave][S], vb[kMaxRowsPerWave][S];
-  const bool has_b = lane + kCW < A.XC;
+  // the rows / cells this workgroup walks: the window; FOLD: the union of window and own block (see SpfArgs)
+  const int r_lo = FOLD ? A.RF0 : A.RLO, n_rows = FOLD ? A.NRF : A.XR, c_lo = FOLD ? A.CF0 : A.CLO, n_cells = FOLD ? A.NCF : A.XC;
+  const bool has_b = lane + kCW < n_cells;
 #pragma unroll
   for (int it = 0; it < kMaxRowsPerWave; ++it) {
     const int row = wv + it * kNW;
-    const int grr = S * i0 + A.RLO + row;
-    const bool row_in = row < A.XR && (unsigned)grr < (unsigned)A.H;  // uniform
-    const int gca = j0 + A.CLO + lane, gcb = gca + kCW;
+    const int grr = S * i0 + r_lo + row;
+    const bool row_in = row < n_rows && (unsigned)grr < (unsigned)A.H;  // uniform
+    const int gca = j0 + c_lo + lane, gcb = gca + kCW;
     const bool ina = row_in && (unsigned)gca < (unsigned)A.wl;
     const bool inb = row_in && has_b && (unsigned)gcb < (unsigned)A.wl;
     const T* sa = xplane + (ina ? (size_t)grr * A.W + (size_t)gca * S : (size_t)0);
@@ -93,6 +110,33 @@ __global__ __launch_bounds__(64 * kNW) void k_forward_sp(SpfArgs<T> A) {
     for (int pc = 0; pc < S; ++pc) va[it][pc] = sa[pc];
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) vb[it][pc] = sb[pc];
+    if (FOLD) {
+      const T* dpl = A.dvec + (size_t)ch * N;
+      const T* da = dpl + (sa - xplane);
+      const T* db = dpl + (sb - xplane);
+      T vda[S], vdb[S];
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) vda[pc] = da[pc];
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) vdb[pc] = db[pc];
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) {
+        va[it][pc] = va[it][pc] + A.fold_stp * dir_elem<T>(vda[pc], dsc);
+        vb[it][pc] = vb[it][pc] + A.fold_stp * dir_elem<T>(vdb[pc], dsc);
+      }
+      // the workgroup's own pixels of the trial point go out (every image pixel is some workgroup's own exactly once)
+      const int orow = r_lo + row;  // HR row relative to S * i0
+      const bool own_row = row_in && orow >= 0 && orow < S * kLRH;
+      T* xo = A.xout + (size_t)ch * N;
+      if (own_row && ina && gca >= j0 && gca < j0 + kCW) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) xo[(size_t)grr * A.W + (size_t)gca * S + pc] = va[it][pc];
+      }
+      if (own_row && inb && gcb >= j0 && gcb < j0 + kCW) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) xo[(size_t)grr * A.W + (size_t)gcb * S + pc] = vb[it][pc];
+      }
+    }
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
       va[it][pc] = ina ? va[it][pc] : T(0);
@@ -102,12 +146,27 @@ __global__ __launch_bounds__(64 * kNW) void k_forward_sp(SpfArgs<T> A) {
 #pragma unroll
   for (int it = 0; it < kMaxRowsPerWave; ++it) {
     const int row = wv + it * kNW;
-    if (row < A.XR) {  // uniform
+    if (!FOLD) {
+      if (row < A.XR) {  // uniform
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) xs[row * XROW + pc * A.XC + lane] = va[it][pc];
-      if (has_b) {
+        for (int pc = 0; pc < S; ++pc) xs[row * XROW + pc * A.XC + lane] = va[it][pc];
+        if (has_b) {
 #pragma unroll
-        for (int pc = 0; pc < S; ++pc) xs[row * XROW + pc * A.XC + kCW + lane] = vb[it][pc];
+          for (int pc = 0; pc < S; ++pc) xs[row * XROW + pc * A.XC + kCW + lane] = vb[it][pc];
+        }
+      }
+    } else {
+      const int wrow = r_lo + row - A.RLO;                   // window row (uniform)
+      const int wca = c_lo + lane - A.CLO, wcb = wca + kCW;  // window cells
+      if (row < n_rows && wrow >= 0 && wrow < A.XR) {
+        if (wca >= 0 && wca < A.XC) {
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) xs[wrow * XROW + pc * A.XC + wca] = va[it][pc];
+        }
+        if (has_b && wcb >= 0 && wcb < A.XC) {
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) xs[wrow * XROW + pc * A.XC + wcb] = vb[it][pc];
+        }
       }
     }
   }
@@ -212,8 +271,13 @@ bool upload_frames(const srmap_problem* p, SpForwardPlan* sp) {
 
 template <typename T, int S, int B>
 int launch_typed(srmap_problem* p, const Geometry& geo, const SpForwardPlan& sp, const T* x, const T* y, int obs_C,
-                 int obs_c0, T* out, double* partials, int* nblocks, hipStream_t st) {
+                 int obs_c0, T* out, double* partials, int* nblocks, hipStream_t st, const SpFold& fold) {
   SpfArgs<T> A;
+  A.fold_xk = (const T*)fold.xk; A.dvec = (const T*)fold.dvec; A.xout = const_cast<T*>(x); A.fold_stp = (T)fold.stp;
+  A.fold_norms = fold.norms;
+  if (fold.xk != nullptr && !sp.can_fold)
+    return set_error(p->ctx, SRMAP_EINVAL, "internal: the forward tile kernel cannot form the trial point for this geometry (no fold)");
+  A.RF0 = sp.RF0; A.NRF = sp.NRF; A.CF0 = sp.CF0; A.NCF = sp.NCF;
   A.x = x; A.y = y; A.out = out; A.partials = partials;
   A.frames = (const SpFrame<T>*)sp.d_frames;
   A.K = geo.K; A.W = geo.W; A.H = geo.H; A.wl = geo.w; A.hl = geo.h; A.C = geo.C;
@@ -222,7 +286,8 @@ int launch_typed(srmap_problem* p, const Geometry& geo, const SpForwardPlan& sp,
   A.cost_scale = (double)geo.s * (double)geo.s;
   dim3 grid((unsigned)((geo.w + kCW - 1) / kCW), (unsigned)((geo.h + kLRH - 1) / kLRH), (unsigned)geo.C);
   const size_t lds = (size_t)sp.XR * S * sp.XC * sizeof(T);
-  hipLaunchKernelGGL((k_forward_sp<T, S, B>), grid, dim3(64 * kNW), lds, st, A);
+  if (fold.xk != nullptr) hipLaunchKernelGGL((k_forward_sp<T, S, B, true>), grid, dim3(64 * kNW), lds, st, A);
+  else hipLaunchKernelGGL((k_forward_sp<T, S, B, false>), grid, dim3(64 * kNW), lds, st, A);
   SRMAP_HIP(p->ctx, hipGetLastError());
   *nblocks = (int)(grid.x * grid.y * grid.z);
   return SRMAP_OK;
@@ -231,7 +296,8 @@ int launch_typed(srmap_problem* p, const Geometry& geo, const SpForwardPlan& sp,
 template <typename T, int S, int B>
 void preload_typed() {
   hipFuncAttributes attr;
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_forward_sp<T, S, B>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_forward_sp<T, S, B, false>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_forward_sp<T, S, B, true>));
 }
 
 }  // namespace
@@ -260,6 +326,10 @@ bool spfwd_plan(srmap_problem* p, SpForwardPlan* sp) {
   const bool ok = p->dtype == SRMAP_F32 ? upload_frames<float>(p, sp) : upload_frames<double>(p, sp);
   if (!ok) { spfwd_release(sp); return false; }
   sp->ok = true;
+  // fold (solver line search): a workgroup walks the union of its window and its own S kLRH x S kCW pixels
+  sp->RF0 = std::min(sp->RLO, 0); sp->NRF = std::max(sp->RLO + sp->XR, S * kLRH) - sp->RF0;
+  sp->CF0 = std::min(sp->CLO, 0); sp->NCF = std::max(sp->CLO + sp->XC, kCW) - sp->CF0;
+  sp->can_fold = sp->NRF <= kMaxRowsPerWave * kNW && sp->NCF <= 2 * kCW;
   if (p->dtype == SRMAP_F32) {
     if (S == 2 && B == 1) preload_typed<float, 2, 1>(); else if (S == 2) preload_typed<float, 2, 3>();
     else if (S == 3 && B == 1) preload_typed<float, 3, 1>(); else if (S == 3) preload_typed<float, 3, 3>();
@@ -280,18 +350,18 @@ void spfwd_release(SpForwardPlan* sp) {
 
 template <typename T>
 int launch_forward_sp(srmap_problem* p, const Geometry& geo, const SpForwardPlan& sp, const T* x, const T* y,
-                      int obs_C, int obs_c0, T* out, double* partials, int* nblocks, hipStream_t st) {
+                      int obs_C, int obs_c0, T* out, double* partials, int* nblocks, hipStream_t st, const SpFold& fold) {
   const int S = geo.s, B = geo.b;
 #define SPF(SS, BB) \
-  if (S == SS && B == BB) return launch_typed<T, SS, BB>(p, geo, sp, x, y, obs_C, obs_c0, out, partials, nblocks, st)
+  if (S == SS && B == BB) return launch_typed<T, SS, BB>(p, geo, sp, x, y, obs_C, obs_c0, out, partials, nblocks, st, fold)
   SPF(2, 1); SPF(2, 3); SPF(3, 1); SPF(3, 3); SPF(4, 1); SPF(4, 3);
 #undef SPF
   return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no forward tile kernel for scale %d blur %d", S, B);
 }
 
 template int launch_forward_sp<float>(srmap_problem*, const Geometry&, const SpForwardPlan&, const float*,
-                                      const float*, int, int, float*, double*, int*, hipStream_t);
+                                      const float*, int, int, float*, double*, int*, hipStream_t, const SpFold&);
 template int launch_forward_sp<double>(srmap_problem*, const Geometry&, const SpForwardPlan&, const double*,
-                                       const double*, int, int, double*, double*, int*, hipStream_t);
+                                       const double*, int, int, double*, double*, int*, hipStream_t, const SpFold&);
 
 }  // namespace srmap

@@ -477,6 +477,28 @@ __global__ __launch_bounds__((ZCfg<T, S, B, REGK, R>::NT), (sizeof(T) == 4 ? SRM
   }
   if (want_reg && A.g != nullptr) reg_pass2z<T, S, REGK, R, C>(acc, xs, cs, wv, lane, A.powtab);
 
+  if (SP && want_data && A.g != nullptr && A.ringbuf != nullptr) {
+    // the ring pass ran AHEAD of this launch (k_gather_ring into the plan's buffer): its exact data gradient of the pixels
+    // within Dr of the image edge is added LAST, as the pass added it to the stored g when it ran behind the launch
+    // (uniform test first: only edge tiles hold such pixels)
+    const int Dr = A.Dr;
+    if (R0 < Dr || R0 + C::TH > A.H - Dr || C0 < Dr || C0 + C::TW > A.W - Dr) {
+      const int band = Dr * A.W, mid = A.H - 2 * Dr;
+      const T* rb = A.ringbuf + (size_t)ch * (size_t)(2 * band + 2 * Dr * mid);
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) {
+        const int gc = gc0 + pc;
+        if (gr < A.H && gc < A.W) {
+          int t = -1;
+          if (gr < Dr) t = gr * A.W + gc;
+          else if (gr >= A.H - Dr) t = band + (gr - (A.H - Dr)) * A.W + gc;
+          else if (gc < Dr) t = 2 * band + (gr - Dr) * 2 * Dr + gc;
+          else if (gc >= A.W - Dr) t = 2 * band + (gr - Dr) * 2 * Dr + Dr + (gc - (A.W - Dr));
+          if (t >= 0) acc[pc] += rb[t];
+        }
+      }
+    }
+  }
   if (A.g != nullptr && gr < A.H && gc0 < A.W) {
     T* dst = A.g + (size_t)ch * N + (size_t)gr * A.W + gc0;
 #pragma unroll
@@ -590,6 +612,7 @@ void ztile_release(srmap_problem* p) {
   if (z->d_aux) (void)hipFree(z->d_aux);
   if (z->d_spw) (void)hipFree(z->d_spw);
   if (z->d_spsrc) (void)hipFree(z->d_spsrc);
+  if (z->d_ringbuf) (void)hipFree(z->d_ringbuf);
   spfwd_release(&z->spf);
   if (z->d_corr) (void)hipFree(z->d_corr);
   if (z->d_bd) (void)hipFree(z->d_bd);
@@ -724,6 +747,11 @@ bool ztile_plan(srmap_problem* p) {
               hipMemcpy(z->d_spsrc, srctab.data(), sizeof(ZSrc) * srctab.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&z->d_off, 64) == hipSuccess;
     p->zplan = z;
+    if (ok && gather_ring_kernel_ok(p, g, K, z->Dr)) {
+      // the ring pass runs ahead of the tile kernel into this buffer (g.d and the cost then finish inside the tile launch)
+      const size_t nring = 2 * (size_t)z->Dr * g.W + 2 * (size_t)z->Dr * (g.H - 2 * z->Dr);
+      ok = hipMalloc(&z->d_ringbuf, nring * g.C * p->elem()) == hipSuccess;
+    }
     if (ok) {  // granules of the in-kernel cost reduction (as below)
       const size_t cap = std::min<size_t>(ztile_partials_needed(p), kMaxFusedPartials);
       ok = hipMalloc((void**)&z->d_mpart, 2 * cap * sizeof(double)) == hipSuccess &&
@@ -874,7 +902,9 @@ static size_t ztile_est_partials(const ZPlan* z, int w, int H, int C) {
 // reduction.  launch_eval_ztile asks it for the launch, ztile_can_fold for the solver (a folded trial point exists only
 // inside that instance): the two cannot drift apart.
 static bool ztile_gd_instance_ok(const srmap_problem* p, const ZPlan& z, int w, int H, int C, unsigned terms) {
-  if (z.subpix) return false;
+  // sub-pixel plans: the ring pass must be able to run AHEAD of the tile launch (into z.d_ringbuf) -- a pass that adds to g
+  // behind it would leave the launch's g.d without the ring's share
+  if (z.subpix && z.d_ringbuf == nullptr) return false;
   if (terms & SRMAP_TERM_REG)
     for (int r = 0; r < p->nreg; ++r)
       if (!(z.regk != 0 && r == z.reg_index) && p->reg[r].lambda > 0.0) return false;
@@ -885,6 +915,8 @@ bool ztile_can_fold(const srmap_problem* p) {
   const ZPlan* z = static_cast<const ZPlan*>(p->zplan);
   if (!z || p->impl == SRMAP_IMPL_DIRECT || p->ov_hook != nullptr) return false;
   const Geometry& g = p->geo;
+  // sub-pixel plans: the trial point is formed by the forward tile kernel, whose window has to hold a workgroup's own pixels
+  if (z->subpix && !(z->spf.ok && z->spf.can_fold)) return false;
   return ztile_gd_instance_ok(p, *z, g.w, g.H, p->view_C > 0 ? p->view_C : g.C, SRMAP_TERM_ALL);
 }
 
@@ -896,13 +928,16 @@ size_t ztile_partials_needed(const srmap_problem* p) {
 template <typename T, int S, int B, int REGK, int R>
 static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                     const T* wts, const ZPlan& z, double* partials, int* nblocks, hipStream_t st, const T* dvec,
-                    double* partials_gd, MFin mfin) {
+                    double* partials_gd, MFin mfin, bool ring_ahead) {
   using C = ZCfg<T, S, B, REGK, R>;
   ZArgs<T, B, C::NP> A;
   fill_zargs<T, S, B, REGK, R>(A, p, geo, obs_c0, terms, x, g, wts, z, partials, dvec, partials_gd);
   if (dvec != nullptr && p->eval_fold_xk != nullptr) {  // line search: the point is xk + stp * d; its own pixels go to x
-    A.fold_xk = (const T*)p->eval_fold_xk; A.fold_x = const_cast<T*>(x); A.fold_stp = (T)p->eval_fold_stp;
     A.fold_norms = p->eval_fold_norms;
+    if (!(z.subpix && (terms & SRMAP_TERM_DATA))) {
+      A.fold_xk = (const T*)p->eval_fold_xk; A.fold_x = const_cast<T*>(x); A.fold_stp = (T)p->eval_fold_stp;
+    }  // sub-pixel plans: the forward kernel ahead of this launch formed the point and wrote x (launch_eval_ztile); dvec is
+       // still the unnormalised direction here (fold_norms)
   }
   dim3 grid((geo.w + C::CW - 1) / C::CW, (geo.H + C::TH - 1) / C::TH, geo.C);
   { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }
@@ -917,7 +952,8 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
     nbb = A.nby * (int)grid.x;
     grid.y += A.nby;
   }
-  A.rbuf = nullptr; A.spw = z.d_spw; A.Dr = z.Dr;
+  A.rbuf = nullptr; A.spw = z.d_spw; A.Dr = z.Dr; A.ringbuf = nullptr;
+
   A.mfinish = mfin.on ? 1 : 0;
   A.n_partials = n_tile_partials + nbb * (int)grid.z;
   A.mpart = z.d_mpart;
@@ -932,7 +968,9 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   if (z.subpix && (terms & SRMAP_TERM_DATA)) {
     A.rbuf = (const T*)p->d_resid;
     A.obs_C = geo.C;  // layout of the residual buffer written by launch_forward_direct for this evaluation
-    hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
+    A.ringbuf = ring_ahead ? (const T*)z.d_ringbuf : nullptr;
+    if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, true>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
+    else hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, false, true>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
   } else {
     auto launch = [&]() {
       if (dvec != nullptr) hipLaunchKernelGGL((k_eval_z<T, S, B, REGK, R, true, false>), grid, dim3(C::NT), SRMAP_EXP_LDS_PAD, st, A);
@@ -967,6 +1005,7 @@ static void preload_z() {
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false, false>));
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, true, false>));
   (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, false, true>));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_eval_z<T, S, B, REGK, R, true, true>));
 }
 template <typename T, int S, int B>
 static void preload_reg(int regk, int regr) {
@@ -1002,12 +1041,12 @@ void ztile_preload(const srmap_problem* p) {
 template <typename T, int S, int B>
 static int dispatch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned terms, const T* x, T* g,
                       const T* wts, const ZPlan& z, int regk, int regr, double* partials, int* nb, hipStream_t st,
-                      const T* dv, double* pgd, MFin mfin) {
-  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
-  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin);
+                      const T* dv, double* pgd, MFin mfin, bool ring_ahead) {
+  if (regk == 1) return launch_z<T, S, B, 1, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, ring_ahead);
+  if (regk == 2 && regr == 1) return launch_z<T, S, B, 2, 1>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, ring_ahead);
+  if (regk == 2 && regr == 2) return launch_z<T, S, B, 2, 2>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, ring_ahead);
+  if (regk == 2 && regr == 3) return launch_z<T, S, B, 2, 3>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, ring_ahead);
+  return launch_z<T, S, B, 0, 0>(p, geo, obs_c0, terms, x, g, wts, z, partials, nb, st, dv, pgd, mfin, ring_ahead);
 }
 
 template <typename T>
@@ -1039,16 +1078,32 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   const bool sp_data = z.subpix && (terms & SRMAP_TERM_DATA);
   const bool with_d = p->eval_dvec != nullptr && g != nullptr && ztile_gd_instance_ok(p, z, geo.w, geo.H, geo.C, terms);
   int nfwd = 0;
+  // the exact ring pass AHEAD of the tile kernel (k_gather_ring into the plan's buffer; the edge tiles add the values as
+  // they store g, so g.d and the cost finish inside the tile launch) wherever the ring kernel applies; else behind it,
+  // adding to g (then no g.d from the launch: ztile_gd_instance_ok).  Ring blocks at the front of the tile launch's own
+  // grid (one launch less) were built and measured: every ring workgroup holds a tile slot (73 KB of LDS) for its 6 - 9 us of
+  // latency, 450 of the 512 slots of the first generation -- 82.9 us against 82.5 us, and slower inside a solve.
+  const bool ring_ahead = sp_data && g != nullptr && z.d_ringbuf != nullptr;
   if (sp_data) {
     // sub-pixel shifts: exact residuals (and the data cost) from the direct forward kernel, then the tile kernel
-    // gathers them with the 4-tap tables; the pixels within Dr of the edge are redone exactly afterwards
+    // gathers them with the 4-tap tables; the pixels within Dr of the edge are evaluated exactly by the ring pass
     if (!p->d_resid) SRMAP_HIP(p->ctx, hipMalloc(&p->d_resid, p->lr_count() * sizeof(T)));
+    SpFold sf;
+    if (p->eval_fold_xk != nullptr) {
+      if (!(with_d && z.spf.ok && z.spf.can_fold))
+        return set_error(p->ctx, SRMAP_EINVAL, "internal: a folded trial point needs the forward tile kernel and the g.d instance (ztile_can_fold)");
+      sf.xk = p->eval_fold_xk; sf.dvec = p->eval_dvec; sf.stp = p->eval_fold_stp; sf.norms = p->eval_fold_norms;
+    }
     if (z.spf.ok)
-      rc = launch_forward_sp<T>(p, geo, z.spf, x, (const T*)p->d_obs, p->geo.C, obs_c0, (T*)p->d_resid, partials, &nfwd, st);
+      rc = launch_forward_sp<T>(p, geo, z.spf, x, (const T*)p->d_obs, p->geo.C, obs_c0, (T*)p->d_resid, partials, &nfwd, st, sf);
     else
       rc = launch_forward_direct<T>(p, geo, x, (const T*)p->d_obs, p->geo.C, obs_c0, (T*)p->d_resid, 0, geo.K, partials, &nfwd, st);
     if (rc) return rc;
     partials += nfwd;
+    if (ring_ahead) {
+      rc = launch_gather_direct<T>(p, geo, (const T*)p->d_resid, g, 0, geo.K, 2.0 * geo.s * geo.s, true, st, z.Dr, (T*)z.d_ringbuf);
+      if (rc) return rc;
+    }
   }
   if (p->eval_fold_xk != nullptr && !(with_d && p->ov_hook == nullptr))
     return set_error(p->ctx, SRMAP_EINVAL, "internal: a folded trial point needs the tile kernel's g.d instance (ztile_can_fold)");
@@ -1059,7 +1114,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   // tiles: the cost reduction inside the kernel (no finish launch) when no in-image pixel of the border frame needs a
   // correction, no further regulariser kernel follows and the granules suffice
   // Sub-pixel plan: the forward kernel's data-cost partials (plain doubles, complete before the tile kernel starts) are
-  // added by the same in-kernel finish; the ring pass that follows touches g only.
+  // added by the same in-kernel finish; the ring pass touches g only.
   MFin mfin;
   mfin.on = !more_regs && p->ov_hook == nullptr && z.d_mpart != nullptr && est_parts <= z.mpart_cap &&
             (z.n_ring == 0 || (z.ring.rg[0] == 0 && z.ring.rg[1] == 0)) && (size_t)nfwd <= kMaxFusedPartials;
@@ -1071,15 +1126,15 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
     if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == 3 && regk == 2 && regr == 3)
       return launch_z<SRMAP_ZT_ONLY_T, 4, 3, 2, 3>(p, geo, obs_c0, zterms, (const SRMAP_ZT_ONLY_T*)x, (SRMAP_ZT_ONLY_T*)g,
                                                    (const SRMAP_ZT_ONLY_T*)wts, z, partials, &nb, st, (const SRMAP_ZT_ONLY_T*)dv, pgd,
-                                                   mfin);
+                                                   mfin, ring_ahead);
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "measurement build: cfg2 instance only");
 #else
-    if (S == 2 && B == 1) return dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-    if (S == 2 && B == 3) return dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-    if (S == 3 && B == 1) return dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-    if (S == 3 && B == 3) return dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-    if (S == 4 && B == 1) return dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
-    if (S == 4 && B == 3) return dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin);
+    if (S == 2 && B == 1) return dispatch_z<T, 2, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, ring_ahead);
+    if (S == 2 && B == 3) return dispatch_z<T, 2, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, ring_ahead);
+    if (S == 3 && B == 1) return dispatch_z<T, 3, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, ring_ahead);
+    if (S == 3 && B == 3) return dispatch_z<T, 3, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, ring_ahead);
+    if (S == 4 && B == 1) return dispatch_z<T, 4, 1>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, ring_ahead);
+    if (S == 4 && B == 3) return dispatch_z<T, 4, 3>(p, geo, obs_c0, zterms, x, g, wts, z, regk, regr, partials, &nb, st, dv, pgd, mfin, ring_ahead);
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "no tile kernel for scale %d blur %d", S, B);
 #endif
   };
@@ -1088,7 +1143,7 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   if (sp_data) {
     partials -= nfwd;
     nb += nfwd;
-    if (g != nullptr) {
+    if (g != nullptr && !ring_ahead) {
       rc = launch_gather_direct<T>(p, geo, (const T*)p->d_resid, g, 0, geo.K, 2.0 * geo.s * geo.s, true, st, z.Dr);
       if (rc) return rc;
     }

@@ -175,7 +175,9 @@ int launch_forward_direct(srmap_problem* p, const Geometry& g, const T* x, const
 template <typename T>
 int launch_gather_direct(srmap_problem* p, const Geometry& geo, const T* resid, T* g,
                          int k0, int nk, double out_scale, bool accumulate,
-                         hipStream_t st, int ring = 0);
+                         hipStream_t st, int ring = 0, T* ringbuf = nullptr);
+// whether the ring mode (ring > 0) runs as k_gather_ring (which can also write the ring's values to a side buffer)
+bool gather_ring_kernel_ok(const srmap_problem* p, const Geometry& geo, int nk, int ring);
 template <typename T>
 int launch_reg_values(srmap_problem* p, const Geometry& geo, const RegSpec& rs,
                       const T* x, T* values, hipStream_t st);
@@ -214,13 +216,19 @@ struct SpForwardPlan {
   void* d_frames = nullptr;  // per frame: integer offsets + blur (x) bilinear stencil
   int RLO = 0, CLO = 0, XR = 0, XC = 0;  // LDS window of a workgroup relative to its first LR row / cell
   bool ok = false;
+  int RF0 = 0, NRF = 0, CF0 = 0, NCF = 0;  // union of the window and the workgroup's own HR block (rows / cells FOLD instances walk)
+  bool can_fold = false;     // that union fits the kernel's load loop: the trial point can be formed (folded) here
 };
+// solver line search: the evaluation's point is xk + stp * d (d = dvec, scaled by the factors of `norms` when given:
+// cg_norm.hpp); the forward kernel forms it as it loads its window and writes it to the evaluation's x.  xk == nullptr: none
+struct SpFold { const void* xk = nullptr; const void* dvec = nullptr; double stp = 0.0; const double* norms = nullptr; };
 bool spfwd_plan(srmap_problem* p, SpForwardPlan* sp);
 void spfwd_release(SpForwardPlan* sp);
 // out[k][c][h][w] = A_k x - y_k for all frames + cost partials (one per workgroup)
 template <typename T>
 int launch_forward_sp(srmap_problem* p, const Geometry& geo, const SpForwardPlan& sp, const T* x, const T* y,
-                      int obs_C, int obs_c0, T* out, double* partials, int* nblocks, hipStream_t st);
+                      int obs_C, int obs_c0, T* out, double* partials, int* nblocks, hipStream_t st,
+                      const SpFold& fold = SpFold());
 
 // ---- vector kernels for the solver (solver.hip) ----
 int solve_impl(srmap_problem* p, srmap_comm* comm, const srmap_shard_desc* shard,

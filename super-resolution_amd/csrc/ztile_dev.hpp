@@ -291,6 +291,8 @@ struct ZArgs {
   int spn[4];
   int spmax;
   int Dr;                //   data gradient of the pixels within Dr of the image edge comes from the exact ring pass
+  const T* ringbuf;      //   ... which ran AHEAD of this launch into ringbuf[C][2 Dr W + 2 Dr (H - 2 Dr)] (k_gather_ring's pixel
+                         //   order): added as g is stored.  nullptr: the ring pass follows the launch and adds to g itself
   RingRects ring;        // border frame rectangles (border blocks / tasks, corrections)
   // ---- in-kernel finish (no second launch): partials leave as write-through granules, the last block of the grid
   // gathers them (see m_finish_block) ----
@@ -928,29 +930,6 @@ struct BorderArgs {      // device-resident (one per problem): only the border b
 
 __device__ __forceinline__ int dfdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-// How an evaluation reads the search direction: the vector as given, or -- norms given -- the normalised direction formed
-// from the unnormalised one (uniform values, kept in scalar registers).
-struct DirScale {
-  double mx, s1, s2;
-  bool on;
-};
-__device__ __forceinline__ double uniform_d(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ DirScale dir_scale(const double* __restrict__ norms) {
-  DirScale ds{0.0, 1.0, 1.0, false};
-  if (norms != nullptr) {  // uniform
-    double s1, s2;
-    const double mx = norms[0];
-    norm_factors(mx, norms[1], s1, s2);
-    ds.mx = uniform_d(mx); ds.s1 = uniform_d(s1); ds.s2 = uniform_d(s2); ds.on = true;
-  }
-  return ds;
-}
-template <typename T>
-__device__ __forceinline__ T dir_elem(T v, const DirScale& ds) { return ds.on ? norm_elem<T>(v, ds.mx, ds.s1, ds.s2) : v; }
-
 // r_k(i, j) = (D B M_k x)(i, j) - y_k(i, j) with both clips (warped image, blur zero padding)
 // S, B at compile time and the taps from the kernel arguments: the B * B loads of a residual are requested together
 // (with run-time loop bounds and a tap table in memory every tap was its own round trip: ~9 us per border block).
@@ -1095,6 +1074,7 @@ __device__ __forceinline__ void border_block(const ArgsT& A, const BorderArgs<T>
   }
 }
 
+
 }  // namespace
 
 // host side: plan (per problem, owned by the problem)
@@ -1103,6 +1083,7 @@ struct ZPlan {
   int regk = 0, regr = 0, reg_index = -1;
   bool subpix = false;  // sub-pixel shifts: residuals from k_forward_direct, z by 4-tap tables, exact ring by k_gather_direct
   int Dr = 0;           //   ring width
+  void* d_ringbuf = nullptr;   //   [C][ring pixels] data gradient of the ring pixels (the ring pass ahead of the tile kernel)
   double* d_spw = nullptr;
   ZSrc* d_spsrc = nullptr;     //   source-major tap table [S][spmax] (z_row_sp2)
   int spn[4] = {0, 0, 0, 0};

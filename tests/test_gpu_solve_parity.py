@@ -168,3 +168,63 @@ def test_fold_equals_separate_passes_over_geometries(sr, ctx, case):
         out[paced] = (x, rep.irls_rounds, rep.cg_iterations, rep.evaluations, rep.final_cost)
     assert out[0][1:] == out[1][1:]
     assert np.array_equal(out[0][0], out[1][0])
+
+
+# sub-pixel shifts (the case registration produces: motion_module.cpp:18-51 with fractional dx, dy) on the tile path:
+# (scale, blur, HR width, HR height, channels, shifts, regulariser, dtype)
+SP_FOLD_GEOMS = [
+    (4, 3, 256, 136, 1, [[0.5, 0.25], [-1.3, 2.71], [0.01, -0.99], [3.0, -2.5], [2.0, 1.0], [-0.03125, 0.96875]], (2, 0.01, 3, 0.5), 0),
+    (4, 3, 328, 72, 2, [[0.25 * k - 0.8, 1.1 - 0.35 * k] for k in range(7)], (2, 0.02, 2, 0.7), 0),
+    (3, 1, 201, 99, 1, [[0.75, -0.5], [1, 1], [-2.25, 0.125], [0.3, 0.3]], (0, 0.02, 0, 0.0), 0),
+    (2, 3, 130, 70, 1, [[0.5, 0.5], [-0.5, 1.5], [1.25, -1.75], [0, 0]], (2, 0.01, 1, 0.5), 0),
+    (4, 3, 256, 136, 1, [[0.5, 0.25], [-1.3, 2.71], [0.01, -0.99], [3.0, -2.5]], (2, 0.01, 3, 0.5), 1),
+]
+
+
+def _sp_problem(sr, ctx, case, impl=None):
+    s, b, W, H, C, shifts, reg, dtype = SP_FOLD_GEOMS[case]
+    rng = np.random.default_rng(1700 + case)
+    w, h = W // s, H // s
+    W, H = w * s, h * s
+    lr = rng.random((len(shifts), C, h, w))
+    x0 = rng.random((C, H, W))
+    p = sr.Problem(ctx, W, H, C, len(shifts), s, shifts, b, 1.0 if b > 1 else 0.0, dtype)
+    if impl is not None:
+        p.set_impl(impl)
+    p.set_observations(lr)
+    p.add_regularizer(*reg)
+    return p, x0
+
+
+@pytest.mark.parametrize("case", range(len(SP_FOLD_GEOMS)))
+def test_subpixel_fold_equals_separate_passes(sr, ctx, case):
+    """Sub-pixel plans: the FORWARD tile kernel forms the trial point x = xk + stp * d_i as it loads its window and writes
+    it out, the tile kernel behind it produces g.d with the gradient (the ring pass runs ahead of it into a side buffer).
+    Against host_paced_passes = 1 (a scaling pass stores d, k_axpy_out forms every trial point): same iterates bit for
+    bit, same counts."""
+    out = {}
+    for paced in (0, 1):
+        p, x0 = _sp_problem(sr, ctx, case)
+        opts = sr.default_irls_options()
+        opts.max_num_irls_iterations = 2
+        opts.max_num_solver_iterations = 6
+        opts.host_paced_passes = paced
+        x, rep = p.solve(x0, opts)
+        out[paced] = (x, rep.irls_rounds, rep.cg_iterations, rep.evaluations, rep.final_cost)
+    assert out[0][1:] == out[1][1:]
+    assert np.array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("case", [0, 2, 3])
+def test_subpixel_cg_on_tiles_follows_direct_kernels(sr, ctx, case):
+    """g.d out of the sub-pixel tile launch (interior from the phase tables, ring from the side buffer) against the direct
+    kernels, where cost and g.d come from separate reduction passes: a CG run follows evaluation for evaluation."""
+    res = {}
+    for name, impl in (("tiled", sr.IMPL_TILED), ("direct", sr.IMPL_DIRECT)):
+        p, x0 = _sp_problem(sr, ctx, case, impl)
+        x, its, nfev, term, trace = p.cg_trace(x0, 0.0, 0.0, 0.0, 4)
+        res[name] = (x, its, nfev, term, np.asarray(trace))
+    (x1, i1, n1, t1, tr1), (x2, i2, n2, t2, tr2) = res["tiled"], res["direct"]
+    assert (i1, n1, t1) == (i2, n2, t2) and len(tr1) == len(tr2)
+    assert np.max(np.abs(tr1 - tr2) / np.maximum(1.0, np.abs(tr2))) <= 1e-11
+    assert np.max(np.abs(x1 - x2)) <= 1e-9
