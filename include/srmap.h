@@ -320,6 +320,13 @@ typedef struct {
 int srmap_solve(srmap_problem* p, const srmap_irls_options* options,
                 const double* x0, double* x_out, srmap_solve_report* report);
 
+/* Self-check of the solver's derived sums (no reference counterpart).  mincg forms the DY / HS betas with the
+ * denominator y.dk summed over the vectors (optimization.cpp:17700-17760); this solver derives it from sums it already
+ * holds, y.dk = (g.d) / (s1 s2) - g_prev.dk.  With srmap_irls_options::host_paced_passes = 1 the beta pass ALSO sums y.dk
+ * directly; *beta_denominator_rel_dev receives the largest relative deviation |derived - direct| / |direct| seen by the
+ * host-paced solves of this problem so far (0 if none ran).  Expected: reduction-order level (<= 1e-12 f64, <= 1e-6 f32). */
+int srmap_problem_selfcheck(const srmap_problem* p, double* beta_denominator_rel_dev);
+
 /* ------------------------------------------------- multi-GPU (one rank per GPU) */
 /* The reference is single-process.  Its objective shards three ways (SURVEY.md
  * section 8e); a communicator carries the exchanges the sharded evaluation and the

@@ -962,6 +962,7 @@ static int launch_z(srmap_problem* p, const Geometry& geo, int obs_c0, unsigned 
   A.pub = mfin.publish ? p->eval_pub : nullptr;
   A.tag_slot = p->eval_pub_tag_slot;
   A.tag = p->eval_pub_tag;
+  A.to_host = p->eval_timeout_host;
   A.xpart = mfin.xpart; A.n_xpart = mfin.n_xpart;
   if (mfin.on && (size_t)A.n_partials > z.mpart_cap) return set_error(p->ctx, SRMAP_EHIP, "granule capacity");
   A.sel_mode = 0; A.sel0 = 0; A.sel1 = 0;

@@ -94,6 +94,7 @@ struct Fin {
   double* tag_slot;
   double tag;
   double* timeout_flag;   // sticky device word: a reduction gave up waiting for a block (srmap_solve reports it)
+  double* timeout_host;   // the same event for the host at once (host-mapped word: wait_tag ends the solve on it)
 };
 
 // Block partials of up to 3 sums (row 0 a max when max0).  Two-launch scheme: part[k * gridDim.x + blockIdx.x].
@@ -154,6 +155,7 @@ __device__ __forceinline__ bool block_partials3(double s0, double s1, double s2,
     const double qn = __builtin_nan("");
     red[0][0] = qn; red[1][0] = qn; red[2][0] = qn;
     if (fin.timeout_flag != nullptr) fin.timeout_flag[0] = 1.0;
+    if (fin.timeout_host != nullptr) *(volatile double*)fin.timeout_host = 1.0;
   }
   const double t0 = max0 ? fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]))
                          : (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
@@ -332,21 +334,26 @@ __global__ __launch_bounds__(256) void k_normalize(T* __restrict__ d, const T* _
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_beta_dots(const T* __restrict__ gp, const T* __restrict__ g,
                                                   size_t n, Owned ow, double* __restrict__ part, Fin fin,
-                                                  double* __restrict__ beta_dst, int restart, double vv) {
-  double b = 0, c = 0;
+                                                  double* __restrict__ beta_dst, int restart, double vv,
+                                                  const T* __restrict__ dk_check) {
+  // dk_check (host-paced passes only): the denominator y.dk summed directly as well, row [2] -- the self-check of the
+  // derived vv (srmap_problem_selfcheck); the betas still use the derived one, so both pacing modes stay bit-equal
+  double b = 0, c = 0, e = 0;
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * 256 * V) {
-    T gv[V], pv[V];
+    T gv[V], pv[V], kv[V];
     ldv<T, V, false>(g + i, gv);
     ldv<T, V, true>(gp + i, pv);
+    if (dk_check != nullptr) ldv<T, V, true>(dk_check + i, kv);
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       if (!ow.has(i + q)) continue;
       const T y = -pv[q] + gv[q];
       b += (double)gv[q] * (double)gv[q]; c += (double)gv[q] * (double)y;
+      if (dk_check != nullptr) e += (double)y * (double)kv[q];
     }
   }
   double tot[3];
-  if (block_partials3(b, c, 0.0, part, false, 2, fin, tot)) {
+  if (block_partials3(b, c, e, part, false, dk_check != nullptr ? 3 : 2, fin, tot)) {
     if (beta_dst != nullptr) {
       // betak = max(0, min(betady, betahs)) exactly as run_cg forms it on the host (same IEEE divisions and compares):
       // the direction pass queued behind this one reads it, the host never has to answer in between
@@ -620,7 +627,9 @@ struct DeviceCG {
     struct Acc { DeviceCG* c; std::chrono::steady_clock::time_point t; ~Acc() {
       c->wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); c->waits++; } } acc{this, t0};
     unsigned spins = 0;
+    volatile double* to = hs + 13;   // a device-side reduction of this solve timed out: its sums are NaN, its granules not re-armed
     while (!(*slot >= want)) {
+      if (*to != 0.0) return set_error(p->ctx, SRMAP_EHIP, "solver: a device-side reduction timed out waiting for a workgroup");
       if ((++spins & 0x3ff) == 0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
         SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
@@ -652,6 +661,7 @@ struct DeviceCG {
     if (rc) return rc;
     hs = p->ctx->h_scal;
     SRMAP_HIP(p->ctx, hipStreamSynchronize(st));
+    hs[13] = 0.0;  // time-out word of this solve (Fin::timeout_host, ZArgs::to_host)
     tag = hs[15];  // tags keep increasing across solves of one context: a stale word can never match
     return SRMAP_OK;
   }
@@ -675,7 +685,7 @@ struct DeviceCG {
     if (fused()) {
       tag += 1.0;
       f.gran = gran; f.out = out ? out : hs; f.cost_src = with_cost ? (const double*)p->d_cost : nullptr;
-      f.timeout_flag = dscal + 15;
+      f.timeout_flag = dscal + 15; f.timeout_host = hs + 13;
       f.pub_src = pub_src; f.pub_dst = pub_dst; f.pub_n = pub_n;
       f.tag_slot = hs + 15; f.tag = tag;
     }
@@ -725,6 +735,7 @@ struct DeviceCG {
     p->eval_pub = (!reduce_scalars && p->eval_dvec != nullptr) ? hs : nullptr;
     p->eval_pub_tag_slot = hs + 15;
     p->eval_pub_tag = tag + 1.0;
+    p->eval_timeout_host = hs + 13;
     // fold: `dir` is the UNNORMALISED direction dk; the kernel scales it by the factors it derives from the norms the
     // direction pass left at dscal[4..5] (norm_factors / norm_elem: the bits of the stored d)
     p->eval_fold_xk = (fold_xk != nullptr && p->eval_dvec != nullptr) ? fold_xk : nullptr;
@@ -735,6 +746,7 @@ struct DeviceCG {
     p->eval_fold_norms = nullptr;
     p->eval_dvec = nullptr;
     p->eval_pub = nullptr;
+    p->eval_timeout_host = nullptr;
     published = p->eval_published;
     if (published) tag += 1.0;
     return rc;
@@ -787,7 +799,7 @@ struct DeviceCG {
     if (fused()) {
       tag += 1.0;
       dir_tag = tag;
-      f.gran = gran; f.out = dscal + 4; f.timeout_flag = dscal + 15;
+      f.gran = gran; f.out = dscal + 4; f.timeout_flag = dscal + 15; f.timeout_host = hs + 13;
       if (publish_cost) { f.pub_src = (const double*)p->d_cost; f.pub_dst = hs; f.pub_n = 1; }  // hs[0] = f
       f.tag_slot = hs + 15; f.tag = tag;
     }
@@ -1120,12 +1132,15 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
       // host: gp.dk is the direction pass's g.dn, g.dk = (g.d) / (s2 s1) with the accepted evaluation's g.d (k_beta_dots)
       const double vv = (dg_acc / ns2) / ns1 - gdk;
       double* beta_dst = chain ? cg.dscal + 8 : (double*)nullptr;
+      // host-paced passes: the pass also sums y.dk directly (one more vector read) and the deviation of the derived
+      // denominator from it is recorded (srmap_problem_selfcheck; tests/test_gpu_solve_parity.py)
+      const T* dk_chk = chain ? (const T*)nullptr : (const T*)cg.dk;
       if (cg.vec())
         hipLaunchKernelGGL((k_beta_dots<T, DeviceCG<T>::kVec>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
-                           n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart, vv);
+                           n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart, vv, dk_chk);
       else
         hipLaunchKernelGGL((k_beta_dots<T, 1>), dim3(cg.nb()), dim3(256), 0, cg.st, (const T*)cg.gp, (const T*)cg.g,
-                           n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart, vv);
+                           n, cg.ow, cg.part, cg.fin_host(false), beta_dst, restart, vv, dk_chk);
       if (chain) {
         const double tag_beta = cg.tag;
         rc = cg.direction(cg.dk, 0.0, false, cg.dscal + 8);  // dn, sums of dn (device)
@@ -1134,11 +1149,13 @@ static int run_cg(DeviceCG<T>& cg, double epsg, double epsf, double epsx, int ma
         if (rc) return rc;
         gg = cg.hs[0];
       } else {
-        double h[2];
-        rc = cg.finish(2, false, false, h);
+        double h[3];
+        rc = cg.finish(3, false, false, h);
         if (rc) return rc;
         betak = dmax(0.0, dmin(h[0] / vv, h[1] / vv));
         gg = h[0];
+        if (h[2] != 0.0 && std::isfinite(h[2]) && std::isfinite(vv))
+          cg.p->selfcheck_beta_den = dmax(cg.p->selfcheck_beta_den, std::fabs(vv - h[2]) / std::fabs(h[2]));
       }
     } else {
       if (cg.vec())
@@ -1316,11 +1333,11 @@ static int solve_typed(srmap_problem* p, srmap_comm* comm, const srmap_shard_des
     // A reduction that gave up waiting for a workgroup (the tile kernel's in-kernel finish: sticky word d_cost[6]; a CG
     // pass: dscal[15]) left NaN sums behind -- the stopping rules ended the run -- and its granules un-re-armed.  The
     // evaluations inside a solve never look at the word (they pass no cost pointer): look now, re-initialise, report.
-    double flags[2] = {0.0, 0.0};
+    // Both kinds of finisher also raise the host-mapped word hs[13] (wait_tag ends the solve on it at once): no device
+    // copy on the successful path.
     (void)hipStreamSynchronize(st);
-    if (p->d_cost) (void)hipMemcpy(&flags[0], p->d_cost + 6, sizeof(double), hipMemcpyDeviceToHost);
-    if (cg.dscal) (void)hipMemcpy(&flags[1], cg.dscal + 15, sizeof(double), hipMemcpyDeviceToHost);
-    if (flags[0] != 0.0 || flags[1] != 0.0) {
+    if (cg.hs != nullptr && cg.hs[13] != 0.0) {
+      cg.hs[13] = 0.0;
       (void)hipDeviceSynchronize();
       ztile_rearm(p);
       if (p->d_cost) (void)hipMemset(p->d_cost + 6, 0, sizeof(double));

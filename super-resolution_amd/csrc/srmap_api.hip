@@ -860,6 +860,12 @@ int srmap_solve_sharded(srmap_problem* p, srmap_comm* comm, const srmap_shard_de
   return solve_impl(p, comm, shard, &o, x0, x_out, report);
 }
 
+int srmap_problem_selfcheck(const srmap_problem* p, double* beta_denominator_rel_dev) {
+  if (!p || !beta_denominator_rel_dev) return SRMAP_EINVAL;
+  *beta_denominator_rel_dev = p->selfcheck_beta_den;
+  return SRMAP_OK;
+}
+
 int srmap_solve(srmap_problem* p, const srmap_irls_options* options, const double* x0, double* x_out,
                 srmap_solve_report* report) {
   return srmap_solve_sharded(p, nullptr, nullptr, options, x0, x_out, report);

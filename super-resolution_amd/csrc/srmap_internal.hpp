@@ -114,6 +114,8 @@ struct srmap_problem {
   // {cost, g.d} to, followed by the arrival tag (saves the separate publish launch); eval_published reports it did
   double* eval_pub = nullptr;
   double* eval_pub_tag_slot = nullptr;
+  double selfcheck_beta_den = 0.0;   // largest relative deviation of the derived beta denominator from the directly summed one
+  double* eval_timeout_host = nullptr;   // host-mapped word the in-kernel finish raises when it gives up waiting (solver)
   double eval_pub_tag = 0.0;
   bool eval_published = false;
   // stream ordering of the device STATE an evaluation reads (observations, IRLS weights): state_ev is recorded on the

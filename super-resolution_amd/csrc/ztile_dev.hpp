@@ -224,7 +224,7 @@ __device__ __forceinline__ void finish_block(const ArgsT& A, double* red /* LDS,
   // would publish into a re-armed slot and the next evaluation would consume that stale partial; the granules stay as
   // they are, cost_out[0] is NaN, the sticky word cost_out[6] tells the host to re-initialise them (srmap_api.hip).
   if (timed_out) {
-    if (tid == 0) { A.cost_out[0] = __builtin_nan(""); A.cost_out[6] = 1.0; if (WD && A.pub != nullptr) { A.pub[0] = A.cost_out[0]; A.pub[1] = 0.0; __threadfence_system(); *(volatile double*)A.tag_slot = A.tag; } }
+    if (tid == 0) { A.cost_out[0] = __builtin_nan(""); A.cost_out[6] = 1.0; if (A.to_host != nullptr) *(volatile double*)A.to_host = 1.0; if (WD && A.pub != nullptr) { A.pub[0] = A.cost_out[0]; A.pub[1] = 0.0; __threadfence_system(); *(volatile double*)A.tag_slot = A.tag; } }
     return;
   }
   for (int i = tid; i < A.n_partials; i += NT) {
@@ -304,6 +304,7 @@ struct ZArgs {
   double* pub;           // solver line search: host-mapped {cost, g.d}, then the arrival tag
   double* tag_slot;
   double tag;
+  double* to_host;       // host-mapped word raised when the in-kernel finish times out (solver: the solve ends at once)
   const double* xpart;   // plain cost partials of an EARLIER launch on the stream (sub-pixel path: the forward kernel's data
   int n_xpart;           //   cost), complete when this kernel starts: the in-kernel finish adds them, in index order
   // ---- solver line search (WD instances): the trial point x = fold_xk + fold_stp * dvec is formed when the window goes

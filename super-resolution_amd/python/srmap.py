@@ -100,6 +100,7 @@ _SIGNATURES = [
     ("srmap_synchronize", C.c_int, [C.c_void_p]),
     ("srmap_irls_options_default", None, [C.POINTER(IrlsOptions)]),
     ("srmap_solve", C.c_int, [C.c_void_p, C.POINTER(IrlsOptions), c_double_p, c_double_p, C.POINTER(SolveReport)]),
+    ("srmap_problem_selfcheck", C.c_int, [C.c_void_p, c_double_p]),
     ("srmap_comm_get_unique_id", C.c_int, [C.c_void_p, C.c_char_p]),
     ("srmap_comm_create_rccl", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("srmap_comm_create_host", C.c_int, [C.c_void_p, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_SENDRECV_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -354,6 +355,12 @@ class Problem:
                                             out.ctypes.data_as(c_double_p), C.byref(rep))
         self.ctx.check(st)
         return out, rep
+
+    def selfcheck(self):
+        """Largest relative deviation of the solver's derived beta denominator from the directly summed y.dk (host-paced solves)."""
+        v = C.c_double(0.0)
+        self.ctx.check(load().srmap_problem_selfcheck(self._h, C.byref(v)))
+        return v.value
 
     def eval_sharded_device(self, comm, shard, x_ptr, g_ptr, terms=TERM_ALL, want_cost=False, stream=None):
         cost = C.c_double()
