@@ -593,7 +593,7 @@ def main():
                                             "FETCH_SIZE correction of MI355X_MICROARCH.md") if traffic_src else None,
                          "algorithmic_bytes_per_step": b_alg * share,
                          "kernel": "whole evaluation (every kernel of one step: k_eval_z with its in-kernel reduction), HIP "
-                                   "events on the launch stream; the dominant kernel alone is in profiles/r05_bench_*_kernel_stats.csv"},
+                                   "events on the launch stream; the dominant kernel alone is in profiles/r06_bench_*_kernel_stats.csv"},
         }
         if second is not None:
             out["frames_variant"] = {"value": 1.0 / second["wall_per_step"], "unit": "MAP gradient iterations/s",
