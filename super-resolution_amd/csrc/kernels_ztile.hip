@@ -66,6 +66,10 @@
 #ifndef SRMAP_ZT_ONLY_T
 #define SRMAP_ZT_ONLY_T double
 #endif
+//   SRMAP_ZT_ONLY_B     with SRMAP_ZT_ONLY_CFG2: the blur size of that one instance (default 3; 1 = the cfg3 / cfg5 instance)
+#ifndef SRMAP_ZT_ONLY_B
+#define SRMAP_ZT_ONLY_B 3
+#endif
 #ifndef SRMAP_EXP_F32_WPE
 #define SRMAP_EXP_F32_WPE 6
 #endif
@@ -1019,7 +1023,7 @@ static void preload_reg(int regk, int regr) {
 template <typename T>
 static void preload_sb(int S, int B, int regk, int regr) {
 #ifdef SRMAP_ZT_ONLY_CFG2
-  if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == 3 && regk == 2 && regr == 3) preload_z<SRMAP_ZT_ONLY_T, 4, 3, 2, 3>();
+  if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == SRMAP_ZT_ONLY_B && regk == 2 && regr == 3) preload_z<SRMAP_ZT_ONLY_T, 4, SRMAP_ZT_ONLY_B, 2, 3>();
   return;
 #else
   if (S == 2 && B == 1) preload_reg<T, 2, 1>(regk, regr);
@@ -1124,8 +1128,8 @@ int launch_eval_ztile(srmap_problem* p, const Geometry& geo, int obs_c0, unsigne
   mfin.n_xpart = (mfin.on && sp_data) ? nfwd : 0;
   auto tiles = [&]() {
 #ifdef SRMAP_ZT_ONLY_CFG2
-    if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == 3 && regk == 2 && regr == 3)
-      return launch_z<SRMAP_ZT_ONLY_T, 4, 3, 2, 3>(p, geo, obs_c0, zterms, (const SRMAP_ZT_ONLY_T*)x, (SRMAP_ZT_ONLY_T*)g,
+    if (sizeof(T) == sizeof(SRMAP_ZT_ONLY_T) && S == 4 && B == SRMAP_ZT_ONLY_B && regk == 2 && regr == 3)
+      return launch_z<SRMAP_ZT_ONLY_T, 4, SRMAP_ZT_ONLY_B, 2, 3>(p, geo, obs_c0, zterms, (const SRMAP_ZT_ONLY_T*)x, (SRMAP_ZT_ONLY_T*)g,
                                                    (const SRMAP_ZT_ONLY_T*)wts, z, partials, &nb, st, (const SRMAP_ZT_ONLY_T*)dv, pgd,
                                                    mfin, ring_ahead);
     return set_error(p->ctx, SRMAP_EUNSUPPORTED, "measurement build: cfg2 instance only");
