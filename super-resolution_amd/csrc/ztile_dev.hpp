@@ -49,6 +49,25 @@ __device__ __forceinline__ float absv<float>(float d) { return __builtin_fabsf(d
 template <>
 __device__ __forceinline__ double absv<double>(double d) { return __builtin_fabs(d); }
 
+// Pin a set of accumulators at this point of the program: what was computed into them so far is complete here and no memory
+// access moves across.  Left alone the scheduler gathers the LDS reads of EVERY window row of a regulariser pass at its head
+// and the register allocation follows the window data in flight, not the arithmetic: with the two regulariser passes pinned
+// per row (round 6) the blur-free f64 instances drop from 116 to 72 VGPRs -- 6 waves per SIMD = three workgroups per CU at
+// their 53 KB of LDS -- and cfg3 runs 0.394 -> 0.358 ms, cfg5 77.5 -> 72.6 us per channel, f32 26.3 -> 25.6 us; the cfg2
+// instance (124 -> 126 VGPRs, 73.5 KB) is unchanged.  Same instructions, same results bit for bit.
+// SRMAP_EXP_PIN = bit mask for A/B builds: 1 = regulariser pass 1 (per window row), 2 = regulariser pass 2 (per neighbour
+// row), 4 = data term (per blur row: costs the cfg2 instance spills -- off).  0 = the schedule of rounds 3 - 5.
+#ifndef SRMAP_EXP_PIN
+#define SRMAP_EXP_PIN 3
+#endif
+template <int WHICH, typename T, int N>
+__device__ __forceinline__ void pin(T (&a)[N]) {
+  if ((SRMAP_EXP_PIN & WHICH) != 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]) : : "memory");
+  }
+}
+
 constexpr int zmax(int a, int b) { return a > b ? a : b; }
 constexpr int zceil(int a, int b) { return (a + b - 1) / b; }
 
@@ -481,6 +500,7 @@ __device__ __forceinline__ void z_row(const ArgsT& A, const T* __restrict__ xs, 
         }
       }
     }
+    pin<4>(bx);
   }
   const T unscale = Pre<T>::down(T(1));
   int cn[S];
@@ -807,6 +827,8 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
         if (FULL) dv[pc] = -sgn_pre<T>(dxv, T(1));
       }
     }
+    pin<1>(rv);
+    if (FULL) pin<1>(dv);
   }
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) {
@@ -900,6 +922,7 @@ __device__ __forceinline__ void reg_pass2z(T (&acc)[S], const T* __restrict__ xs
         else sum[pc] += cw[pc + RU] * sgn_pre<T>(x0v[pc] - xw[pc + RU], T(1));
       }
     }
+    pin<2>(sum);
   }
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) acc[pc] += sum[pc];
