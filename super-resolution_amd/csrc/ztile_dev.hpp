@@ -791,9 +791,28 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
   T x0v[S], rv[S], dv[S];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) { rv[pc] = T(0); dv[pc] = T(0); }
+  // BORDER (tiles at the right / bottom image edge): a tap beyond the image is the reference's skipped tap = a zero
+  // difference.  Rows: gr + i is wave-uniform -- a window row below the image is handled as a whole.  Columns: the image
+  // width and a thread's first column are multiples of S, so a tap column c = pc + j of an in-image cell lies beyond the
+  // image only if it crosses into a FOLLOWING cell (c >= S; with S = 2 the window reaches two cells on) and that cell does:
+  // a per-lane factor (1 / 0) per following cell on the crossing taps instead of two compares and two selects on every tap
+  // (the masked path cost the edge tiles 148 compare / select issues per wave; d * 1 = d and |d * 0| = 0,
+  // step(+-0) = 1/2: the same bits as the select).
+  static_assert(S - 1 + WIN < 3 * S, "a window tap reaches at most two cells beyond the thread's own");
+  const T mR1 = (!BORDER || gc0 + S < W) ? T(1) : T(0), mR2 = (!BORDER || gc0 + 2 * S < W) ? T(1) : T(0);
   // the window is walked row by row (i outer, j inner per pixel: the reference's summation order)
 #pragma unroll
   for (int i = 0; i <= WIN; ++i) {
+    if (BORDER && REGK == 2 && i > 0 && gr + i >= H) {  // uniform: every tap of this window row is skipped
+      if (FULL && sizeof(T) == 8 && i < R) {
+#pragma unroll
+        for (int pc = 0; pc < S; ++pc) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) dv[pc] += pw[i + j] * T(0.5);   // (sgn(0) + 1) / 2, as the masked path adds it
+        }
+      }
+      continue;
+    }
     T row[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) row[j] = xs[xi<C>(xrow + i, j) + lane];
@@ -808,7 +827,7 @@ __device__ __forceinline__ void reg_row(T (&acc)[S], double& cost, const T* __re
         for (int j = 0; j <= R; ++j) {
           if (i == 0 && j == 0) continue;  // |x0 - x0| = 0 and sgn(0) = 0
           T d = x0v[pc] - row[pc + j];
-          if (BORDER) d = ((gr + i < H) && (gc0 + pc + j < W)) ? d : T(0);  // skipped tap == zero difference
+          if (BORDER && pc + j >= S) d = d * ((pc + j) / S == 1 ? mR1 : mR2);  // skipped tap == zero difference
           rv[pc] += pw[i + j] * absv(d);
           if (FULL && i < R && j < R) {  // exclusive window in the gradient
             if (sizeof(T) == 8) dv[pc] += pw[i + j] * step_pre<T>(d);  // (sgn + 1) / 2: add with clamp + FMA, two f64 issues
